@@ -1,0 +1,173 @@
+/*
+ * rbr_hip.h -- C ABI of librbr_hip.so, the MI355X (gfx950) review-encoder hot path.
+ *
+ * Drop-in boundary.  The reference (H263/review-based-recommender) is pure Python on
+ * PyTorch and has no FFI of its own: the boundary it exposes is the nn.Module layer
+ * (SURVEY.md §8b).  Each entry point below replaces the ATen call sequence of one
+ * reference layer; the reference file:line it replaces is cited per function.  The
+ * Python modules in review-based-recommender_amd/ (same class names, ctor/forward
+ * signatures and state_dict keys as the reference) are the only callers.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host";
+ *   - tensors are dense row-major fp32 unless stated; ids are int64, masks are uint8
+ *     (torch.bool storage), argmax indices are int32;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are
+ *     asynchronous, nothing is allocated, freed or synchronised inside a call
+ *     (graph-capture safe);
+ *   - return value: 0 on success, otherwise a hipError_t / negative rbr error code;
+ *     rbr_last_error() returns a thread-local description.
+ */
+#ifndef RBR_HIP_H
+#define RBR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBR_MAX_WIDTHS 8
+
+#define RBR_PAD_SAME 0  /* odd kz, zero pad (kz-1)/2 each side: MyConv1d (deepconn/layers.py:41-44) */
+#define RBR_PAD_VALID 1 /* no padding, pool over L-kz+1:  GlobalAttention convs (dual_att/layers.py:68-79) */
+#define RBR_ACT_RELU 0
+#define RBR_ACT_TANH 1
+
+#define RBR_ERR_BAD_ARG (-1)
+#define RBR_ERR_UNSUPPORTED (-2)
+
+/* Shape of one TextCNN call: n_docs documents of L tokens, a [V, D] word table and
+ * n_widths conv banks (width-major output channel order, as torch.cat in
+ * deepconn/layers.py:58). */
+typedef struct rbr_textcnn_desc {
+    int32_t n_docs;
+    int32_t L;
+    int32_t D;
+    int32_t V;
+    int32_t n_widths;
+    int32_t kz[RBR_MAX_WIDTHS]; /* kernel width of bank w */
+    int32_t ch[RBR_MAX_WIDTHS]; /* output channels of bank w */
+    int32_t pad_mode;           /* RBR_PAD_* */
+    int32_t act;                /* RBR_ACT_* */
+    int32_t padding_idx;        /* table row that never receives gradient (nn.Embedding padding_idx); -1 = none */
+} rbr_textcnn_desc;
+
+int rbr_version(void);
+const char* rbr_last_error(void);
+
+/* ---- TextCNN encoder: WordEmbedding + masked_tensor + MyConv1d + ReLU/Tanh + MaxPool1d(seq_len)
+ *      replaces deepconn/layers.py:22-24 (embedding), deepconn/utils.py:49-61 (masked_fill),
+ *      layers.py:46-60 (multi-width conv1d + cat), layers.py:107-109 (ReLU, MaxPool1d) and their
+ *      narre/layers.py:119-153,365-401 twins; with RBR_PAD_VALID/RBR_ACT_TANH also the gated
+ *      convs of dual_att/layers.py:37-40,68-79.                                            ---- */
+
+/* number of floats of the packed-weight buffer / of the partial-max workspace for `d` */
+size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d);
+size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d);
+
+/* Stage 1: repack the per-width Conv1d weights W[w] ([ch[w], D, kz[w]], torch layout) into the
+ * MFMA tile-major image the conv kernel streams.  `W` is a HOST array of device pointers. */
+int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* packed, void* stream);
+
+/* Stage 2 (the dominant kernel): gather rows table[ids] (zero where mask==0 or out of range, scaled
+ * by gate[doc,l] when gate != NULL), run every conv width on the f32 MFMA pipe and max-pool each
+ * 32-token slab.  Writes partial (max, first-argmax) pairs: pval/pidx[partial_elems]. */
+int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                         const float* table, const float* packed, float* pval, int32_t* pidx, void* stream);
+
+/* Stage 3: reduce the slabs of each document, add the conv bias, apply the activation.
+ * feat[n_docs, C] (C = sum ch[w]); argmax[n_docs, C] = first position attaining the max.
+ * `bias` is a HOST array of device pointers (one [ch[w]] vector per width). */
+int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx,
+                              const float* const* bias, float* feat, int32_t* argmax, void* stream);
+
+/* Backward of the whole encoder from d_feat[n_docs, C], using the max-pool sparsity (the gradient
+ * of out[doc,c] reaches exactly one conv window).  Replaces convolution_backward, max_pool
+ * backward, masked_fill backward and embedding_dense_backward of loss.backward()
+ * (trainer/train_deepconn_pp.py:165).
+ *   dW[w]    [ch[w], D, kz[w]]  overwritten          (host arrays of device pointers)
+ *   dbias[w] [ch[w]]            overwritten
+ *   dtable   [V, D]             ACCUMULATED (caller zeroes); NULL = frozen embeddings
+ *   dgate    [n_docs, L]        ACCUMULATED (caller zeroes); NULL when gate == NULL
+ *   ws       workspace of rbr_textcnn_bwd_ws_floats(d) floats                                  */
+size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d);
+int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                    const float* table, const float* packed, const float* feat, const int32_t* argmax,
+                    const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,
+                    float* ws, void* stream);
+
+/* ---- Rating head: LastFeat x2 + FM  (deepconn/layers.py:156-165,189-209; narre.py:84-93,118-137)
+ *   ul = u_feat @ Wu + bu + Eu[u_id];  il = i_feat @ Wi + bi + Ei[i_id]
+ *   pred = (relu(ul*il) * drop) @ h + ub[u_id] + ib[i_id] + g
+ * drop [B,K] is the dropout multiplier (0 or 1/(1-p)) drawn by the caller; NULL = no dropout.
+ * ul, il [B,K] are saved for the backward.                                                  ---- */
+typedef struct rbr_head_params {
+    const float* Wu; const float* bu; const float* Eu;   /* [H,K] [K] [U,K] */
+    const float* Wi; const float* bi; const float* Ei;   /* [H,K] [K] [I,K] */
+    const float* h;  const float* g;                     /* [K]   [1] */
+    const float* ub; const float* ib;                    /* [U]   [I] */
+} rbr_head_params;
+
+typedef struct rbr_head_grads {
+    float* dWu; float* dbu; float* dEu;                  /* dEu/dEi/dub/dib ACCUMULATED (caller zeroes) */
+    float* dWi; float* dbi; float* dEi;
+    float* dh;  float* dg;
+    float* dub; float* dib;
+} rbr_head_grads;
+
+int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                      const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                      float* ul, float* il, float* pred, void* stream);
+
+/* d_ufeat/d_ifeat [B,H] overwritten; dense grads overwritten; embedding grads accumulated
+ * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx). */
+int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                      const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                      const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                      const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, void* stream);
+
+/* ---- NARRE review-level attention pool (narre.py:40-64)
+ *   e = ebd[other_id];  logit = relu(feat@W_rv + e@W_id + b1) @ h + b2
+ *   att = exp(logit) / (sum_R exp(logit) + 1e-8)   (unmasked, no max subtraction)
+ *   out = sum_R att * feat
+ * feat [B,R,H], other_id [B,R]; out [B,H], att [B,R]; hid [B,R,A] saved for backward.       ---- */
+typedef struct rbr_attn_params {
+    const float* W_rv; const float* W_id; const float* h; const float* b1; const float* b2; const float* ebd;
+} rbr_attn_params;                                       /* [H,A] [A,A] [A] [A] [1] [N,A] */
+
+typedef struct rbr_attn_grads {
+    float* dW_rv; float* dW_id; float* dh; float* db1; float* db2; float* debd; /* debd ACCUMULATED */
+} rbr_attn_grads;
+
+int rbr_review_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                        const rbr_attn_params* p, float* out, float* att, float* hid, void* stream);
+size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t A);
+int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                        const rbr_attn_params* p, const float* att, const float* hid, const float* d_out,
+                        const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat, float* ws,
+                        void* stream);
+
+/* ---- D-ATT gates (dual_att/layers.py:34-36,50 and 65-67,84)
+ * local : gate[b,l] = sigmoid(b0 + sum_{j<win} sum_e w[e,j] * x[b, l+j-(win-1)/2, e])   (zero padded)
+ * global: gate[b,l] = sigmoid(b0 + sum_l sum_e w[e,l] * x[b,l,e])  (one scalar per doc, broadcast over l)
+ * x = table[ids];  w is the Conv1d weight [1,E,win] / [1,E,L].                               ---- */
+int rbr_datt_local_gate_fwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
+                            const float* w, const float* b0, float* gate, void* stream);
+int rbr_datt_global_gate_fwd(int32_t B, int32_t L, int32_t E, const int64_t* ids, const float* table,
+                             const float* w, const float* b0, float* gate, void* stream);
+/* Backward of a gate from dgate[b,l] (for the global gate: summed over l inside).
+ * dw, db0 overwritten; dtable accumulated (row pad_idx excluded). ws: B*(E*win) / B*... floats, see .hip */
+size_t rbr_datt_gate_bwd_ws_floats(int32_t B, int32_t L, int32_t E, int32_t win, int32_t is_global);
+int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
+                            const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
+                            float* db0, float* dtable, float* ws, void* stream);
+int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids, const float* table,
+                             const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
+                             float* db0, float* dtable, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBR_HIP_H */

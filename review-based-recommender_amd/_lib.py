@@ -1,0 +1,193 @@
+"""ctypes binding of librbr_hip.so (the C ABI of include/rbr_hip.h).
+
+No fallback: `lib()` raises if the shared library is missing or lacks a symbol, and the
+helpers below raise if a tensor is not a contiguous HIP tensor of the expected dtype.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Sequence
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "librbr_hip.so")
+
+RBR_MAX_WIDTHS = 8
+PAD_SAME, PAD_VALID = 0, 1
+ACT_RELU, ACT_TANH = 0, 1
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class TextCNNDesc(C.Structure):
+    _fields_ = [
+        ("n_docs", C.c_int32), ("L", C.c_int32), ("D", C.c_int32), ("V", C.c_int32),
+        ("n_widths", C.c_int32),
+        ("kz", C.c_int32 * RBR_MAX_WIDTHS), ("ch", C.c_int32 * RBR_MAX_WIDTHS),
+        ("pad_mode", C.c_int32), ("act", C.c_int32), ("padding_idx", C.c_int32),
+    ]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib")]
+
+
+class HeadGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dWu", "dbu", "dEu", "dWi", "dbi", "dEi", "dh", "dg", "dub", "dib")]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W_rv", "W_id", "h", "b1", "b2", "ebd")]
+
+
+class AttnGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dW_rv", "dW_id", "dh", "db1", "db2", "debd")]
+
+
+_PP = C.POINTER(C.c_void_p)
+_DESC = C.POINTER(TextCNNDesc)
+i32 = C.c_int32
+
+# name -> (restype, argtypes); mirrors include/rbr_hip.h one to one
+SIGNATURES = {
+    "rbr_version": (C.c_int, []),
+    "rbr_last_error": (C.c_char_p, []),
+    "rbr_textcnn_packed_floats": (C.c_size_t, [_DESC]),
+    "rbr_textcnn_partial_elems": (C.c_size_t, [_DESC]),
+    "rbr_textcnn_pack": (C.c_int, [_DESC, _PP, c_f32p, c_stream]),
+    "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
+    "rbr_textcnn_pool_finalize": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, c_stream]),
+    "rbr_textcnn_bwd_ws_floats": (C.c_size_t, [_DESC]),
+    "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,
+                                  c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_pair_head_fwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
+                                    c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_pair_head_bwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
+                                    c_f32p, c_f32p, c_f32p, i32, i32, C.POINTER(HeadGrads), c_f32p, c_f32p, c_stream]),
+    "rbr_review_attn_fwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p,
+                                      c_f32p, c_stream]),
+    "rbr_review_attn_bwd_ws_floats": (C.c_size_t, [i32, i32, i32, i32]),
+    "rbr_review_attn_bwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p,
+                                      c_f32p, c_f32p, i32, C.POINTER(AttnGrads), c_f32p, c_f32p, c_stream]),
+    "rbr_datt_local_gate_fwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_datt_global_gate_fwd": (C.c_int, [i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_datt_gate_bwd_ws_floats": (C.c_size_t, [i32, i32, i32, i32, i32]),
+    "rbr_datt_local_gate_bwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p,
+                                          c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_datt_global_gate_bwd": (C.c_int, [i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p,
+                                           c_f32p, c_f32p, c_f32p, c_stream]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Loads librbr_hip.so once; raises RuntimeError (never falls back) when it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). This package has no CPU or eager fallback.")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                if os.environ.get("RBR_DEV_PARTIAL_LIB") == "1":   # bring-up only: symbol raises when called
+                    continue
+                raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().rbr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def dev_ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str) -> Optional[int]:
+    """Raw device pointer of a contiguous HIP tensor (None passes through as NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def ptr_array(tensors: Sequence[torch.Tensor], dtype: torch.dtype, name: str):
+    arr = (C.c_void_p * RBR_MAX_WIDTHS)()
+    for i, t in enumerate(tensors):
+        arr[i] = dev_ptr(t, dtype, f"{name}[{i}]")
+    return arr
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx) -> TextCNNDesc:
+    if len(kernel_sizes) > RBR_MAX_WIDTHS:
+        raise RuntimeError(f"at most {RBR_MAX_WIDTHS} kernel widths are supported")
+    d = TextCNNDesc()
+    d.n_docs, d.L, d.D, d.V = int(n_docs), int(L), int(D), int(V)
+    d.n_widths = len(kernel_sizes)
+    for i, (k, c) in enumerate(zip(kernel_sizes, channels)):
+        d.kz[i] = int(k)
+        d.ch[i] = int(c)
+    d.pad_mode, d.act = int(pad_mode), int(act)
+    d.padding_idx = -1 if padding_idx is None else int(padding_idx)
+    return d
+
+
+# --------------------------------------------------------------------------- kernel timing hooks
+class KernelTimer:
+    """Optional HIP-event timing of individual C-ABI calls on the current stream (bench.py)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    def start(self):
+        self.enabled = True
+        self.events = {}
+
+    def stop(self):
+        self.enabled = False
+
+    def record(self, name):
+        if not self.enabled:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((a, b))
+        a.record()
+        return b
+
+    def summary(self):
+        """name -> (calls, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+TIMER = KernelTimer()

@@ -1,0 +1,70 @@
+// rbr_common.h -- shared host/device definitions of librbr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/rbr_hip.h"
+
+namespace rbr {
+
+constexpr int kWave = 64;        // CDNA4 wavefront
+constexpr int kTile = 32;        // MFMA 32x32x2 f32: 32 token positions x 32 channel slots
+constexpr int kMaxTiles = 8;     // channel tiles per launch (8 x 16 accumulator VGPRs)
+constexpr int kMaxGroups = 4;    // launches per conv (<= 1024 output channels)
+constexpr int kMaxSlots = kMaxTiles * kTile;
+constexpr int kMaxKF = 9;        // widest conv window
+constexpr int kMaxPieces = kMaxTiles * kMaxKF;
+constexpr int kWavesPerWG = 4;
+
+// One launch of the conv kernel: <= kMaxTiles channel tiles over all wave-tiles of the batch.
+// Passed BY VALUE as a kernel argument (lives in SGPRs / the scalar cache).
+struct ConvPlan {
+    int n_docs, L, D, V;
+    int C;              // output channels of the whole conv (all groups)
+    int KF;             // frame taps: max kz
+    int P;              // frame left pad: row = l + s - P
+    int DC;             // embedding-dim chunk staged per piece
+    int nchunks;        // ceil(D / DC)
+    int wpd;            // wave-tiles (32-token slabs) per document
+    int total_wt;       // n_docs * wpd
+    int nslots_total;   // 32 * (tiles over all groups): row pitch of the partial-max workspace
+    int tile_base;      // first tile of this group in the packed image / workspace
+    int ntiles;         // tiles in this group
+    int npieces;        // (tap, tile) pairs streamed per embedding chunk
+    int pad_mode, act;
+    unsigned char piece_s[kMaxPieces];
+    unsigned char piece_t[kMaxPieces];
+    short slot_chan[kMaxSlots];        // global output channel of slot, -1 = padding slot
+    unsigned char slot_w[kMaxSlots];   // conv bank of the slot
+    unsigned char slot_off[kMaxSlots]; // frame tap of the channel's tap 0
+    unsigned char slot_kz[kMaxSlots];  // kernel width (0 = padding slot)
+    int n_widths;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
+};
+
+struct PtrArray {
+    const float* p[RBR_MAX_WIDTHS];
+};
+struct MutPtrArray {
+    float* p[RBR_MAX_WIDTHS];
+};
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// Builds the launch plans for `d`.  Returns the number of groups (0 on error, see rbr_last_error()).
+int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */);
+
+inline int choose_dc(int D) { return (D % 60 == 0) ? 60 : 20; }
+
+}  // namespace rbr
+
+#define RBR_CHECK_LAUNCH(what)                                   \
+    do {                                                         \
+        int _e = rbr::check_hip(hipGetLastError(), what);        \
+        if (_e) return _e;                                       \
+    } while (0)

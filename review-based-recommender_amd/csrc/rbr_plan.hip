@@ -1,0 +1,110 @@
+// rbr_plan.hip -- error plumbing and the channel-tile planner shared by forward and backward.
+#include "rbr_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace rbr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+static bool validate(const rbr_textcnn_desc* d) {
+    if (!d) { set_error("null descriptor"); return false; }
+    if (d->n_docs <= 0 || d->L <= 0 || d->D <= 0 || d->V <= 0) {
+        set_error("bad shape n_docs=%d L=%d D=%d V=%d", d->n_docs, d->L, d->D, d->V);
+        return false;
+    }
+    if (d->n_widths <= 0 || d->n_widths > RBR_MAX_WIDTHS) { set_error("n_widths=%d out of range", d->n_widths); return false; }
+    for (int w = 0; w < d->n_widths; ++w) {
+        if (d->kz[w] <= 0 || d->kz[w] > kMaxKF) { set_error("kernel width %d unsupported (1..%d)", d->kz[w], kMaxKF); return false; }
+        if (d->ch[w] <= 0) { set_error("bank %d has %d channels", w, d->ch[w]); return false; }
+        // the reference asserts odd widths for 'same' convs (deepconn/layers.py:39)
+        if (d->pad_mode == RBR_PAD_SAME && d->kz[w] % 2 == 0) { set_error("'same' conv needs odd kernel width, got %d", d->kz[w]); return false; }
+        if (d->pad_mode == RBR_PAD_VALID && d->kz[w] > d->L) { set_error("valid conv wider than the document"); return false; }
+    }
+    if (d->pad_mode != RBR_PAD_SAME && d->pad_mode != RBR_PAD_VALID) { set_error("pad_mode %d", d->pad_mode); return false; }
+    if (d->act != RBR_ACT_RELU && d->act != RBR_ACT_TANH) { set_error("act %d", d->act); return false; }
+    return true;
+}
+
+// Channel slots are ordered by ascending kernel width and cut into tiles of 32: a tile then only
+// streams the taps its widest member needs (3/5/7 x 50 channels -> 27 tap-tiles instead of 30).
+int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
+    if (!validate(d)) return 0;
+    int C = 0, KF = 0;
+    int ch_off[RBR_MAX_WIDTHS];
+    for (int w = 0; w < d->n_widths; ++w) { ch_off[w] = C; C += d->ch[w]; KF = std::max(KF, d->kz[w]); }
+    const int tiles_total = (C + kTile - 1) / kTile;
+    const int ngroups = (tiles_total + kMaxTiles - 1) / kMaxTiles;
+    if (ngroups > kMaxGroups) { set_error("%d output channels exceed the supported %d", C, kMaxGroups * kMaxSlots); return 0; }
+
+    std::vector<int> order(d->n_widths);
+    for (int w = 0; w < d->n_widths; ++w) order[w] = w;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d->kz[a] < d->kz[b]; });
+    struct Slot { int chan, w; };
+    std::vector<Slot> slots;
+    for (int w : order)
+        for (int c = 0; c < d->ch[w]; ++c) slots.push_back({ch_off[w] + c, w});
+
+    const int DC = choose_dc(d->D);
+    const int P = (d->pad_mode == RBR_PAD_SAME) ? (KF - 1) / 2 : 0;
+    for (int g = 0; g < ngroups; ++g) {
+        ConvPlan& p = plans[g];
+        memset(&p, 0, sizeof(p));
+        p.n_docs = d->n_docs; p.L = d->L; p.D = d->D; p.V = d->V;
+        p.C = C; p.KF = KF; p.P = P; p.DC = DC; p.nchunks = (d->D + DC - 1) / DC;
+        p.wpd = (d->L + kTile - 1) / kTile;
+        p.total_wt = d->n_docs * p.wpd;
+        p.nslots_total = tiles_total * kTile;
+        p.tile_base = g * kMaxTiles;
+        p.ntiles = std::min(kMaxTiles, tiles_total - p.tile_base);
+        p.pad_mode = d->pad_mode; p.act = d->act;
+        p.n_widths = d->n_widths;
+        for (int w = 0; w < d->n_widths; ++w) { p.kz[w] = d->kz[w]; p.ch[w] = d->ch[w]; p.ch_off[w] = ch_off[w]; }
+        int lo[kMaxTiles], hi[kMaxTiles];
+        for (int t = 0; t < p.ntiles; ++t) {
+            lo[t] = KF; hi[t] = -1;
+            for (int i = 0; i < kTile; ++i) {
+                const int gs = (p.tile_base + t) * kTile + i;
+                const int ls = t * kTile + i;
+                if (gs < (int)slots.size()) {
+                    const int w = slots[gs].w, kz = d->kz[w];
+                    const int off = (d->pad_mode == RBR_PAD_SAME) ? (KF - kz) / 2 : 0;
+                    p.slot_chan[ls] = (short)slots[gs].chan;
+                    p.slot_w[ls] = (unsigned char)w;
+                    p.slot_off[ls] = (unsigned char)off;
+                    p.slot_kz[ls] = (unsigned char)kz;
+                    lo[t] = std::min(lo[t], off);
+                    hi[t] = std::max(hi[t], off + kz - 1);
+                } else {
+                    p.slot_chan[ls] = -1;
+                }
+            }
+        }
+        // tap-major piece order: consecutive pieces of one tap reuse the same token rows
+        int np = 0;
+        for (int s = 0; s < KF; ++s)
+            for (int t = 0; t < p.ntiles; ++t)
+                if (s >= lo[t] && s <= hi[t]) { p.piece_s[np] = (unsigned char)s; p.piece_t[np] = (unsigned char)t; ++np; }
+        p.npieces = np;
+    }
+    return ngroups;
+}
+
+}  // namespace rbr
+
+extern "C" int rbr_version(void) { return 1; }
+extern "C" const char* rbr_last_error(void) { return rbr::g_err; }

@@ -1,0 +1,351 @@
+// textcnn_fwd.hip -- fused  embedding gather -> mask/gate -> multi-width conv1d -> max-pool
+// for gfx950 (MI355X), exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Replaces, for one batch of documents, the ATen sequence of the reference's NgramFeat
+// (models/deepconn/layers.py:123-136): aten::embedding (layers.py:23), masked_fill
+// (utils.py:60), transpose (layers.py:132), conv1d per width + cat (layers.py:55-58),
+// relu + max_pool1d (layers.py:107-109).  Nothing of shape [docs, L, D] or [docs, C, L]
+// is ever written to HBM: the only outputs are (max, argmax) per document and channel.
+//
+// Work decomposition
+//   wave-tile  = 32 consecutive token positions of one document (one MFMA M-block);
+//   workgroup  = 4 waves = 4 consecutive wave-tiles; one wave per SIMD, ~3 workgroups per CU;
+//   GEMM view  : out[pos, chan] = sum_{tap s} sum_{d} X[pos + s - P, d] * Wf[chan, s, d]
+//                M = positions, N = channel slots (tiles of 32), K = (tap, d).
+//   The K loop is cut into "pieces" = (embedding chunk dc of DC floats, tap s, channel tile t):
+//   a [32 slots][DC] weight block that all 4 waves share through a 2-deep LDS ring, 30 MFMAs per
+//   wave and piece (DC = 60).  Each wave keeps its own [32 + KF - 1][DC] slab of gathered token
+//   rows in LDS and re-reads it for every tap and tile of the chunk.
+//
+// MFMA operand mapping (v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k][j = l&31]):
+//   both operands are fetched with ONE ds_read_b128 per 4 MFMAs: lane (i, h) reads floats
+//   d0+4h .. d0+4h+3 of its row, and MFMA e (0..3) uses element e, i.e. sums the K pair
+//   {d0+e, d0+4+e}.  K order inside a chunk is a permutation -- legal because A and B agree.
+//   Row stride DC floats with DC/4 odd => the b128 reads are bank-conflict free.
+#include "rbr_common.h"
+
+namespace rbr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------ pack
+// packed[tile][s][dc][slot][dd] = W_w[chan_local][d = dc*DC+dd][j = s - off]   (0 outside)
+__global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrArray W, float* __restrict__ packed) {
+    const int DC = P.DC;
+    const long per_tile = (long)P.KF * P.nchunks * kTile * DC;
+    const long total = (long)P.ntiles * per_tile;
+    float* out = packed + (long)P.tile_base * per_tile;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int dd = (int)(r % DC); r /= DC;
+        const int slot = (int)(r % kTile); r /= kTile;
+        const int dc = (int)(r % P.nchunks); r /= P.nchunks;
+        const int s = (int)(r % P.KF);
+        const int t = (int)(r / P.KF);
+        const int ls = t * kTile + slot;
+        const int chan = P.slot_chan[ls];
+        float v = 0.f;
+        if (chan >= 0) {
+            const int w = P.slot_w[ls], kz = P.slot_kz[ls];
+            const int j = s - (int)P.slot_off[ls];
+            const int d = dc * DC + dd;
+            if (j >= 0 && j < kz && d < P.D) v = W.p[w][((long)(chan - P.ch_off[w]) * P.D + d) * kz + j];
+        }
+        out[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ conv
+template <int DC>
+__device__ __forceinline__ void mma_piece(f32x16& acc, const float* __restrict__ xa, const float* __restrict__ wb, int h) {
+    // xa / wb already include the lane's row and the 4*h column offset
+#pragma unroll
+    for (int q = 0; q < DC / 8; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 8 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(wb + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (DC % 8 == 4) {  // last 4 columns: lane half h takes columns DC-4+2h, DC-4+2h+1
+        const f32x2 a = *reinterpret_cast<const f32x2*>(xa - 4 * h + (DC - 4) + 2 * h);
+        const f32x2 b = *reinterpret_cast<const f32x2*>(wb - 4 * h + (DC - 4) + 2 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    }
+}
+
+template <int NT, int DC, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const long long* __restrict__ ids,
+                                                       const unsigned char* __restrict__ mask,
+                                                       const float* __restrict__ gate, const float* __restrict__ table,
+                                                       const float* __restrict__ packed, float* __restrict__ pval,
+                                                       int* __restrict__ pidx) {
+    static_assert(DC % 4 == 0 && (DC / 4) % 2 == 1, "row stride must be 4*odd floats (bank-conflict-free b128 reads)");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PIECE = kTile * DC;              // floats per weight piece
+    constexpr int PIECE_V4 = PIECE / 4;
+    constexpr int NLD = (PIECE_V4 + 255) / 256;    // float4 prefetch registers per thread
+    const int XR = kTile + P.KF - 1;               // token rows per wave slab
+    float* Ws = smem;                              // [2][32][DC]
+    float* Xs = smem + 2 * PIECE;                  // [4 waves][XR][DC]
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wt = blockIdx.x * kWavesPerWG + wave;   // global wave-tile
+    const bool active = wt < P.total_wt;              // wave-uniform
+    const int doc = active ? wt / P.wpd : 0;
+    const int l0 = active ? (wt % P.wpd) * kTile : 0;
+    const int L = P.L, D = P.D;
+    float* Xw = Xs + wave * XR * DC;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const long per_tile = (long)P.KF * P.nchunks * PIECE;
+    const float* wbase = packed + (long)P.tile_base * per_tile;
+    auto piece_src = [&](int dc, int pi) -> const float* {
+        const int s = P.piece_s[pi], t = P.piece_t[pi];
+        return wbase + ((long)(t * P.KF + s) * P.nchunks + dc) * PIECE;
+    };
+
+    f32x4 pre[NLD];
+    auto issue = [&](const float* src) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int v = tid + 256 * k;
+            if (v < PIECE_V4) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * v);
+        }
+    };
+    auto commit = [&](float* dst) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int v = tid + 256 * k;
+            if (v < PIECE_V4) *reinterpret_cast<f32x4*>(dst + 4 * v) = pre[k];
+        }
+    };
+
+    issue(piece_src(0, 0));
+    commit(Ws);
+    int cur = 0;
+
+    for (int dc = 0; dc < P.nchunks; ++dc) {
+        // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) -------------------------
+        if (active) {
+            if (VEC) {
+                constexpr int QPR = DC / 4;
+                for (int idx = lane; idx < XR * QPR; idx += 64) {
+                    const int row = idx / QPR, q = idx - row * QPR;
+                    const int p = l0 - P.P + row;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int d = dc * DC + 4 * q;
+                    if (p >= 0 && p < L && d < D) {
+                        const long tok = (long)doc * L + p;
+                        if (mask == nullptr || mask[tok]) {
+                            const long id = ids[tok];
+                            v = *reinterpret_cast<const f32x4*>(table + id * D + d);
+                            if (gate != nullptr) v *= gate[tok];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(Xw + row * DC + 4 * q) = v;
+                }
+            } else {
+                for (int idx = lane; idx < XR * DC; idx += 64) {
+                    const int row = idx / DC, dd = idx - row * DC;
+                    const int p = l0 - P.P + row;
+                    float v = 0.f;
+                    const int d = dc * DC + dd;
+                    if (p >= 0 && p < L && d < D) {
+                        const long tok = (long)doc * L + p;
+                        if (mask == nullptr || mask[tok]) {
+                            v = table[ids[tok] * D + d];
+                            if (gate != nullptr) v *= gate[tok];
+                        }
+                    }
+                    Xw[row * DC + dd] = v;
+                }
+            }
+        }
+        __syncthreads();  // token rows + the pending weight piece are visible
+
+        for (int pi = 0; pi < P.npieces; ++pi) {
+            const bool last = (dc == P.nchunks - 1) && (pi == P.npieces - 1);
+            if (!last) {
+                const bool wrap = (pi + 1 == P.npieces);
+                issue(piece_src(wrap ? dc + 1 : dc, wrap ? 0 : pi + 1));  // lands while this piece computes
+            }
+            if (active) {
+                const int s = P.piece_s[pi], t = P.piece_t[pi];
+                const float* xa = Xw + (i + s) * DC + 4 * h;
+                const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    if (tt == t) mma_piece<DC>(acc[tt], xa, wb, h);
+            }
+            if (!last) commit(Ws + (cur ^ 1) * PIECE);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: max + first argmax over this wave's 32 positions, per channel slot --------------
+    if (!active) return;
+    const float NEG = -__builtin_huge_valf();
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        if (tt < P.ntiles) {
+            const int ls = tt * kTile + i;
+            const int kz = P.slot_kz[ls];
+            const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;   // pool length of this channel
+            float best = NEG;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // ascending position order; strict '>' keeps the first maximum
+                const int pos = l0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = acc[tt][r];
+                if (pos < Lv && v > best) { best = v; bidx = pos; }
+            }
+            const float ob = __shfl_xor(best, 32);
+            const int oi = __shfl_xor(bidx, 32);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            if (h == 0) {
+                const long o = (long)wt * P.nslots_total + (long)(P.tile_base + tt) * kTile + i;
+                pval[o] = best;
+                pidx[o] = bidx;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ finalize
+// one thread per (doc, slot): reduce the wpd slabs in position order, bias + activation.
+__global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, const float* __restrict__ pval,
+                                                            const int* __restrict__ pidx, const PtrArray bias,
+                                                            float* __restrict__ feat, int* __restrict__ argmax) {
+    const int nslots = P.ntiles * kTile;
+    const long total = (long)P.n_docs * nslots;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int doc = (int)(idx / nslots), ls = (int)(idx % nslots);
+        const int chan = P.slot_chan[ls];
+        if (chan < 0) continue;
+        const long base = (long)doc * P.wpd * P.nslots_total + (long)P.tile_base * kTile + ls;
+        float best = -__builtin_huge_valf();
+        int bidx = 0;
+        for (int w = 0; w < P.wpd; ++w) {
+            const float v = pval[base + (long)w * P.nslots_total];
+            if (v > best) { best = v; bidx = pidx[base + (long)w * P.nslots_total]; }
+        }
+        const int bw = P.slot_w[ls];
+        const float y = best + bias.p[bw][chan - P.ch_off[bw]];
+        const float f = (P.act == RBR_ACT_RELU) ? fmaxf(y, 0.f) : tanhf(y);
+        feat[(long)doc * P.C + chan] = f;
+        argmax[(long)doc * P.C + chan] = bidx;
+    }
+}
+
+template <int DC, bool VEC>
+static int launch_conv(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
+                       const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
+    const int XR = kTile + p.KF - 1;
+    const size_t smem = (size_t)(2 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float);
+    const dim3 grid((p.total_wt + kWavesPerWG - 1) / kWavesPerWG), block(256);
+#define RBR_LAUNCH(NT)                                                                                          \
+    case NT:                                                                                                    \
+        hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table,    \
+                           packed, pval, pidx);                                                                 \
+        break;
+    switch (p.ntiles) {
+        RBR_LAUNCH(1) RBR_LAUNCH(2) RBR_LAUNCH(3) RBR_LAUNCH(4) RBR_LAUNCH(5) RBR_LAUNCH(6) RBR_LAUNCH(7) RBR_LAUNCH(8)
+        default: set_error("ntiles=%d", p.ntiles); return RBR_ERR_UNSUPPORTED;
+    }
+#undef RBR_LAUNCH
+    RBR_CHECK_LAUNCH("textcnn conv_fwd launch");
+    return 0;
+}
+
+static size_t packed_floats(const ConvPlan& p0) {
+    return (size_t)(p0.nslots_total / kTile) * p0.KF * p0.nchunks * kTile * p0.DC;
+}
+
+}  // namespace rbr
+
+using namespace rbr;
+
+extern "C" size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return 0;
+    return packed_floats(plans[0]);
+}
+
+extern "C" size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return 0;
+    return (size_t)plans[0].total_wt * plans[0].nslots_total;
+}
+
+extern "C" int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* packed, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    const int ng = build_plans(d, plans);
+    if (!ng) return RBR_ERR_BAD_ARG;
+    if (!W || !packed) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    PtrArray wp{};
+    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
+    for (int g = 0; g < ng; ++g) {
+        const long total = (long)plans[g].ntiles * plans[g].KF * plans[g].nchunks * kTile * plans[g].DC;
+        const int blocks = (int)std::min<long>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, plans[g], wp, packed);
+        RBR_CHECK_LAUNCH("textcnn pack launch");
+    }
+    return 0;
+}
+
+extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
+                                    const float* gate, const float* table, const float* packed, float* pval,
+                                    int32_t* pidx, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    const int ng = build_plans(d, plans);
+    if (!ng) return RBR_ERR_BAD_ARG;
+    if (!ids || !table || !packed || !pval || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const bool vec = (d->D % 4 == 0) && (((uintptr_t)table & 15) == 0);
+    for (int g = 0; g < ng; ++g) {
+        int e;
+        const ConvPlan& p = plans[g];
+        const long long* ids64 = reinterpret_cast<const long long*>(ids);
+        if (p.DC == 60) {
+            e = vec ? launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream)
+                    : RBR_ERR_UNSUPPORTED;   // D % 60 == 0 implies D % 4 == 0; only a misaligned table gets here
+            if (e == RBR_ERR_UNSUPPORTED && !vec) { set_error("word table must be 16-byte aligned"); }
+        } else {
+            e = vec ? launch_conv<20, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream)
+                    : launch_conv<20, false>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
+        }
+        if (e) return e;
+    }
+    return 0;
+}
+
+extern "C" int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx,
+                                         const float* const* bias, float* feat, int32_t* argmax, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    const int ng = build_plans(d, plans);
+    if (!ng) return RBR_ERR_BAD_ARG;
+    if (!pval || !pidx || !bias || !feat || !argmax) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    PtrArray bp{};
+    for (int w = 0; w < d->n_widths; ++w) bp.p[w] = bias[w];
+    for (int g = 0; g < ng; ++g) {
+        const long total = (long)plans[g].n_docs * plans[g].ntiles * kTile;
+        const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(pool_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, plans[g], pval, pidx,
+                           bp, feat, argmax);
+        RBR_CHECK_LAUNCH("textcnn pool_finalize launch");
+    }
+    return 0;
+}

@@ -1,0 +1,130 @@
+"""torch.autograd.Functions over the C ABI (include/rbr_hip.h).  HIP tensors only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_RELU, ACT_TANH, PAD_SAME, PAD_VALID, TIMER, check, current_stream, dev_ptr, ptr_array
+
+F32, I64, I32, U8 = torch.float32, torch.int64, torch.int32, torch.uint8
+
+
+def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    if mask.dtype == torch.uint8:
+        return mask.contiguous()
+    raise RuntimeError(f"mask must be bool or uint8, got {mask.dtype}")
+
+
+class _TextCNN(torch.autograd.Function):
+    """feat[n_docs, C] = pool(act(conv(mask * gate * table[ids])))  -- see rbr_textcnn_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *wb):
+        n = len(kernel_sizes)
+        weights, biases = wb[:n], wb[n:]
+        if ids.dim() != 2:
+            raise RuntimeError("ids must be [n_docs, L]")
+        n_docs, L = ids.shape
+        V, D = table.shape
+        for k, w, b in zip(kernel_sizes, weights, biases):
+            assert w.shape[1] == D and w.shape[2] == k and b.shape[0] == w.shape[0]
+        channels = [w.shape[0] for w in weights]
+        Ctot = sum(channels)
+        desc = _lib.make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx)
+        L_ = _lib.lib()
+        dev = table.device
+        ids = ids.contiguous()
+        mask8 = _mask_u8(mask)
+        if mask8 is not None and mask8.shape != ids.shape:
+            raise AssertionError("inputs.shape[:-1] == masks.shape")   # deepconn/utils.py:58
+        if gate is not None:
+            gate = gate.contiguous()
+        table_c = table.contiguous()
+        ws = [w.contiguous() for w in weights]
+        bs = [b.contiguous() for b in biases]
+
+        n_packed = L_.rbr_textcnn_packed_floats(C.byref(desc))
+        n_part = L_.rbr_textcnn_partial_elems(C.byref(desc))
+        if n_packed == 0 or n_part == 0:
+            check(-1, "rbr_textcnn plan")
+        packed = torch.empty(n_packed, dtype=F32, device=dev)
+        pval = torch.empty(n_part, dtype=F32, device=dev)
+        pidx = torch.empty(n_part, dtype=I32, device=dev)
+        feat = torch.empty(n_docs, Ctot, dtype=F32, device=dev)
+        argmax = torch.empty(n_docs, Ctot, dtype=I32, device=dev)
+        st = current_stream()
+
+        check(L_.rbr_textcnn_pack(C.byref(desc), ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"), st),
+              "rbr_textcnn_pack")
+        ev = TIMER.record("textcnn_conv_fwd")
+        check(L_.rbr_textcnn_conv_fwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                      dev_ptr(gate, F32, "gate"), dev_ptr(table_c, F32, "word table"),
+                                      dev_ptr(packed, F32, "packed"), dev_ptr(pval, F32, "pval"),
+                                      dev_ptr(pidx, I32, "pidx"), st), "rbr_textcnn_conv_fwd")
+        if ev is not None:
+            ev.record()
+        check(L_.rbr_textcnn_pool_finalize(C.byref(desc), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
+                                           ptr_array(bs, F32, "conv bias"), dev_ptr(feat, F32, "feat"),
+                                           dev_ptr(argmax, I32, "argmax"), st), "rbr_textcnn_pool_finalize")
+        ctx.desc = desc
+        ctx.n = n
+        ctx.has_gate = gate is not None
+        ctx.has_mask = mask8 is not None
+        ctx.save_for_backward(table_c, ids, packed, feat, argmax, *([mask8] if mask8 is not None else []),
+                              *([gate] if gate is not None else []), *ws)
+        ctx.mark_non_differentiable(argmax)
+        return feat, argmax
+
+    @staticmethod
+    def backward(ctx, d_feat, _d_argmax):
+        saved = list(ctx.saved_tensors)
+        table, ids, packed, feat, argmax = saved[:5]
+        k = 5
+        mask8 = None
+        gate = None
+        if ctx.has_mask:
+            mask8 = saved[k]; k += 1
+        if ctx.has_gate:
+            gate = saved[k]; k += 1
+        ws = saved[k:]
+        desc = ctx.desc
+        L_ = _lib.lib()
+        dev = table.device
+        need_table = ctx.needs_input_grad[0]
+        need_gate = ctx.has_gate and ctx.needs_input_grad[1]
+        d_feat = d_feat.contiguous()
+        dWs = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
+        dtable = torch.zeros_like(table) if need_table else None
+        dgate = torch.zeros_like(gate) if need_gate else None
+        wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
+        wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
+        ev = TIMER.record("textcnn_bwd")
+        check(L_.rbr_textcnn_bwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                 dev_ptr(gate, F32, "gate"), dev_ptr(table, F32, "table"), dev_ptr(packed, F32, "packed"),
+                                 dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                 dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                 dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"),
+                                 dev_ptr(wsb, F32, "ws"), current_stream()), "rbr_textcnn_bwd")
+        if ev is not None:
+            ev.record()
+        return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
+
+
+def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor], weights: Sequence[torch.Tensor],
+            biases: Sequence[torch.Tensor], *, gate: Optional[torch.Tensor] = None, pad_mode: int = PAD_SAME,
+            act: int = ACT_RELU, padding_idx: Optional[int] = 0, return_argmax: bool = False):
+    """Fused WordEmbedding -> masked_tensor -> MyConv1d -> act -> MaxPool1d(seq_len).
+
+    table [V,D] f32; ids [n_docs,L] int64; mask [n_docs,L] bool or None; weights[w] [C_w,D,kz_w];
+    biases[w] [C_w].  Returns feat [n_docs, sum C_w] (width-major channels)."""
+    kernel_sizes = tuple(int(w.shape[2]) for w in weights)
+    feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *weights, *biases)
+    return (feat, argmax) if return_argmax else feat
