@@ -122,11 +122,13 @@ int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       float* ul, float* il, float* pred, void* stream);
 
 /* d_ufeat/d_ifeat [B,H] overwritten; dense grads overwritten; embedding grads accumulated
- * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx). */
+ * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx).
+ * ws: rbr_pair_head_bwd_ws_floats(B, K) floats. */
+size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K);
 int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                       const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
-                      const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, void* stream);
+                      const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream);
 
 /* ---- NARRE review-level attention pool (narre.py:40-64)
  *   e = ebd[other_id];  logit = relu(feat@W_rv + e@W_id + b1) @ h + b2

@@ -1,0 +1,174 @@
+// pair_head.hip -- rating head: LastFeat (user) + LastFeat (item) + FM, forward and backward.
+//
+// Replaces models/deepconn/layers.py:156-165 (text_feat @ W + b + ebd[id]) for both towers and
+// layers.py:189-209 (relu(u*i) -> dropout -> @h + user_bias[uid] + item_bias[iid] + g_bias), and the
+// identical classes of models/narre/narre.py:66-137.  The "FM" here is an elementwise product and a
+// K-long dot (K = latent_dim = 32), not an outer product: it is latency/HBM-bound VALU work, so it
+// runs one wave per (user,item) pair with shuffle reductions -- no MFMA.
+#include "rbr_common.h"
+
+namespace rbr {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per pair; lanes stride over the latent dimension K
+__global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
+                                                       const float* __restrict__ itf, const long long* __restrict__ uid,
+                                                       const long long* __restrict__ iid, const rbr_head_params p,
+                                                       const float* __restrict__ drop, float* __restrict__ ul,
+                                                       float* __restrict__ il, float* __restrict__ pred) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const long u = uid[b], it = iid[b];
+    float part = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float su = p.bu[k] + p.Eu[u * K + k];
+        float si = p.bi[k] + p.Ei[it * K + k];
+        for (int hh = 0; hh < H; ++hh) {
+            su = fmaf(uf[(long)b * H + hh], p.Wu[(long)hh * K + k], su);
+            si = fmaf(itf[(long)b * H + hh], p.Wi[(long)hh * K + k], si);
+        }
+        ul[(long)b * K + k] = su;
+        il[(long)b * K + k] = si;
+        float z = fmaxf(su * si, 0.f);
+        if (drop != nullptr) z *= drop[(long)b * K + k];
+        part = fmaf(z, p.h[k], part);
+    }
+    part = wave_sum(part);
+    if (lane == 0) pred[b] = part + p.ub[u] + p.ib[it] + p.g[0];
+}
+
+// per-pair part of the backward: d_ul, d_il (to workspace), embedding-row grads, d_feat
+__global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K, const long long* __restrict__ uid,
+                                                            const long long* __restrict__ iid, const rbr_head_params p,
+                                                            const float* __restrict__ drop, const float* __restrict__ ul,
+                                                            const float* __restrict__ il, const float* __restrict__ d_pred,
+                                                            int pad_u, int pad_i, const rbr_head_grads g,
+                                                            float* __restrict__ d_uf, float* __restrict__ d_if,
+                                                            float* __restrict__ ws_dul, float* __restrict__ ws_dil,
+                                                            float* __restrict__ ws_zdp) {
+    extern __shared__ float sm[];   // [4 waves][2][K]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;             // whole wave exits together; no block barrier below
+    float* s_dul = sm + wave * 2 * K;
+    float* s_dil = s_dul + K;
+    const long u = uid[b], it = iid[b];
+    const float dp = d_pred[b];
+    for (int k = lane; k < K; k += 64) {
+        const float su = ul[(long)b * K + k], si = il[(long)b * K + k];
+        const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
+        const float prod = su * si;
+        const float dz = (prod > 0.f) ? dp * p.h[k] * dr : 0.f;
+        const float dul = dz * si, dil = dz * su;
+        s_dul[k] = dul;
+        s_dil[k] = dil;
+        ws_dul[(long)b * K + k] = dul;
+        ws_dil[(long)b * K + k] = dil;
+        ws_zdp[(long)b * K + k] = fmaxf(prod, 0.f) * dr * dp;
+        if (u != pad_u) atomicAdd(g.dEu + u * K + k, dul);
+        if (it != pad_i) atomicAdd(g.dEi + it * K + k, dil);
+    }
+    if (lane == 0) {
+        if (u != pad_u) atomicAdd(g.dub + u, dp);
+        if (it != pad_i) atomicAdd(g.dib + it, dp);
+    }
+    __builtin_amdgcn_wave_barrier();   // LDS ops of one wave retire in order; keep the compiler from reordering
+    for (int hh = lane; hh < H; hh += 64) {
+        float a = 0.f, c = 0.f;
+        for (int k = 0; k < K; ++k) {
+            a = fmaf(s_dul[k], p.Wu[(long)hh * K + k], a);
+            c = fmaf(s_dil[k], p.Wi[(long)hh * K + k], c);
+        }
+        d_uf[(long)b * H + hh] = a;
+        d_if[(long)b * H + hh] = c;
+    }
+}
+
+// batch reductions in fixed order (bitwise reproducible): dW = feat^T @ d_l, db, dh, dg
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(int B, int H, int K, const float* __restrict__ uf,
+                                                              const float* __restrict__ itf,
+                                                              const float* __restrict__ d_pred,
+                                                              const float* __restrict__ ws_dul,
+                                                              const float* __restrict__ ws_dil,
+                                                              const float* __restrict__ ws_zdp, const rbr_head_grads g) {
+    const int rows = H + 1;                 // row H holds the bias / h reductions
+    const long total = 2L * rows * K;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % K);
+        const int r = (int)((idx / K) % rows);
+        const int side = (int)(idx / ((long)K * rows));
+        const float* dl = side ? ws_dil : ws_dul;
+        const float* ft = side ? itf : uf;
+        float s = 0.f;
+        if (r < H) {
+            for (int b = 0; b < B; ++b) s = fmaf(ft[(long)b * H + r], dl[(long)b * K + k], s);
+            (side ? g.dWi : g.dWu)[(long)r * K + k] = s;
+        } else {
+            for (int b = 0; b < B; ++b) s += dl[(long)b * K + k];
+            (side ? g.dbi : g.dbu)[k] = s;
+            if (side == 0) {
+                float hsum = 0.f;
+                for (int b = 0; b < B; ++b) hsum += ws_zdp[(long)b * K + k];
+                g.dh[k] = hsum;
+                if (k == 0) {
+                    float gs = 0.f;
+                    for (int b = 0; b < B; ++b) gs += d_pred[b];
+                    g.dg[0] = gs;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rbr
+
+using namespace rbr;
+
+static bool head_args_ok(int B, int H, int K) {
+    if (B <= 0 || H <= 0 || K <= 0) { set_error("bad head shape B=%d H=%d K=%d", B, H, K); return false; }
+    return true;
+}
+
+extern "C" int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                                 float* ul, float* il, float* pred, void* stream) {
+    if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
+    if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !pred) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, K, u_feat, i_feat,
+                       reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
+                       il, pred);
+    RBR_CHECK_LAUNCH("pair_head_fwd launch");
+    return 0;
+}
+
+extern "C" size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K) { return (size_t)3 * B * K; }
+
+extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                                 const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                                 const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
+    if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
+    if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !d_pred || !g || !d_ufeat || !d_ifeat || !ws) {
+        set_error("null pointer");
+        return RBR_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* ws_dul = ws;
+    float* ws_dil = ws + (size_t)B * K;
+    float* ws_zdp = ws + (size_t)2 * B * K;
+    hipLaunchKernelGGL(head_bwd_pair_kernel, dim3((B + 3) / 4), dim3(256), (size_t)8 * K * sizeof(float), st, B, H, K,
+                       reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
+                       il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, ws_dul, ws_dil, ws_zdp);
+    RBR_CHECK_LAUNCH("pair_head_bwd pair launch");
+    const long total = 2L * (H + 1) * K;
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, H, K, u_feat,
+                       i_feat, d_pred, ws_dul, ws_dil, ws_zdp, *g);
+    RBR_CHECK_LAUNCH("pair_head_bwd reduce launch");
+    return 0;
+}

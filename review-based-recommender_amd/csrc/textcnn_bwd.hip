@@ -1,0 +1,274 @@
+// textcnn_bwd.hip -- backward of the fused TextCNN encoder, exploiting max-pool sparsity.
+//
+// The reference back-propagates through MaxPool1d / ReLU / conv1d / masked_fill / embedding as
+// dense ops (loss.backward(), trainer/train_deepconn_pp.py:165; convolution_backward is 42 % of
+// its step).  Mathematically d(out[doc,c]) reaches exactly ONE conv window -- the one at
+// argmax[doc,c] -- so with g = d_feat * act'(feat):
+//     dbias[c]        = sum_doc g
+//     dW[c, :, j]     = sum_doc g * x[doc, l* + j - pad, :]           (x = mask * gate * table[ids])
+//     dtable[id, :]  += g * gate * W[c, :, j]      for id = ids[doc, l* + j - pad]  (not padding_idx)
+//     dgate[doc, p]  += g * <W[c, :, j], table[id, :]>
+// which is HBM/atomic-bound row traffic, not a GEMM.  Results equal the dense backward up to
+// fp32 summation order.
+//
+// Kernels
+//   dw_partial : grid (C, NCH).  One workgroup owns channel c and a contiguous range of documents;
+//                thread d keeps dW[c, d, 0..kz) in registers (no atomics), window rows are resolved
+//                once per 32 documents into LDS so the table reads are independent, coalesced loads.
+//   dw_reduce  : sums the NCH partial slabs in fixed order (bitwise reproducible) into torch layout.
+//   dx_scatter : grid (n_docs).  Entries (channel, tap) are resolved into LDS, then one WAVE per entry
+//                adds g*W[c,:,j] into the token's table row with 256-byte contiguous f32 atomics.
+#include "rbr_common.h"
+
+namespace rbr {
+
+constexpr int kDocsPerBatch = 32;
+constexpr int kMaxChunksBwd = 32;
+constexpr int kChanBatch = 128;   // channels resolved per LDS batch in dx_scatter
+
+__device__ __forceinline__ float act_grad(int act, float f, float d) {
+    return (act == RBR_ACT_RELU) ? (f > 0.f ? d : 0.f) : d * (1.f - f * f);
+}
+
+struct BwdArgs {
+    int n_docs, L, D, C, KF, DC, nchunks;
+    int pad_mode, act, padding_idx;
+    int n_widths;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
+    int rank_off[RBR_MAX_WIDTHS];   // first slot (kz-sorted channel order) of bank w in the packed image
+    int NCH, DPC;                   // document chunks of dw_partial and documents per chunk
+};
+
+__device__ __forceinline__ int bank_of(const BwdArgs& A, int c) {
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < A.n_widths && c >= A.ch_off[k]) w = k;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------ dW
+__global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const long long* __restrict__ ids,
+                                                         const unsigned char* __restrict__ mask,
+                                                         const float* __restrict__ gate, const float* __restrict__ table,
+                                                         const float* __restrict__ feat, const int* __restrict__ argmax,
+                                                         const float* __restrict__ d_feat, float* __restrict__ ws_w,
+                                                         float* __restrict__ ws_b) {
+    __shared__ long s_row[kDocsPerBatch * kMaxKF];
+    __shared__ float s_sc[kDocsPerBatch * kMaxKF];
+    __shared__ float s_g[kDocsPerBatch];
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int w = bank_of(A, c);
+    const int kz = A.kz[w];
+    const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
+    const int doc_begin = chunk * A.DPC;
+    const int doc_end = min(A.n_docs, doc_begin + A.DPC);
+    const int L = A.L, D = A.D, C = A.C;
+
+    float bsum = 0.f;
+    for (int dbase = 0; dbase < D; dbase += 256) {
+        const int d = dbase + tid;
+        float acc[kMaxKF];
+#pragma unroll
+        for (int j = 0; j < kMaxKF; ++j) acc[j] = 0.f;
+
+        for (int b0 = doc_begin; b0 < doc_end; b0 += kDocsPerBatch) {
+            const int nb = min(kDocsPerBatch, doc_end - b0);
+            __syncthreads();   // previous batch fully consumed
+            for (int e = tid; e < nb * kz; e += 256) {
+                const int dl = e / kz, j = e - dl * kz;
+                const long o = (long)(b0 + dl) * C + c;
+                const float g = act_grad(A.act, feat[o], d_feat[o]);
+                const int p = argmax[o] + j - padl;
+                long row = -1;
+                float sc = 0.f;
+                if (g != 0.f && p >= 0 && p < L) {
+                    const long tok = (long)(b0 + dl) * L + p;
+                    if (mask == nullptr || mask[tok]) {
+                        row = ids[tok] * (long)D;
+                        sc = (gate != nullptr) ? g * gate[tok] : g;
+                    }
+                }
+                s_row[e] = row;
+                s_sc[e] = sc;
+                if (j == 0) s_g[dl] = g;
+            }
+            __syncthreads();
+            if (dbase == 0 && tid == 0)
+                for (int dl = 0; dl < nb; ++dl) bsum += s_g[dl];   // fixed order
+            if (d < D) {
+                for (int dl = 0; dl < nb; ++dl) {
+#pragma unroll
+                    for (int j = 0; j < kMaxKF; ++j) {
+                        if (j < kz) {
+                            const long row = s_row[dl * kz + j];
+                            if (row >= 0) acc[j] = fmaf(s_sc[dl * kz + j], table[row + d], acc[j]);
+                        }
+                    }
+                }
+            }
+        }
+        if (d < D) {
+#pragma unroll
+            for (int j = 0; j < kMaxKF; ++j)
+                if (j < kz) ws_w[(((long)chunk * C + c) * A.KF + j) * D + d] = acc[j];
+        }
+    }
+    if (tid == 0) ws_b[(long)chunk * C + c] = bsum;
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const float* __restrict__ ws_w,
+                                                        const float* __restrict__ ws_b, const MutPtrArray dW,
+                                                        const MutPtrArray dbias) {
+    const long total = (long)A.C * A.KF * A.D;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % A.D);
+        const int j = (int)((idx / A.D) % A.KF);
+        const int c = (int)(idx / ((long)A.D * A.KF));
+        const int w = bank_of(A, c);
+        const int kz = A.kz[w];
+        if (j >= kz) continue;
+        float s = 0.f;
+        for (int k = 0; k < A.NCH; ++k) s += ws_w[(((long)k * A.C + c) * A.KF + j) * A.D + d];
+        dW.p[w][((long)(c - A.ch_off[w]) * A.D + d) * kz + j] = s;
+        if (j == 0 && d == 0) {
+            float b = 0.f;
+            for (int k = 0; k < A.NCH; ++k) b += ws_b[(long)k * A.C + c];
+            dbias.p[w][c - A.ch_off[w]] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ dtable / dgate
+__global__ __launch_bounds__(256) void dx_scatter_kernel(const BwdArgs A, const long long* __restrict__ ids,
+                                                         const unsigned char* __restrict__ mask,
+                                                         const float* __restrict__ gate, const float* __restrict__ table,
+                                                         const float* __restrict__ packed, const float* __restrict__ feat,
+                                                         const int* __restrict__ argmax, const float* __restrict__ d_feat,
+                                                         float* __restrict__ dtable, float* __restrict__ dgate) {
+    __shared__ long s_row[kChanBatch * kMaxKF];    // table row offset (id * D), -1 = no contribution
+    __shared__ long s_w[kChanBatch * kMaxKF];      // offset of W[c, 0, j] inside the packed image
+    __shared__ float s_g[kChanBatch * kMaxKF];     // g (without the gate)
+    __shared__ int s_tok[kChanBatch * kMaxKF];     // token index inside the document
+    const int doc = blockIdx.x, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int L = A.L, D = A.D, C = A.C, KF = A.KF, DC = A.DC;
+    const long piece = (long)kTile * DC;
+
+    for (int c0 = 0; c0 < C; c0 += kChanBatch) {
+        const int nc = min(kChanBatch, C - c0);
+        __syncthreads();
+        for (int e = tid; e < nc * KF; e += 256) {
+            const int cl = e / KF, j = e - cl * KF;
+            const int c = c0 + cl;
+            const int w = bank_of(A, c);
+            const int kz = A.kz[w];
+            long row = -1, woff = 0;
+            float g = 0.f;
+            int p = 0;
+            if (j < kz) {
+                const long o = (long)doc * C + c;
+                g = act_grad(A.act, feat[o], d_feat[o]);
+                const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
+                p = argmax[o] + j - padl;
+                if (g != 0.f && p >= 0 && p < L) {
+                    const long tok = (long)doc * L + p;
+                    if (mask == nullptr || mask[tok]) {
+                        row = ids[tok] * (long)D;
+                        const int slot = A.rank_off[w] + (c - A.ch_off[w]);   // kz-sorted slot of the channel
+                        const int off = (A.pad_mode == RBR_PAD_SAME) ? (KF - kz) / 2 : 0;
+                        const int t = slot / kTile, i = slot % kTile, s = j + off;
+                        woff = ((long)(t * KF + s) * A.nchunks) * piece + (long)i * DC;
+                    }
+                }
+            }
+            s_row[e] = row; s_w[e] = woff; s_g[e] = g; s_tok[e] = p;
+        }
+        __syncthreads();
+        for (int e = wave; e < nc * KF; e += 4) {   // one wave per (channel, tap) window row
+            const long row = s_row[e];
+            if (row < 0) continue;                   // wave-uniform
+            const float g = s_g[e];
+            const long woff = s_w[e];
+            const long tok = (long)doc * L + s_tok[e];
+            const float gv = (gate != nullptr) ? gate[tok] : 1.f;
+            const bool to_table = (dtable != nullptr) && (row != (long)A.padding_idx * D);
+            float dot = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                const int dc = d / DC, dd = d - dc * DC;
+                const float v = g * packed[woff + (long)dc * piece + dd];
+                if (to_table) atomicAdd(dtable + row + d, v * gv);
+                if (dgate != nullptr) dot = fmaf(v, table[row + d], dot);
+            }
+            if (dgate != nullptr) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                if (lane == 0) atomicAdd(dgate + tok, dot);
+            }
+        }
+    }
+}
+
+static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    const ConvPlan& p = plans[0];
+    memset(&A, 0, sizeof(A));
+    A.n_docs = d->n_docs; A.L = d->L; A.D = d->D; A.C = p.C; A.KF = p.KF; A.DC = p.DC; A.nchunks = p.nchunks;
+    A.pad_mode = d->pad_mode; A.act = d->act; A.padding_idx = d->padding_idx;
+    A.n_widths = d->n_widths;
+    for (int w = 0; w < d->n_widths; ++w) { A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = p.ch_off[w]; }
+    // slot rank of bank w = channels of all banks sorted before it (stable by kz), as build_plans orders them
+    for (int w = 0; w < d->n_widths; ++w) {
+        int r = 0;
+        for (int v = 0; v < d->n_widths; ++v)
+            if (d->kz[v] < d->kz[w] || (d->kz[v] == d->kz[w] && v < w)) r += d->ch[v];
+        A.rank_off[w] = r;
+    }
+    A.NCH = std::min(kMaxChunksBwd, (d->n_docs + kDocsPerBatch - 1) / kDocsPerBatch);
+    A.DPC = (d->n_docs + A.NCH - 1) / A.NCH;
+    A.NCH = (d->n_docs + A.DPC - 1) / A.DPC;
+    return 0;
+}
+
+}  // namespace rbr
+
+using namespace rbr;
+
+extern "C" size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d) {
+    BwdArgs A;
+    if (fill_args(d, A)) return 0;
+    return (size_t)A.NCH * A.C * A.KF * A.D + (size_t)A.NCH * A.C;
+}
+
+extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                               const float* table, const float* packed, const float* feat, const int32_t* argmax,
+                               const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,
+                               float* ws, void* stream) {
+    BwdArgs A;
+    if (int e = fill_args(d, A)) return e;
+    if (!ids || !table || !packed || !feat || !argmax || !d_feat || !dW || !dbias || !ws) {
+        set_error("null pointer");
+        return RBR_ERR_BAD_ARG;
+    }
+    if ((long)d->V * d->D <= 0) { set_error("bad table shape"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const long long* ids64 = reinterpret_cast<const long long*>(ids);
+    float* ws_w = ws;
+    float* ws_b = ws + (size_t)A.NCH * A.C * A.KF * A.D;
+    hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
+                       d_feat, ws_w, ws_b);
+    RBR_CHECK_LAUNCH("textcnn dw_partial launch");
+    MutPtrArray dWp{}, dbp{};
+    for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
+    const long total = (long)A.C * A.KF * A.D;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, A,
+                       ws_w, ws_b, dWp, dbp);
+    RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
+    if (dtable != nullptr || (dgate != nullptr && gate != nullptr)) {
+        hipLaunchKernelGGL(dx_scatter_kernel, dim3(A.n_docs), dim3(256), 0, st, A, ids64, mask, gate, table, packed, feat,
+                           argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
+        RBR_CHECK_LAUNCH("textcnn dx_scatter launch");
+    }
+    return 0;
+}

@@ -128,3 +128,80 @@ def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor]
     kernel_sizes = tuple(int(w.shape[2]) for w in weights)
     feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *weights, *biases)
     return (feat, argmax) if return_argmax else feat
+
+
+class _PairHead(torch.autograd.Function):
+    """pred[B] = FM(LastFeat_u(u_feat, u_id), LastFeat_i(i_feat, i_id))  -- rbr_pair_head_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib):
+        B, H = u_feat.shape
+        K = Wu.shape[1]
+        dev = u_feat.device
+        L_ = _lib.lib()
+        u_feat, i_feat = u_feat.contiguous(), i_feat.contiguous()
+        u_id, i_id = u_id.contiguous(), i_id.contiguous()
+        params = [t.contiguous() for t in (Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)]
+        hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(params, ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib"))])
+        if drop is not None:
+            drop = drop.contiguous()
+        ul = torch.empty(B, K, dtype=F32, device=dev)
+        il = torch.empty(B, K, dtype=F32, device=dev)
+        pred = torch.empty(B, dtype=F32, device=dev)
+        check(L_.rbr_pair_head_fwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
+                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                   dev_ptr(drop, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                   dev_ptr(pred, F32, "pred"), current_stream()), "rbr_pair_head_fwd")
+        ctx.dims = (B, H, K, int(pad_u), int(pad_i))
+        ctx.has_drop = drop is not None
+        ctx.save_for_backward(u_feat, i_feat, u_id, i_id, ul, il, *params, *([drop] if drop is not None else []))
+        return pred
+
+    @staticmethod
+    def backward(ctx, d_pred):
+        B, H, K, pad_u, pad_i = ctx.dims
+        saved = list(ctx.saved_tensors)
+        u_feat, i_feat, u_id, i_id, ul, il = saved[:6]
+        params = saved[6:16]
+        drop = saved[16] if ctx.has_drop else None
+        dev = u_feat.device
+        L_ = _lib.lib()
+        names = ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib")
+        hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(params, names)])
+        # embedding-style grads are accumulated with atomics -> start from zero; the rest is overwritten
+        grads = [torch.zeros_like(t) if n in ("Eu", "Ei", "ub", "ib") else torch.empty_like(t)
+                 for t, n in zip(params, names)]
+        hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
+        d_uf = torch.empty_like(u_feat)
+        d_if = torch.empty_like(i_feat)
+        ws = torch.empty(L_.rbr_pair_head_bwd_ws_floats(B, K), dtype=F32, device=dev)
+        d_pred = d_pred.contiguous()
+        check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
+                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                   dev_ptr(drop, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                   dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
+                                   dev_ptr(d_uf, F32, "d_ufeat"), dev_ptr(d_if, F32, "d_ifeat"), dev_ptr(ws, F32, "ws"),
+                                   current_stream()), "rbr_pair_head_bwd")
+        return (d_uf, d_if, None, None, None, None, None, *grads)
+
+
+def pair_head(u_feat, i_feat, u_id, i_id, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib, *, drop=None, pad_u=0, pad_i=0):
+    """LastFeat x2 + FM.  u_feat/i_feat [B,H]; ids [B] int64; returns pred [B]."""
+    return _PairHead.apply(u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)
+
+
+def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torch.Tensor]:
+    """The multiplier F.dropout would apply (0 or 1/(1-p)), drawn from torch's HIP generator."""
+    if not training or p <= 0.0:
+        return None
+    if p >= 1.0:
+        return torch.zeros(shape, dtype=F32, device=device)
+    return torch.empty(shape, dtype=F32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+def embedding(table, ids, padding_idx=0):
+    raise RuntimeError("standalone embedding gather kernel is not part of this build yet")
+
+
+def hier_pool(table, ids, masks, kernel_size, proj_w, proj_b, padding_idx=0):
+    raise RuntimeError("HierPooling kernel is not part of this build yet")

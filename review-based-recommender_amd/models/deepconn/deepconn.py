@@ -1,0 +1,35 @@
+"""DeepCoNN++ with the reference's constructor / forward signature and state_dict keys
+(models/deepconn/deepconn.py:10-53), running on the HIP kernels of csrc/."""
+import torch
+import torch.nn as nn
+
+from .layers import FM, LastFeat, NgramFeat, WordEmbedding, rating_head
+
+
+class DeepCoNNpp(nn.Module):
+    def __init__(self, user_size, item_size, vocab_size, kernel_sizes, embedding_dim, hidden_dim, latent_dim, doc_len,
+                 pretrained_embeddings, dropout, arch="CNN"):
+        super().__init__()
+        self.user_size = user_size
+        self.item_size = item_size
+        self.vocab_size = vocab_size
+        self.hidden_dim = hidden_dim
+
+        self.word_embeddings = WordEmbedding(vocab_size, embedding_dim, pretrained_embeddings=pretrained_embeddings)
+        self.ngram = NgramFeat(kernel_sizes, embedding_dim, hidden_dim, doc_len, arch=arch)
+        self.user_feat = LastFeat(user_size, hidden_dim, latent_dim, padding_idx=0)
+        self.item_feat = LastFeat(item_size, hidden_dim, latent_dim, padding_idx=0)
+        self.fm = FM(user_size, item_size, latent_dim, dropout, user_padding_idx=0, item_padding_idx=0)
+
+    def forward(self, u_revs, i_revs, u_rev_masks, i_rev_masks, u_ids, i_ids):
+        """u_revs/i_revs [bz, doc_len] int64, masks [bz, doc_len] bool, ids [bz] -> preds [bz].
+
+        Both towers share the table and the TextCNN (deepconn.py:43-47), so the user and item
+        documents go through ONE launch of the fused gather+conv+pool kernel as a 2*bz batch."""
+        bz = u_revs.shape[0]
+        ids = torch.cat([u_revs, i_revs], dim=0)
+        masks = torch.cat([u_rev_masks, i_rev_masks], dim=0)
+        feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
+        u_rev_feats, i_rev_feats = feats[:bz], feats[bz:]
+        preds = rating_head(self.user_feat, self.item_feat, self.fm, u_rev_feats, i_rev_feats, u_ids, i_ids)
+        return preds.view(bz)

@@ -1,0 +1,167 @@
+"""Layer classes with the reference's names, constructor arguments, parameter names and
+shapes (models/deepconn/layers.py), backed by the HIP kernels of csrc/.
+
+The classes own ordinary nn.Parameters so optimisers, clip_grad_norm_, state_dict and
+.to(device) behave exactly as with the reference modules.  Compute happens in
+review_based_recommender_amd.functional (no ATen conv / embedding / matmul on the path).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ... import functional as RF
+
+
+class WordEmbedding(nn.Module):
+    """layers.py:9-24: nn.Embedding(V, D, padding_idx) table; optional pretrained rows; freeze flag."""
+
+    def __init__(self, vocab_size, embedding_dim, pretrained_embeddings=None, padding_idx=0, freeze_embeddings=False):
+        super().__init__()
+        self.freeze_embeddings = freeze_embeddings
+        self.padding_idx = padding_idx
+        # nn.Embedding is kept as the parameter container (state_dict key `embedding.weight`,
+        # default N(0,1) init with a zero pad row); its forward is never used.
+        self.embedding = nn.Embedding(vocab_size, embedding_dim, padding_idx=padding_idx)
+        self.embedding.weight.requires_grad = not self.freeze_embeddings
+        if pretrained_embeddings is not None:
+            self.embedding.load_state_dict({"weight": torch.as_tensor(pretrained_embeddings)})
+        else:
+            print("[Warning] not use pretrained embeddings ...")
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.embedding.weight
+
+    def forward(self, inputs):
+        """Materialised lookup [*, D] for callers that want the rows themselves (HIP row gather)."""
+        return RF.embedding(self.embedding.weight, inputs, self.padding_idx)
+
+
+class MyConv1d(nn.Module):
+    """layers.py:26-60: one nn.Conv1d parameter set per (odd) kernel width, `"3,5,7"` strings allowed."""
+
+    def __init__(self, kernel_sizes, in_features, out_features):
+        super().__init__()
+        if type(kernel_sizes) is str:
+            kernel_sizes = [int(x) for x in kernel_sizes.split(",")]
+        assert out_features % len(kernel_sizes) == 0
+        assert all([kz % 2 == 1 for kz in kernel_sizes])
+        self.kernel_sizes = [int(k) for k in kernel_sizes]
+        self.out_features_per_kz = out_features // len(kernel_sizes)
+        self.list_of_conv1d = nn.ModuleList([
+            nn.Conv1d(in_features, self.out_features_per_kz, kz, padding=(kz - 1) // 2) for kz in self.kernel_sizes])
+
+    def weights(self):
+        return [c.weight for c in self.list_of_conv1d]
+
+    def biases(self):
+        return [c.bias for c in self.list_of_conv1d]
+
+    def forward(self, inputs):
+        raise RuntimeError("MyConv1d has no standalone HIP forward: the conv is fused with the gather and the "
+                           "max-pool (NgramFeat); a [bz, C, L] activation is never materialised")
+
+
+class HierPooling(nn.Module):
+    """layers.py:62-98 parameter container: optional Linear(in->out) projection."""
+
+    def __init__(self, in_features, out_features, kernel_size):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.proj_layer = nn.Linear(in_features, out_features) if in_features != out_features else None
+
+
+class NgramFeat(nn.Module):
+    """layers.py:100-136.  arch="CNN": MyConv1d -> ReLU -> MaxPool1d(seq_len) (all positions, pads included);
+    arch="HierPooling": avg-pool window -> global max -> optional Linear -> ReLU."""
+
+    def __init__(self, kernel_sizes, in_features, out_features, seq_len, dropout=0., arch="CNN"):
+        super().__init__()
+        self.arch = arch
+        self.seq_len = seq_len
+        if arch == "CNN":
+            print("use CNN archiecture for Ngram.")
+            self.feature_layer = nn.Sequential(MyConv1d(kernel_sizes, in_features, out_features), nn.ReLU(),
+                                               nn.MaxPool1d(seq_len))
+        elif arch == "HierPooling":
+            print("use HierPooling arch for Ngram.")
+            assert len(kernel_sizes) == 1
+            self.feature_layer = nn.Sequential(HierPooling(in_features, out_features, kernel_sizes[0]), nn.ReLU())
+        else:
+            raise ValueError(f"{arch} is not predefined.")
+        # stored, never applied -- as in the reference (layers.py:118-121, quirk 7)
+        self.dropout = nn.Dropout(p=dropout) if dropout else None
+
+    # fused entry used by the models: token ids in, pooled features out
+    def encode(self, table: torch.Tensor, ids: torch.Tensor, masks: torch.Tensor, padding_idx=0) -> torch.Tensor:
+        """ids/masks [n_docs, L] -> [n_docs, out_features]."""
+        if self.arch == "CNN":
+            conv = self.feature_layer[0]
+            return RF.textcnn(table, ids, masks, conv.weights(), conv.biases(), padding_idx=padding_idx)
+        hp = self.feature_layer[0]
+        pw = hp.proj_layer.weight if hp.proj_layer is not None else None
+        pb = hp.proj_layer.bias if hp.proj_layer is not None else None
+        return RF.hier_pool(table, ids, masks, hp.kernel_size, pw, pb, padding_idx=padding_idx)
+
+    def forward(self, inputs, input_masks):
+        """Reference signature: inputs [bz, seq_len, in_features] (already embedded), masks [bz, seq_len]
+        -> [bz, out_features, 1] for CNN / [bz, out_features] for HierPooling.
+
+        Runs the same fused kernels by treating `inputs` as a [bz*seq_len, D] table addressed by
+        ids = arange (no padding row), so gradients flow back into `inputs`."""
+        bz, L, D = inputs.shape
+        table = inputs.reshape(bz * L, D)
+        ids = torch.arange(bz * L, device=inputs.device, dtype=torch.int64).view(bz, L)
+        out = self.encode(table, ids, input_masks, padding_idx=None)
+        return out.unsqueeze(-1) if self.arch == "CNN" else out
+
+
+class LastFeat(nn.Module):
+    """layers.py:138-165 parameters: W [feat, latent], b [latent], ebd [vocab, latent] (pad row re-initialised)."""
+
+    def __init__(self, vocab_size, feat_size, latent_dim, padding_idx):
+        super().__init__()
+        self.padding_idx = padding_idx
+        self.W = nn.Parameter(torch.Tensor(feat_size, latent_dim))
+        self.b = nn.Parameter(torch.Tensor(latent_dim))
+        self.ebd = nn.Embedding(vocab_size, latent_dim, padding_idx=padding_idx)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 0.1
+        nn.init.uniform_(self.W, -bound, bound)
+        nn.init.constant_(self.b, bound)
+        nn.init.uniform_(self.ebd.weight, -bound, bound)
+
+
+class FM(nn.Module):
+    """layers.py:167-209 parameters: h [latent,1], g_bias [1], user_bias [U,1], item_bias [I,1]; Dropout(p)."""
+
+    def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.user_padding_idx = user_padding_idx
+        self.item_padding_idx = item_padding_idx
+        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
+        self.user_bias = nn.Embedding(user_size, 1, padding_idx=user_padding_idx)
+        self.item_bias = nn.Embedding(item_size, 1, padding_idx=item_padding_idx)
+        self.g_bias = nn.Parameter(torch.Tensor(1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 0.1
+        nn.init.uniform_(self.h, -bound, bound)
+        nn.init.uniform_(self.user_bias.weight, -bound, bound)
+        nn.init.uniform_(self.item_bias.weight, -bound, bound)
+        nn.init.constant_(self.g_bias, bound)
+
+
+def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm: FM, u_text_feat, i_text_feat, u_ids, i_ids):
+    """LastFeat(user) + LastFeat(item) + FM in one HIP kernel pair (layers.py:156-165,189-209)."""
+    drop = RF.dropout_multiplier((u_text_feat.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
+    return RF.pair_head(u_text_feat, i_text_feat, u_ids, i_ids,
+                        user_feat.W, user_feat.b, user_feat.ebd.weight,
+                        item_feat.W, item_feat.b, item_feat.ebd.weight,
+                        fm.h, fm.g_bias, fm.user_bias.weight, fm.item_bias.weight,
+                        drop=drop, pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)

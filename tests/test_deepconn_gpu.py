@@ -1,0 +1,135 @@
+"""DeepCoNN++ on the HIP path vs golden vectors captured from the reference and vs the CPU oracle.
+Every test goes through the C ABI (ctypes -> librbr_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import check_grads, check_params_after, golden, max_err, quiet
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4   # BASELINE.json north_star: outputs within 1e-4 (fp32) of the reference CPU forward
+
+
+def _model(cfg, sd, arch="CNN", dropout=0.0):
+    from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
+    kz = cfg["kz"] if arch == "CNN" else cfg["kz"][:1]
+    m = quiet(DeepCoNNpp, cfg["U"], cfg["I"], cfg["V"], kz, cfg["D"], cfg["H"], cfg["K"], cfg["L"], None, dropout, arch)
+    m.load_state_dict(sd)
+    return m.to("cuda:0")
+
+
+def _batch(b):
+    d = torch.device("cuda:0")
+    return tuple(b[k].to(d) for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids")), b["ratings"].to(d)
+
+
+@pytest.mark.parametrize("name,cfgname,edge", [
+    ("deepconn_tiny", "tiny", True), ("deepconn_small", "small", True), ("deepconn_k3", "k3", False),
+    ("deepconn_cfg1", "cfg1", False), ("deepconn_cfg2", "cfg2", False)])
+def test_deepconn_matches_reference(golden_dir, name, cfgname, edge):
+    from review_based_recommender_amd.train_step import make_optimizer, train_step
+    g = golden(golden_dir, name)
+    cfg = synth.DEEPCONN_CFGS[cfgname]
+    model = _model(cfg, synth.deepconn_params(cfg, 0))
+    args, ratings = _batch(synth.deepconn_batch(cfg, 1, edge_cases=edge))
+
+    model.eval()
+    with torch.no_grad():
+        pred = model(*args)
+    assert pred.shape == (cfg["B"],) and pred.dtype == torch.float32
+    assert max_err(pred.cpu().numpy(), g["pred_eval"]) <= FWD_TOL
+
+    model.train()
+    opt = make_optimizer(model)
+    for step in range(3):
+        loss, gnorm, pred = train_step(model, opt, args, ratings)
+        if step == 0:
+            assert max_err(pred.cpu().numpy(), g["pred"]) <= FWD_TOL
+            assert abs(float(loss) - float(g["loss"])) <= 1e-4          # |MSE_hip - MSE_ref| <= 1e-4
+            assert abs(float(gnorm) - float(g["gnorm"])) <= 2e-4 * float(g["gnorm"])
+        if step in (0, 2):
+            check_params_after(model, g, f"after{step + 1}")
+    assert abs(float(loss) - float(g["loss_after3"])) <= 2e-4 * max(1.0, float(g["loss_after3"]))
+
+
+@pytest.mark.parametrize("name,cfgname,edge", [
+    ("deepconn_tiny", "tiny", True), ("deepconn_small", "small", True), ("deepconn_k3", "k3", False),
+    ("deepconn_cfg1", "cfg1", False), ("deepconn_cfg2", "cfg2", False)])
+def test_deepconn_gradients_match_reference(golden_dir, name, cfgname, edge):
+    g = golden(golden_dir, name)
+    cfg = synth.DEEPCONN_CFGS[cfgname]
+    model = _model(cfg, synth.deepconn_params(cfg, 0))
+    args, ratings = _batch(synth.deepconn_batch(cfg, 1, edge_cases=edge))
+    model.train()
+    loss = torch.nn.functional.mse_loss(model(*args), ratings)
+    loss.backward()
+    check_grads({k: p.grad for k, p in model.named_parameters()}, g)
+    # nn.Embedding(padding_idx=0): the pad row never receives gradient
+    assert float(model.word_embeddings.embedding.weight.grad[0].abs().max()) == 0.0
+    assert float(model.user_feat.ebd.weight.grad[0].abs().max()) == 0.0
+
+
+def test_ngram_features_match_oracle(golden_dir):
+    """TextCNN features alone (u_rev_feats / i_rev_feats of the reference forward)."""
+    from review_based_recommender_amd import functional as RF
+    from oracle import ref_cpu as O
+    for name, cfgname in (("deepconn_small", "small"), ("deepconn_cfg1", "cfg1")):
+        g = golden(golden_dir, name)
+        cfg = synth.DEEPCONN_CFGS[cfgname]
+        p = synth.deepconn_params(cfg, 0)
+        b = synth.deepconn_batch(cfg, 1, edge_cases=(cfgname == "small"))
+        ws, bs = O.conv_params(p)
+        d = torch.device("cuda:0")
+        feat, am = RF.textcnn(p["word_embeddings.embedding.weight"].to(d), b["u_docs"].to(d), b["u_masks"].to(d),
+                              [w.to(d) for w in ws], [x.to(d) for x in bs], return_argmax=True)
+        assert max_err(feat.cpu().numpy(), g["u_rev_feats"]) <= 2e-5
+        assert int(am.min()) >= 0 and int(am.max()) < cfg["L"]
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    cfg = synth.DEEPCONN_CFGS["tiny"]
+    sd = synth.deepconn_params(cfg, 0)
+    from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
+    m = quiet(DeepCoNNpp, cfg["U"], cfg["I"], cfg["V"], cfg["kz"], cfg["D"], cfg["H"], cfg["K"], cfg["L"], None, 0.5)
+    ours = m.state_dict()
+    assert list(ours.keys()) == list(sd.keys())
+    for k in sd:
+        assert tuple(ours[k].shape) == tuple(sd[k].shape), k
+
+
+def test_dropout_train_mode_runs_and_eval_is_deterministic():
+    cfg = synth.DEEPCONN_CFGS["small"]
+    model = _model(cfg, synth.deepconn_params(cfg, 0), dropout=0.5)
+    args, _ = _batch(synth.deepconn_batch(cfg, 1))
+    model.train()
+    a = model(*args)
+    b = model(*args)
+    assert not torch.equal(a, b)           # FM dropout (layers.py:202) draws a fresh mask
+    model.eval()
+    assert torch.equal(model(*args), model(*args))
+
+
+def test_error_conventions():
+    """AssertionError for even widths / H not divisible (layers.py:38-39), ValueError for unknown arch (:116)."""
+    from review_based_recommender_amd.models.deepconn.layers import NgramFeat
+    with pytest.raises(AssertionError):
+        quiet(NgramFeat, [2], 8, 6, 16)
+    with pytest.raises(AssertionError):
+        quiet(NgramFeat, [3, 5], 8, 7, 16)
+    with pytest.raises(ValueError):
+        quiet(NgramFeat, [3], 8, 6, 16, arch="nope")
+    m = quiet(NgramFeat, "3,5", 8, 6, 16)    # "3,5" strings are accepted (layers.py:34-36)
+    assert m.feature_layer[0].kernel_sizes == [3, 5]
+
+
+def test_cpu_tensors_are_rejected():
+    """There is no CPU fallback: the product path refuses host tensors."""
+    from review_based_recommender_amd import functional as RF
+    cfg = synth.DEEPCONN_CFGS["tiny"]
+    p = synth.deepconn_params(cfg, 0)
+    b = synth.deepconn_batch(cfg, 1)
+    with pytest.raises(RuntimeError):
+        RF.textcnn(p["word_embeddings.embedding.weight"], b["u_docs"], b["u_masks"],
+                   [p["ngram.feature_layer.0.list_of_conv1d.0.weight"]], [p["ngram.feature_layer.0.list_of_conv1d.0.bias"]])
