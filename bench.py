@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- (user,item) pairs/s of the DeepCoNN review-encoder train step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] ("cfg2"): DeepCoNN, batch 256 pairs per GPU, 2 x 512-token
+documents per pair, 300-d embeddings, conv widths 3/5/7 x 50 channels, latent 32, V = 50 002,
+fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the reference trainer's step
+(trainer/train_deepconn_pp.py:161-168): zero_grad -> forward -> MSELoss -> backward ->
+[N>1: RCCL gradient all-reduce] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
+HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
+
+Rank 0 prints ONE JSON line.  `value` = pairs/s over all ranks of the full train step;
+`roofline` prices the dominant kernel (fused gather+conv+max-pool forward, f32 MFMA) with HIP
+events recorded around its launches inside the timed region; `cpu_baseline` times the CPU oracle
+(oracle/ref_cpu.py, torch CPU ops) on the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+
+WORKLOAD = "cfg2"
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def conv_fwd_flops(cfg) -> float:
+    """Algorithmic FLOPs of one conv-kernel launch: 2 docs x 2*L*D*C_w*sum(kz) per pair."""
+    per_w = cfg["H"] // len(cfg["kz"])
+    return 2.0 * cfg["B"] * 2.0 * cfg["L"] * cfg["D"] * per_w * sum(cfg["kz"])
+
+
+def build_model(cfg, device):
+    from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DeepCoNNpp(cfg["U"], cfg["I"], cfg["V"], cfg["kz"], cfg["D"], cfg["H"], cfg["K"], cfg["L"], None, 0.5)
+    m.load_state_dict(synth.deepconn_params(cfg, 0))
+    return m.to(device)
+
+
+def batch_on(cfg, seed, device):
+    b = synth.deepconn_batch(cfg, seed)
+    args = tuple(b[k].to(device) for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids"))
+    return args, b["ratings"].to(device)
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The oracle's train step (same math, torch CPU ops) on a bounded sample: whole batches of the
+    same workload until ~budget_s of CPU time is spent (at least 2 timed steps after 1 warm-up)."""
+    import torch.nn.functional as F
+    from oracle import ref_cpu as O
+    p = synth.deepconn_params(cfg, 0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=2e-3)
+    b = synth.deepconn_batch(cfg, 1)
+    args = (b["u_docs"], b["i_docs"], b["u_masks"], b["i_masks"], b["u_ids"], b["i_ids"])
+
+    def step():
+        opt.zero_grad()
+        pred = O.deepconn_forward(leaves, *args, dropout_p=0.5, training=True)
+        loss = F.mse_loss(pred, b["ratings"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(leaves.values()), 5.0)
+        opt.step()
+
+    step()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 2 and (el >= budget_s or n >= 50):
+            break
+    with torch.no_grad():
+        f0 = time.perf_counter()
+        O.deepconn_forward(p, *args)
+        fwd_s = time.perf_counter() - f0
+    return {
+        "value": round(cfg["B"] * n / el, 2), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n} full train steps of the same cfg2 batch (B=256) with oracle/ref_cpu.py, torch CPU fp32, "
+                  f"{el:.1f} s wall; host has {os.cpu_count()} logical CPUs",
+        "fwd_pairs_per_s": round(cfg["B"] / fwd_s, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd.train_step import make_optimizer, train_step
+    _lib.lib()   # fail loudly now if librbr_hip.so is missing
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    cfg = synth.DEEPCONN_CFGS[WORKLOAD]
+
+    grad_sync = None
+    if world > 1:
+        import torch.distributed as dist
+        from review_based_recommender_amd.distributed import GradAllReduce, init_process_group_from_env
+        init_process_group_from_env("nccl")
+
+    model = build_model(cfg, device)          # identical parameters on every rank (same seed)
+    model.train()
+    opt = make_optimizer(model)
+    args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
+    if world > 1:
+        grad_sync = GradAllReduce(model)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        train_step(model, opt, args, ratings, grad_sync=grad_sync)
+    barrier()
+    _lib.TIMER.start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        train_step(model, opt, args, ratings, grad_sync=grad_sync)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER.stop()
+    ksum = _lib.TIMER.summary()
+
+    # forward-only (eval) rate, reported beside the headline
+    model.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            model(*args)
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for _ in range(20):
+            model(*args)
+        torch.cuda.synchronize()
+        fwd_s = (time.perf_counter() - f0) / 20
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = cfg["B"] * a.steps * world
+        conv_calls, conv_ms = ksum.get("textcnn_conv_fwd", (0, float("nan")))
+        flops = conv_fwd_flops(cfg)
+        ach = flops / (conv_ms * 1e-3) / 1e12
+        out = {
+            "metric": "(user,item) pairs/sec, DeepCoNN train step (fwd+MSE+bwd+clip+Adam), bsz256 2x512tok",
+            "value": round(pairs / elapsed, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
+                                   "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
+                       "parallelism": f"dp{world}"},
+            "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
+            "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel (gather+conv+max-pool, v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flops_per_launch": flops, "avg_launch_ms": round(conv_ms, 4), "launches_timed": conv_calls},
+            "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
