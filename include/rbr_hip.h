@@ -63,7 +63,8 @@ const char* rbr_last_error(void);
  *      narre/layers.py:119-153,365-401 twins; with RBR_PAD_VALID/RBR_ACT_TANH also the gated
  *      convs of dual_att/layers.py:37-40,68-79.                                            ---- */
 
-/* number of floats of the packed-weight buffer / of the partial-max workspace for `d` */
+/* number of floats of the packed-weight buffer / number of elements of EACH of the two partial-max
+ * workspaces (pval: float, pidx: int32) for `d` */
 size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d);
 size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d);
 

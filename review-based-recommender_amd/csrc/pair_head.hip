@@ -90,36 +90,50 @@ __global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K,
     }
 }
 
-// batch reductions in fixed order (bitwise reproducible): dW = feat^T @ d_l, db, dh, dg
+// batch reductions (bitwise reproducible: fixed partition and order): dW = feat^T @ d_l, db, dh, dg.
+// One workgroup per output row (side, r): 8 thread groups stride the batch, 32 lanes cover k.
 __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(int B, int H, int K, const float* __restrict__ uf,
                                                               const float* __restrict__ itf,
                                                               const float* __restrict__ d_pred,
                                                               const float* __restrict__ ws_dul,
                                                               const float* __restrict__ ws_dil,
                                                               const float* __restrict__ ws_zdp, const rbr_head_grads g) {
-    const int rows = H + 1;                 // row H holds the bias / h reductions
-    const long total = 2L * rows * K;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % K);
-        const int r = (int)((idx / K) % rows);
-        const int side = (int)(idx / ((long)K * rows));
-        const float* dl = side ? ws_dil : ws_dul;
-        const float* ft = side ? itf : uf;
-        float s = 0.f;
-        if (r < H) {
-            for (int b = 0; b < B; ++b) s = fmaf(ft[(long)b * H + r], dl[(long)b * K + k], s);
-            (side ? g.dWi : g.dWu)[(long)r * K + k] = s;
-        } else {
-            for (int b = 0; b < B; ++b) s += dl[(long)b * K + k];
-            (side ? g.dbi : g.dbu)[k] = s;
-            if (side == 0) {
-                float hsum = 0.f;
-                for (int b = 0; b < B; ++b) hsum += ws_zdp[(long)b * K + k];
-                g.dh[k] = hsum;
-                if (k == 0) {
-                    float gs = 0.f;
-                    for (int b = 0; b < B; ++b) gs += d_pred[b];
-                    g.dg[0] = gs;
+    __shared__ float red[3][8][32];
+    const int rows = H + 1;                 // row H holds the bias / h / g reductions
+    const int side = blockIdx.x / rows, r = blockIdx.x % rows;
+    const int kk = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float* dl = side ? ws_dil : ws_dul;
+    const float* ft = side ? itf : uf;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k = k0 + kk;
+        float s = 0.f, hs = 0.f, gs = 0.f;
+        if (k < K) {
+            if (r < H) {
+                for (int b = grp; b < B; b += 8) s = fmaf(ft[(long)b * H + r], dl[(long)b * K + k], s);
+            } else {
+                for (int b = grp; b < B; b += 8) {
+                    s += dl[(long)b * K + k];
+                    if (side == 0) {
+                        hs += ws_zdp[(long)b * K + k];
+                        if (k == 0) gs += d_pred[b];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        red[0][grp][kk] = s; red[1][grp][kk] = hs; red[2][grp][kk] = gs;
+        __syncthreads();
+        if (grp == 0 && k < K) {
+            float a = 0.f, bsum = 0.f, c = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a += red[0][q][kk]; bsum += red[1][q][kk]; c += red[2][q][kk]; }
+            if (r < H) {
+                (side ? g.dWi : g.dWu)[(long)r * K + k] = a;
+            } else {
+                (side ? g.dbi : g.dbu)[k] = a;
+                if (side == 0) {
+                    g.dh[k] = bsum;
+                    if (k == 0) g.dg[0] = c;
                 }
             }
         }
@@ -166,8 +180,7 @@ extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u
                        reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
                        il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, ws_dul, ws_dil, ws_zdp);
     RBR_CHECK_LAUNCH("pair_head_bwd pair launch");
-    const long total = 2L * (H + 1) * K;
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, H, K, u_feat,
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)(2 * (H + 1))), dim3(256), 0, st, B, H, K, u_feat,
                        i_feat, d_pred, ws_dul, ws_dil, ws_zdp, *g);
     RBR_CHECK_LAUNCH("pair_head_bwd reduce launch");
     return 0;

@@ -36,8 +36,8 @@ struct ConvPlan {
     int ntiles;         // tiles in this group
     int npieces;        // (tap, tile) pairs streamed per embedding chunk
     int pad_mode, act;
-    unsigned char piece_s[kMaxPieces];
-    unsigned char piece_t[kMaxPieces];
+    int piece_st[kMaxPieces];          // tap | tile << 8  (dword entries: fetched with s_load, not a vector load
+                                       // whose vmcnt wait would drain the weight prefetch in flight)
     short slot_chan[kMaxSlots];        // global output channel of slot, -1 = padding slot
     unsigned char slot_w[kMaxSlots];   // conv bank of the slot
     unsigned char slot_off[kMaxSlots]; // frame tap of the channel's tap 0

@@ -98,7 +98,7 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
         int np = 0;
         for (int s = 0; s < KF; ++s)
             for (int t = 0; t < p.ntiles; ++t)
-                if (s >= lo[t] && s <= hi[t]) { p.piece_s[np] = (unsigned char)s; p.piece_t[np] = (unsigned char)t; ++np; }
+                if (s >= lo[t] && s <= hi[t]) p.piece_st[np++] = s | (t << 8);
         p.npieces = np;
     }
     return ngroups;

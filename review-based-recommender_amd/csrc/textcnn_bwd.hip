@@ -16,8 +16,9 @@
 //                thread d keeps dW[c, d, 0..kz) in registers (no atomics), window rows are resolved
 //                once per 32 documents into LDS so the table reads are independent, coalesced loads.
 //   dw_reduce  : sums the NCH partial slabs in fixed order (bitwise reproducible) into torch layout.
-//   dx_scatter : grid (n_docs).  Entries (channel, tap) are resolved into LDS, then one WAVE per entry
-//                adds g*W[c,:,j] into the token's table row with 256-byte contiguous f32 atomics.
+//   dx_window  : grid (n_docs x windows of 64 positions).  The window's (channel, tap) items are bucketed by
+//                token in LDS; one wave per token sums them in registers and adds one row to dtable with
+//                256-byte contiguous f32 atomics.
 #include "rbr_common.h"
 
 namespace rbr {
@@ -140,70 +141,137 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const f
 }
 
 // ------------------------------------------------------------------------------------ dtable / dgate
-__global__ __launch_bounds__(256) void dx_scatter_kernel(const BwdArgs A, const long long* __restrict__ ids,
-                                                         const unsigned char* __restrict__ mask,
-                                                         const float* __restrict__ gate, const float* __restrict__ table,
-                                                         const float* __restrict__ packed, const float* __restrict__ feat,
-                                                         const int* __restrict__ argmax, const float* __restrict__ d_feat,
-                                                         float* __restrict__ dtable, float* __restrict__ dgate) {
-    __shared__ long s_row[kChanBatch * kMaxKF];    // table row offset (id * D), -1 = no contribution
-    __shared__ long s_w[kChanBatch * kMaxKF];      // offset of W[c, 0, j] inside the packed image
-    __shared__ float s_g[kChanBatch * kMaxKF];     // g (without the gate)
-    __shared__ int s_tok[kChanBatch * kMaxKF];     // token index inside the document
-    const int doc = blockIdx.x, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+// One workgroup per (document, window of 64 token positions).  Every (channel, tap) whose argmax window
+// row falls into the window is an ITEM: it adds  g * gate * W[c, :, j]  to the table row of that token.
+// Items are bucketed in LDS by TOKEN (key = first row of the window carrying the same token id), then
+// one wave per token sums its items in registers (lanes over the embedding dim, no LDS traffic) and
+// issues ONE row of 256-byte contiguous f32 atomics.  Folding same-token rows before the atomics is
+// what keeps Zipf-hot rows ("the", ",") from serialising the memory-side atomic units.
+constexpr int kWin = 64;
+constexpr int kMaxDI = 8;   // embedding dim handled per pass = 64 lanes * kMaxDI
+
+__global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const int nwin,
+                                                        const long long* __restrict__ ids,
+                                                        const unsigned char* __restrict__ mask,
+                                                        const float* __restrict__ gate, const float* __restrict__ table,
+                                                        const float* __restrict__ packed, const float* __restrict__ feat,
+                                                        const int* __restrict__ argmax, const float* __restrict__ d_feat,
+                                                        float* __restrict__ dtable, float* __restrict__ dgate) {
+    constexpr int kCap = kChanBatch * kMaxKF;
+    __shared__ int s_item_w[kCap];          // offset of W[c, 0, j] in the packed image
+    __shared__ float s_item_g[kCap];        // g = d_feat * act'(feat)
+    __shared__ unsigned char s_item_row[kCap];
+    __shared__ short s_sorted[kCap];        // item indices grouped by key
+    __shared__ long s_tok[kWin];            // token id of the row (-1: masked / outside the document)
+    __shared__ int s_leader[kWin];
+    __shared__ int s_cnt[kWin], s_start[kWin], s_fill[kWin];
+    __shared__ int s_count;
+    const int doc = blockIdx.x / nwin, p0 = (blockIdx.x % nwin) * kWin;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = A.L, D = A.D, C = A.C, KF = A.KF, DC = A.DC;
-    const long piece = (long)kTile * DC;
+    const int piece = kTile * DC;
+
+    if (tid < kWin) {
+        const int p = p0 + tid;
+        long t = -1;
+        if (p < L && (mask == nullptr || mask[(long)doc * L + p])) t = ids[(long)doc * L + p];
+        s_tok[tid] = t;
+    }
+    __syncthreads();
+    if (tid < kWin) {
+        int lead = tid;
+        const long t = s_tok[tid];
+        for (int r = 0; r < tid; ++r)
+            if (s_tok[r] == t) { lead = r; break; }
+        s_leader[tid] = lead;
+    }
 
     for (int c0 = 0; c0 < C; c0 += kChanBatch) {
         const int nc = min(kChanBatch, C - c0);
         __syncthreads();
+        if (tid == 0) s_count = 0;
+        if (tid < kWin) { s_cnt[tid] = 0; s_fill[tid] = 0; }
+        __syncthreads();
+        // ---- collect the items of this window ------------------------------------------------------
         for (int e = tid; e < nc * KF; e += 256) {
             const int cl = e / KF, j = e - cl * KF;
             const int c = c0 + cl;
             const int w = bank_of(A, c);
             const int kz = A.kz[w];
-            long row = -1, woff = 0;
-            float g = 0.f;
-            int p = 0;
-            if (j < kz) {
-                const long o = (long)doc * C + c;
-                g = act_grad(A.act, feat[o], d_feat[o]);
-                const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
-                p = argmax[o] + j - padl;
-                if (g != 0.f && p >= 0 && p < L) {
-                    const long tok = (long)doc * L + p;
-                    if (mask == nullptr || mask[tok]) {
-                        row = ids[tok] * (long)D;
-                        const int slot = A.rank_off[w] + (c - A.ch_off[w]);   // kz-sorted slot of the channel
-                        const int off = (A.pad_mode == RBR_PAD_SAME) ? (KF - kz) / 2 : 0;
-                        const int t = slot / kTile, i = slot % kTile, s = j + off;
-                        woff = ((long)(t * KF + s) * A.nchunks) * piece + (long)i * DC;
-                    }
-                }
-            }
-            s_row[e] = row; s_w[e] = woff; s_g[e] = g; s_tok[e] = p;
+            if (j >= kz) continue;
+            const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
+            const long o = (long)doc * C + c;
+            const int p = argmax[o] + j - padl;
+            if (p < p0 || p >= p0 + kWin || p >= L) continue;
+            if (s_tok[p - p0] < 0) continue;                       // masked token: x was zeroed, no gradient
+            const float g = act_grad(A.act, feat[o], d_feat[o]);
+            if (g == 0.f) continue;
+            const int slot = A.rank_off[w] + (c - A.ch_off[w]);    // kz-sorted slot of the channel
+            const int off = (A.pad_mode == RBR_PAD_SAME) ? (KF - kz) / 2 : 0;
+            const int t = slot / kTile, i = slot % kTile, s = j + off;
+            const int k = atomicAdd(&s_count, 1);
+            s_item_row[k] = (unsigned char)(p - p0);
+            s_item_w[k] = ((t * KF + s) * A.nchunks) * piece + i * DC;
+            s_item_g[k] = g;
+            atomicAdd(&s_cnt[s_leader[p - p0]], 1);
         }
         __syncthreads();
-        for (int e = wave; e < nc * KF; e += 4) {   // one wave per (channel, tap) window row
-            const long row = s_row[e];
-            if (row < 0) continue;                   // wave-uniform
-            const float g = s_g[e];
-            const long woff = s_w[e];
-            const long tok = (long)doc * L + s_tok[e];
-            const float gv = (gate != nullptr) ? gate[tok] : 1.f;
-            const bool to_table = (dtable != nullptr) && (row != (long)A.padding_idx * D);
-            float dot = 0.f;
-            for (int d = lane; d < D; d += 64) {
-                const int dc = d / DC, dd = d - dc * DC;
-                const float v = g * packed[woff + (long)dc * piece + dd];
-                if (to_table) atomicAdd(dtable + row + d, v * gv);
-                if (dgate != nullptr) dot = fmaf(v, table[row + d], dot);
-            }
-            if (dgate != nullptr) {
+        if (tid == 0) {
+            int run = 0;
+            for (int r = 0; r < kWin; ++r) { s_start[r] = run; run += s_cnt[r]; }
+        }
+        __syncthreads();
+        const int n = s_count;
+        for (int k = tid; k < n; k += 256) {
+            const int key = s_leader[s_item_row[k]];
+            s_sorted[s_start[key] + atomicAdd(&s_fill[key], 1)] = (short)k;
+        }
+        __syncthreads();
+        // ---- one wave per token: register accumulation, then one row of atomics -------------------
+        for (int key = wave; key < kWin; key += 4) {
+            const int cnt = s_cnt[key];
+            if (cnt == 0) continue;                               // wave-uniform
+            const int base = s_start[key];
+            const long trow = s_tok[key] * (long)D;
+            const bool to_table = (dtable != nullptr) && (s_tok[key] != (long)A.padding_idx);
+            for (int dblk = 0; dblk < D; dblk += 64 * kMaxDI) {
+                int doff[kMaxDI];
+                float sum[kMaxDI], tv[kMaxDI];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-                if (lane == 0) atomicAdd(dgate + tok, dot);
+                for (int u = 0; u < kMaxDI; ++u) {
+                    const int d = dblk + lane + 64 * u;
+                    const int dc = d / DC;
+                    doff[u] = (d < D) ? dc * piece + (d - dc * DC) : -1;
+                    sum[u] = 0.f;
+                    tv[u] = (gate != nullptr && d < D) ? table[trow + d] : 0.f;
+                }
+                for (int q = 0; q < cnt; ++q) {
+                    const int it = s_sorted[base + q];
+                    const float* wrow = packed + s_item_w[it];
+                    const float g = s_item_g[it];
+                    float gv = 1.f;
+                    const long tok = (long)doc * L + p0 + s_item_row[it];
+                    if (gate != nullptr) gv = gate[tok];
+                    float dot = 0.f;
+#pragma unroll
+                    for (int u = 0; u < kMaxDI; ++u) {
+                        if (doff[u] >= 0) {
+                            const float wv = wrow[doff[u]];
+                            sum[u] = fmaf(g * gv, wv, sum[u]);
+                            dot = fmaf(g * wv, tv[u], dot);
+                        }
+                    }
+                    if (gate != nullptr && dgate != nullptr) {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                        if (lane == 0) atomicAdd(dgate + tok, dot);
+                    }
+                }
+                if (to_table) {
+#pragma unroll
+                    for (int u = 0; u < kMaxDI; ++u)
+                        if (doff[u] >= 0) atomicAdd(dtable + trow + dblk + lane + 64 * u, sum[u]);
+                }
             }
         }
     }
@@ -266,9 +334,10 @@ extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, co
                        ws_w, ws_b, dWp, dbp);
     RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
     if (dtable != nullptr || (dgate != nullptr && gate != nullptr)) {
-        hipLaunchKernelGGL(dx_scatter_kernel, dim3(A.n_docs), dim3(256), 0, st, A, ids64, mask, gate, table, packed, feat,
-                           argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
-        RBR_CHECK_LAUNCH("textcnn dx_scatter launch");
+        const int nwin = (A.L + kWin - 1) / kWin;
+        hipLaunchKernelGGL(dx_window_kernel, dim3((unsigned)(A.n_docs * nwin)), dim3(256), 0, st, A, nwin, ids64, mask,
+                           gate, table, packed, feat, argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
+        RBR_CHECK_LAUNCH("textcnn dx_window launch");
     }
     return 0;
 }

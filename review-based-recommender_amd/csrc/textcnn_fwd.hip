@@ -24,6 +24,8 @@
 //   Row stride DC floats with DC/4 odd => the b128 reads are bank-conflict free.
 #include "rbr_common.h"
 
+#include <cstdlib>
+
 namespace rbr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,21 +62,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrAr
 // ------------------------------------------------------------------------------------ conv
 template <int DC>
 __device__ __forceinline__ void mma_piece(f32x16& acc, const float* __restrict__ xa, const float* __restrict__ wb, int h) {
-    // xa / wb already include the lane's row and the 4*h column offset
+    // xa / wb already include the lane's row and the 4*h column offset.
+    // All LDS operands of the piece are requested up front (2 x DC/8 ds_read_b128): one wave alone then keeps
+    // the MFMA pipe fed -- issuing each read pair behind the previous MFMA group left ~40 % of the pipe idle.
+    constexpr int NQ = DC / 8;
+    f32x4 a[NQ], b[NQ];
 #pragma unroll
-    for (int q = 0; q < DC / 8; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(xa + 8 * q);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(wb + 8 * q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) {
+        a[q] = *reinterpret_cast<const f32x4*>(xa + 8 * q);
+        b[q] = *reinterpret_cast<const f32x4*>(wb + 8 * q);
     }
+    f32x2 at = {0.f, 0.f}, bt = {0.f, 0.f};
     if (DC % 8 == 4) {  // last 4 columns: lane half h takes columns DC-4+2h, DC-4+2h+1
-        const f32x2 a = *reinterpret_cast<const f32x2*>(xa - 4 * h + (DC - 4) + 2 * h);
-        const f32x2 b = *reinterpret_cast<const f32x2*>(wb - 4 * h + (DC - 4) + 2 * h);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        at = *reinterpret_cast<const f32x2*>(xa - 4 * h + (DC - 4) + 2 * h);
+        bt = *reinterpret_cast<const f32x2*>(wb - 4 * h + (DC - 4) + 2 * h);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+    }
+    if (DC % 8 == 4) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at.x, bt.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at.y, bt.y, acc, 0, 0, 0);
     }
 }
 
@@ -97,12 +109,23 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int wt = blockIdx.x * kWavesPerWG + wave;   // global wave-tile
+    const int L = P.L, D = P.D;
+    float* Xw = Xs + wave * XR * DC;
+    const long per_tile = (long)P.KF * P.nchunks * PIECE;
+    const float* wbase = packed + (long)P.tile_base * per_tile;
+    const int nitems = (P.total_wt + kWavesPerWG - 1) / kWavesPerWG;
+
+  // Persistent workgroups walk the items (4 consecutive wave-tiles each) with a fixed stride.  All items
+  // cost the same; with 3 resident workgroups per CU and e.g. 8 items per CU the blocks b, b+G/3, b+2G/3
+  // of one CU run 3+3+2 items, so the last round shares each MFMA pipe between 2 waves instead of idling
+  // a third of the CUs (a global work counter does NOT achieve this: a CU's workgroups finish together
+  // and the earliest CUs grab 3 more items each).
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __syncthreads();   // every wave is done with the LDS ring of the previous item
+    const int wt = item * kWavesPerWG + wave;         // global wave-tile
     const bool active = wt < P.total_wt;              // wave-uniform
     const int doc = active ? wt / P.wpd : 0;
     const int l0 = active ? (wt % P.wpd) * kTile : 0;
-    const int L = P.L, D = P.D;
-    float* Xw = Xs + wave * XR * DC;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -110,10 +133,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const long per_tile = (long)P.KF * P.nchunks * PIECE;
-    const float* wbase = packed + (long)P.tile_base * per_tile;
     auto piece_src = [&](int dc, int pi) -> const float* {
-        const int s = P.piece_s[pi], t = P.piece_t[pi];
+        const int st = P.piece_st[pi];
+        const int s = st & 0xff, t = st >> 8;
         return wbase + ((long)(t * P.KF + s) * P.nchunks + dc) * PIECE;
     };
 
@@ -183,7 +205,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                 issue(piece_src(wrap ? dc + 1 : dc, wrap ? 0 : pi + 1));  // lands while this piece computes
             }
             if (active) {
-                const int s = P.piece_s[pi], t = P.piece_t[pi];
+                const int st = P.piece_st[pi];
+                const int s = st & 0xff, t = st >> 8;
                 const float* xa = Xw + (i + s) * DC + 4 * h;
                 const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
 #pragma unroll
@@ -197,11 +220,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     }
 
     // ---- epilogue: max + first argmax over this wave's 32 positions, per channel slot --------------
-    if (!active) return;
     const float NEG = -__builtin_huge_valf();
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
-        if (tt < P.ntiles) {
+        if (active && tt < P.ntiles) {
             const int ls = tt * kTile + i;
             const int kz = P.slot_kz[ls];
             const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;   // pool length of this channel
@@ -223,6 +245,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             }
         }
     }
+  }  // item loop
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -251,24 +274,47 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, co
     }
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <int NT, int DC, bool VEC>
+static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
+                          const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
+    const int XR = kTile + p.KF - 1;
+    static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
+    const size_t smem = (size_t)(2 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) + extra_lds;
+    static int occ = 0;   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
+    if (occ == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_fwd_kernel<NT, DC, VEC>, 256, smem) != hipSuccess || nb <= 0)
+            nb = 2;
+        occ = nb;
+    }
+    const int nitems = (p.total_wt + kWavesPerWG - 1) / kWavesPerWG;
+    const dim3 grid(std::min(nitems, num_cus() * occ)), block(256);
+    hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,
+                       pidx);
+    RBR_CHECK_LAUNCH("textcnn conv_fwd launch");
+    return 0;
+}
+
 template <int DC, bool VEC>
 static int launch_conv(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
                        const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
-    const int XR = kTile + p.KF - 1;
-    const size_t smem = (size_t)(2 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float);
-    const dim3 grid((p.total_wt + kWavesPerWG - 1) / kWavesPerWG), block(256);
-#define RBR_LAUNCH(NT)                                                                                          \
-    case NT:                                                                                                    \
-        hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table,    \
-                           packed, pval, pidx);                                                                 \
-        break;
+#define RBR_LAUNCH(NT) \
+    case NT: return launch_conv_nt<NT, DC, VEC>(p, ids, mask, gate, table, packed, pval, pidx, st);
     switch (p.ntiles) {
         RBR_LAUNCH(1) RBR_LAUNCH(2) RBR_LAUNCH(3) RBR_LAUNCH(4) RBR_LAUNCH(5) RBR_LAUNCH(6) RBR_LAUNCH(7) RBR_LAUNCH(8)
         default: set_error("ntiles=%d", p.ntiles); return RBR_ERR_UNSUPPORTED;
     }
 #undef RBR_LAUNCH
-    RBR_CHECK_LAUNCH("textcnn conv_fwd launch");
-    return 0;
 }
 
 static size_t packed_floats(const ConvPlan& p0) {
