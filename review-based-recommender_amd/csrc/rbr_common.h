@@ -36,8 +36,9 @@ struct ConvPlan {
     int ntiles;         // tiles in this group
     int npieces;        // (tap, tile) pairs streamed per embedding chunk
     int pad_mode, act;
-    int piece_st[kMaxPieces];          // tap | tile << 8  (dword entries: fetched with s_load, not a vector load
-                                       // whose vmcnt wait would drain the weight prefetch in flight)
+    int tiles_total;    // channel tiles over all groups (tile pitch of the packed image)
+    int piece_st[kMaxPieces];          // tap | first tile << 8 | tile count (1..2) << 16.  Dword entries: fetched with
+                                       // s_load, not a vector load whose vmcnt wait would drain the weight prefetch
     short slot_chan[kMaxSlots];        // global output channel of slot, -1 = padding slot
     unsigned char slot_w[kMaxSlots];   // conv bank of the slot
     unsigned char slot_off[kMaxSlots]; // frame tap of the channel's tap 0

@@ -94,12 +94,20 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
                 }
             }
         }
-        // tap-major piece order: consecutive pieces of one tap reuse the same token rows
+        // tap-major piece order; two adjacent active tiles of one tap form ONE piece (they are contiguous in
+        // the packed image and share the token-row operand), which halves the barriers per MFMA
         int np = 0;
-        for (int s = 0; s < KF; ++s)
-            for (int t = 0; t < p.ntiles; ++t)
-                if (s >= lo[t] && s <= hi[t]) p.piece_st[np++] = s | (t << 8);
+        for (int s = 0; s < KF; ++s) {
+            int t = 0;
+            while (t < p.ntiles) {
+                if (!(s >= lo[t] && s <= hi[t])) { ++t; continue; }
+                const bool pair = (t + 1 < p.ntiles) && (s >= lo[t + 1] && s <= hi[t + 1]);
+                p.piece_st[np++] = s | (t << 8) | ((pair ? 2 : 1) << 16);
+                t += pair ? 2 : 1;
+            }
+        }
         p.npieces = np;
+        p.tiles_total = tiles_total;
     }
     return ngroups;
 }

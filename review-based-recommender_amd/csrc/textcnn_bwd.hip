@@ -21,6 +21,9 @@
 //                256-byte contiguous f32 atomics.
 #include "rbr_common.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace rbr {
 
 constexpr int kDocsPerBatch = 32;
@@ -32,12 +35,13 @@ __device__ __forceinline__ float act_grad(int act, float f, float d) {
 }
 
 struct BwdArgs {
-    int n_docs, L, D, C, KF, DC, nchunks;
+    int n_docs, L, D, C, KF, DC, nchunks, tiles_total;
     int pad_mode, act, padding_idx;
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
     int rank_off[RBR_MAX_WIDTHS];   // first slot (kz-sorted channel order) of bank w in the packed image
     int NCH, DPC;                   // document chunks of dw_partial and documents per chunk
+    int dev_flags;                  // tuning aid (RBR_DEV_DX_ABLATE): 1 = no atomics, 2 = no accumulation phase
 };
 
 __device__ __forceinline__ int bank_of(const BwdArgs& A, int c) {
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
                 const long o = (long)(b0 + dl) * C + c;
                 const float g = act_grad(A.act, feat[o], d_feat[o]);
                 const int p = argmax[o] + j - padl;
-                long row = -1;
+                long row = 0;      // (row 0, scale 0) = no contribution
                 float sc = 0.f;
                 if (g != 0.f && p >= 0 && p < L) {
                     const long tok = (long)(b0 + dl) * L + p;
@@ -98,14 +102,27 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
             if (dbase == 0 && tid == 0)
                 for (int dl = 0; dl < nb; ++dl) bsum += s_g[dl];   // fixed order
             if (d < D) {
-                for (int dl = 0; dl < nb; ++dl) {
+                // branch-free: rows without a contribution were resolved to (row 0, scale 0), so all loads of
+                // 4 documents x kz taps are independent and in flight together
+                for (int dl = 0; dl < nb; dl += 4) {
+                    float x[4][kMaxKF], sc[4][kMaxKF];
 #pragma unroll
-                    for (int j = 0; j < kMaxKF; ++j) {
-                        if (j < kz) {
-                            const long row = s_row[dl * kz + j];
-                            if (row >= 0) acc[j] = fmaf(s_sc[dl * kz + j], table[row + d], acc[j]);
+                    for (int q = 0; q < 4; ++q) {
+                        const int dq = min(dl + q, nb - 1);
+                        const bool ok = dl + q < nb;
+#pragma unroll
+                        for (int j = 0; j < kMaxKF; ++j) {
+                            if (j < kz) {
+                                x[q][j] = table[s_row[dq * kz + j] + d];
+                                sc[q][j] = ok ? s_sc[dq * kz + j] : 0.f;
+                            }
                         }
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int j = 0; j < kMaxKF; ++j)
+                            if (j < kz) acc[j] = fmaf(sc[q][j], x[q][j], acc[j]);
                 }
             }
         }
@@ -147,10 +164,13 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const f
 // one wave per token sums its items in registers (lanes over the embedding dim, no LDS traffic) and
 // issues ONE row of 256-byte contiguous f32 atomics.  Folding same-token rows before the atomics is
 // what keeps Zipf-hot rows ("the", ",") from serialising the memory-side atomic units.
-constexpr int kWin = 64;
-constexpr int kMaxDI = 8;   // embedding dim handled per pass = 64 lanes * kMaxDI
+constexpr int kWinMax = 512;   // token positions per workgroup window (upper bound)
+constexpr int kHash = 1024;    // open-addressing table: token id -> first row of the window with that id
+constexpr int kMaxDI = 8;      // embedding dim handled per pass = 64 lanes * kMaxDI (scalar path)
+constexpr int kMaxQ4 = 2;      // float4 columns per lane and pass (vector path): 512 floats per pass
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const int nwin,
+__global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const int kWin, const int nwin,
                                                         const long long* __restrict__ ids,
                                                         const unsigned char* __restrict__ mask,
                                                         const float* __restrict__ gate, const float* __restrict__ table,
@@ -160,37 +180,57 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
     constexpr int kCap = kChanBatch * kMaxKF;
     __shared__ int s_item_w[kCap];          // offset of W[c, 0, j] in the packed image
     __shared__ float s_item_g[kCap];        // g = d_feat * act'(feat)
-    __shared__ unsigned char s_item_row[kCap];
+    __shared__ short s_item_row[kCap];
     __shared__ short s_sorted[kCap];        // item indices grouped by key
-    __shared__ long s_tok[kWin];            // token id of the row (-1: masked / outside the document)
-    __shared__ int s_leader[kWin];
-    __shared__ int s_cnt[kWin], s_start[kWin], s_fill[kWin];
+    __shared__ int s_tok[kWinMax];          // token id of the row (-1: masked / outside the document)
+    __shared__ short s_leader[kWinMax];
+    __shared__ short s_cnt[kWinMax], s_start[kWinMax];
+    __shared__ int s_fill[kWinMax];
+    __shared__ int s_hkey[kHash], s_hval[kHash];
     __shared__ int s_count;
+    __shared__ __attribute__((aligned(16))) float s_strip[4 * 64 * kMaxQ4 * 4];   // per-wave transpose strip
+    const bool vec4 = (A.D % 4 == 0) && (A.DC % 4 == 0) && ((((uintptr_t)table) & 15) == 0);
     const int doc = blockIdx.x / nwin, p0 = (blockIdx.x % nwin) * kWin;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = A.L, D = A.D, C = A.C, KF = A.KF, DC = A.DC;
-    const int piece = kTile * DC;
+    const int piece = kTile * DC;                 // one channel tile of the packed image
+    const int dcstride = A.tiles_total * piece;   // packed[s][dc][tile][slot][dd]
 
-    if (tid < kWin) {
-        const int p = p0 + tid;
-        long t = -1;
-        if (p < L && (mask == nullptr || mask[(long)doc * L + p])) t = ids[(long)doc * L + p];
-        s_tok[tid] = t;
+    for (int k = tid; k < kHash; k += 256) { s_hkey[k] = -1; s_hval[k] = kWinMax; }
+    for (int r = tid; r < kWin; r += 256) {
+        const int p = p0 + r;
+        int t = -1;
+        if (p < L && (mask == nullptr || mask[(long)doc * L + p])) t = (int)ids[(long)doc * L + p];
+        s_tok[r] = t;
     }
     __syncthreads();
-    if (tid < kWin) {
-        int lead = tid;
-        const long t = s_tok[tid];
-        for (int r = 0; r < tid; ++r)
-            if (s_tok[r] == t) { lead = r; break; }
-        s_leader[tid] = lead;
+    // leader[r] = first row of the window that carries the same token (hash table, then a min per slot)
+    for (int r = tid; r < kWin; r += 256) {
+        const int t = s_tok[r];
+        int slot = -1;
+        if (t >= 0) {
+            unsigned hh = ((unsigned)t * 2654435761u) >> 22;   // 10 bits
+            for (;;) {
+                const int old = atomicCAS(&s_hkey[hh], -1, t);
+                if (old == -1 || old == t) break;
+                hh = (hh + 1) & (kHash - 1);
+            }
+            atomicMin(&s_hval[hh], r);
+            slot = (int)hh;
+        }
+        s_leader[r] = (short)slot;       // temporarily the hash slot
+    }
+    __syncthreads();
+    for (int r = tid; r < kWin; r += 256) {
+        const int slot = s_leader[r];
+        s_leader[r] = (short)(slot >= 0 ? s_hval[slot] : r);
     }
 
     for (int c0 = 0; c0 < C; c0 += kChanBatch) {
         const int nc = min(kChanBatch, C - c0);
         __syncthreads();
         if (tid == 0) s_count = 0;
-        if (tid < kWin) { s_cnt[tid] = 0; s_fill[tid] = 0; }
+        for (int r = tid; r < kWin; r += 256) { s_cnt[r] = 0; s_fill[r] = 0; }
         __syncthreads();
         // ---- collect the items of this window ------------------------------------------------------
         for (int e = tid; e < nc * KF; e += 256) {
@@ -210,15 +250,26 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
             const int off = (A.pad_mode == RBR_PAD_SAME) ? (KF - kz) / 2 : 0;
             const int t = slot / kTile, i = slot % kTile, s = j + off;
             const int k = atomicAdd(&s_count, 1);
-            s_item_row[k] = (unsigned char)(p - p0);
-            s_item_w[k] = ((t * KF + s) * A.nchunks) * piece + i * DC;
+            s_item_row[k] = (short)(p - p0);
+            s_item_w[k] = (s * A.nchunks * A.tiles_total + t) * piece + i * DC;
             s_item_g[k] = g;
-            atomicAdd(&s_cnt[s_leader[p - p0]], 1);
+            atomicAdd(&s_fill[s_leader[p - p0]], 1);          // per-key item count (int atomics)
         }
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {   // exclusive scan of the per-key counts by one wave
             int run = 0;
-            for (int r = 0; r < kWin; ++r) { s_start[r] = run; run += s_cnt[r]; }
+            for (int r0 = 0; r0 < kWin; r0 += 64) {
+                const int r = r0 + lane;
+                const int c = (r < kWin) ? s_fill[r] : 0;
+                int inc = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(inc, o);
+                    if (lane >= o) inc += v;
+                }
+                if (r < kWin) { s_start[r] = (short)(run + inc - c); s_cnt[r] = (short)c; s_fill[r] = 0; }
+                run += __shfl(inc, 63);
+            }
         }
         __syncthreads();
         const int n = s_count;
@@ -228,12 +279,82 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
         }
         __syncthreads();
         // ---- one wave per token: register accumulation, then one row of atomics -------------------
+        if (A.dev_flags & 2) continue;
+        if (vec4) {
+            // lanes own float4 columns (D/4 of them, kMaxQ4 per lane); 4 items are loaded together
+            const int nq4 = D >> 2, qpc = DC >> 2;
+            for (int key = wave; key < kWin; key += 4) {
+                const int cnt = s_cnt[key];
+                if (cnt == 0) continue;                               // wave-uniform
+                const int base = s_start[key];
+                const long trow = (long)s_tok[key] * D;
+                const bool to_table = (dtable != nullptr) && (s_tok[key] != A.padding_idx);
+                for (int qblk = 0; qblk < nq4; qblk += 64 * kMaxQ4) {
+                    int doff[kMaxQ4];
+                    f32x4 sum[kMaxQ4], tv[kMaxQ4];
+#pragma unroll
+                    for (int u = 0; u < kMaxQ4; ++u) {
+                        const int q4 = qblk + lane + 64 * u;
+                        const int dc = q4 / qpc;
+                        doff[u] = (q4 < nq4) ? dc * dcstride + 4 * (q4 - dc * qpc) : -1;
+                        sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        tv[u] = (gate != nullptr && q4 < nq4) ? *reinterpret_cast<const f32x4*>(table + trow + 4 * q4)
+                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    for (int q0 = 0; q0 < cnt; q0 += 4) {
+                        f32x4 wv[4][kMaxQ4];
+                        float gg[4], gv[4];
+                        long tok[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const bool ok = q0 + v < cnt;
+                            const int it = s_sorted[base + (ok ? q0 + v : q0)];
+                            const float* wrow = packed + s_item_w[it];
+                            gg[v] = ok ? s_item_g[it] : 0.f;
+                            tok[v] = (long)doc * L + p0 + s_item_row[it];
+                            gv[v] = (gate != nullptr) ? gate[tok[v]] : 1.f;
+#pragma unroll
+                            for (int u = 0; u < kMaxQ4; ++u)
+                                wv[v][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u])
+                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            float dot = 0.f;
+#pragma unroll
+                            for (int u = 0; u < kMaxQ4; ++u) {
+                                sum[u] += (gg[v] * gv[v]) * wv[v][u];
+                                const f32x4 pr = wv[v][u] * tv[u];
+                                dot += gg[v] * (pr.x + pr.y + pr.z + pr.w);
+                            }
+                            if (gate != nullptr && dgate != nullptr && q0 + v < cnt) {
+#pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+                                if (lane == 0) atomicAdd(dgate + tok[v], dot);
+                            }
+                        }
+                    }
+                    if (A.dev_flags & 1) { if (sum[0].x == 1.2345f) dtable[0] = sum[1].y; }
+                    if (to_table && !(A.dev_flags & 1)) {
+                        // transpose through the wave's LDS strip so each atomic wave-instruction covers 256
+                        // contiguous bytes of the table row
+                        float* strip = s_strip + wave * (64 * kMaxQ4 * 4);
+#pragma unroll
+                        for (int u = 0; u < kMaxQ4; ++u)
+                            if (doff[u] >= 0) *reinterpret_cast<f32x4*>(strip + 4 * (lane + 64 * u)) = sum[u];
+                        const int d0 = 4 * qblk, nd = min(D - d0, 64 * kMaxQ4 * 4);
+                        for (int dd = lane; dd < nd; dd += 64) atomicAdd(dtable + trow + d0 + dd, strip[dd]);
+                    }
+                }
+            }
+            continue;
+        }
         for (int key = wave; key < kWin; key += 4) {
             const int cnt = s_cnt[key];
             if (cnt == 0) continue;                               // wave-uniform
             const int base = s_start[key];
-            const long trow = s_tok[key] * (long)D;
-            const bool to_table = (dtable != nullptr) && (s_tok[key] != (long)A.padding_idx);
+            const long trow = (long)s_tok[key] * D;
+            const bool to_table = (dtable != nullptr) && (s_tok[key] != A.padding_idx);
             for (int dblk = 0; dblk < D; dblk += 64 * kMaxDI) {
                 int doff[kMaxDI];
                 float sum[kMaxDI], tv[kMaxDI];
@@ -241,7 +362,7 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
                 for (int u = 0; u < kMaxDI; ++u) {
                     const int d = dblk + lane + 64 * u;
                     const int dc = d / DC;
-                    doff[u] = (d < D) ? dc * piece + (d - dc * DC) : -1;
+                    doff[u] = (d < D) ? dc * dcstride + (d - dc * DC) : -1;
                     sum[u] = 0.f;
                     tv[u] = (gate != nullptr && d < D) ? table[trow + d] : 0.f;
                 }
@@ -267,7 +388,7 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
                         if (lane == 0) atomicAdd(dgate + tok, dot);
                     }
                 }
-                if (to_table) {
+                if (to_table && !(A.dev_flags & 1)) {
 #pragma unroll
                     for (int u = 0; u < kMaxDI; ++u)
                         if (doff[u] >= 0) atomicAdd(dtable + trow + dblk + lane + 64 * u, sum[u]);
@@ -282,7 +403,7 @@ static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
     const ConvPlan& p = plans[0];
     memset(&A, 0, sizeof(A));
-    A.n_docs = d->n_docs; A.L = d->L; A.D = d->D; A.C = p.C; A.KF = p.KF; A.DC = p.DC; A.nchunks = p.nchunks;
+    A.n_docs = d->n_docs; A.L = d->L; A.D = d->D; A.C = p.C; A.KF = p.KF; A.DC = p.DC; A.nchunks = p.nchunks; A.tiles_total = p.tiles_total;
     A.pad_mode = d->pad_mode; A.act = d->act; A.padding_idx = d->padding_idx;
     A.n_widths = d->n_widths;
     for (int w = 0; w < d->n_widths; ++w) { A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = p.ch_off[w]; }
@@ -296,6 +417,8 @@ static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
     A.NCH = std::min(kMaxChunksBwd, (d->n_docs + kDocsPerBatch - 1) / kDocsPerBatch);
     A.DPC = (d->n_docs + A.NCH - 1) / A.NCH;
     A.NCH = (d->n_docs + A.DPC - 1) / A.DPC;
+    static const int flags = getenv("RBR_DEV_DX_ABLATE") ? atoi(getenv("RBR_DEV_DX_ABLATE")) : 0;
+    A.dev_flags = flags;
     return 0;
 }
 
@@ -334,9 +457,12 @@ extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, co
                        ws_w, ws_b, dWp, dbp);
     RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
     if (dtable != nullptr || (dgate != nullptr && gate != nullptr)) {
+        static const int win_env = getenv("RBR_DEV_DX_WIN") ? atoi(getenv("RBR_DEV_DX_WIN")) : 0;   // tuning aid
+        int kWin = win_env > 0 ? std::min(win_env, kWinMax) : 256;
+        kWin = std::min(kWin, ((A.L + 63) / 64) * 64);
         const int nwin = (A.L + kWin - 1) / kWin;
-        hipLaunchKernelGGL(dx_window_kernel, dim3((unsigned)(A.n_docs * nwin)), dim3(256), 0, st, A, nwin, ids64, mask,
-                           gate, table, packed, feat, argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
+        hipLaunchKernelGGL(dx_window_kernel, dim3((unsigned)(A.n_docs * nwin)), dim3(256), 0, st, A, kWin, nwin, ids64,
+                           mask, gate, table, packed, feat, argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
         RBR_CHECK_LAUNCH("textcnn dx_window launch");
     }
     return 0;

@@ -33,19 +33,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------ pack
-// packed[tile][s][dc][slot][dd] = W_w[chan_local][d = dc*DC+dd][j = s - off]   (0 outside)
+// packed[s][dc][tile][slot][dd] = W_w[chan_local][d = dc*DC+dd][j = s - off]   (0 outside); tiles are global
+// (all groups), so the two tiles of a paired piece are contiguous.
 __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrArray W, float* __restrict__ packed) {
     const int DC = P.DC;
-    const long per_tile = (long)P.KF * P.nchunks * kTile * DC;
-    const long total = (long)P.ntiles * per_tile;
-    float* out = packed + (long)P.tile_base * per_tile;
+    const long total = (long)P.KF * P.nchunks * P.ntiles * kTile * DC;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         long r = idx;
         const int dd = (int)(r % DC); r /= DC;
         const int slot = (int)(r % kTile); r /= kTile;
-        const int dc = (int)(r % P.nchunks); r /= P.nchunks;
-        const int s = (int)(r % P.KF);
-        const int t = (int)(r / P.KF);
+        const int t = (int)(r % P.ntiles); r /= P.ntiles;
+        const int dc = (int)(r % P.nchunks);
+        const int s = (int)(r / P.nchunks);
         const int ls = t * kTile + slot;
         const int chan = P.slot_chan[ls];
         float v = 0.f;
@@ -55,38 +54,38 @@ __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrAr
             const int d = dc * DC + dd;
             if (j >= 0 && j < kz && d < P.D) v = W.p[w][((long)(chan - P.ch_off[w]) * P.D + d) * kz + j];
         }
-        out[idx] = v;
+        packed[((((long)s * P.nchunks + dc) * P.tiles_total + P.tile_base + t) * kTile + slot) * DC + dd] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------ conv
 template <int DC>
-__device__ __forceinline__ void mma_piece(f32x16& acc, const float* __restrict__ xa, const float* __restrict__ wb, int h) {
-    // xa / wb already include the lane's row and the 4*h column offset.
-    // All LDS operands of the piece are requested up front (2 x DC/8 ds_read_b128): one wave alone then keeps
-    // the MFMA pipe fed -- issuing each read pair behind the previous MFMA group left ~40 % of the pipe idle.
-    constexpr int NQ = DC / 8;
-    f32x4 a[NQ], b[NQ];
+struct Frag {   // one operand of a piece: DC/8 ds_read_b128 plus a b64 tail when DC % 8 == 4
+    f32x4 v[DC / 8];
+    f32x2 t;
+    __device__ __forceinline__ void load(const float* __restrict__ p, int h) {
+        // p already includes the lane's row and the 4*h column offset
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        a[q] = *reinterpret_cast<const f32x4*>(xa + 8 * q);
-        b[q] = *reinterpret_cast<const f32x4*>(wb + 8 * q);
+        for (int q = 0; q < DC / 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(p + 8 * q);
+        t = f32x2{0.f, 0.f};
+        if (DC % 8 == 4) t = *reinterpret_cast<const f32x2*>(p - 4 * h + (DC - 4) + 2 * h);   // columns DC-4+2h, +1
     }
-    f32x2 at = {0.f, 0.f}, bt = {0.f, 0.f};
-    if (DC % 8 == 4) {  // last 4 columns: lane half h takes columns DC-4+2h, DC-4+2h+1
-        at = *reinterpret_cast<const f32x2*>(xa - 4 * h + (DC - 4) + 2 * h);
-        bt = *reinterpret_cast<const f32x2*>(wb - 4 * h + (DC - 4) + 2 * h);
-    }
+};
+
+// All LDS operands of a piece are requested up front: one wave alone then keeps the MFMA pipe fed (issuing each
+// read pair behind the previous MFMA group left ~40 % of the pipe idle).
+template <int DC>
+__device__ __forceinline__ void mma_chain(f32x16& acc, const Frag<DC>& a, const Frag<DC>& b) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+    for (int q = 0; q < DC / 8; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].x, b.v[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].y, b.v[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].z, b.v[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, b.v[q].w, acc, 0, 0, 0);
     }
     if (DC % 8 == 4) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at.x, bt.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at.y, bt.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.x, b.t.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.y, b.t.y, acc, 0, 0, 0);
     }
 }
 
@@ -98,11 +97,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                                                        int* __restrict__ pidx) {
     static_assert(DC % 4 == 0 && (DC / 4) % 2 == 1, "row stride must be 4*odd floats (bank-conflict-free b128 reads)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int PIECE = kTile * DC;              // floats per weight piece
-    constexpr int PIECE_V4 = PIECE / 4;
-    constexpr int NLD = (PIECE_V4 + 255) / 256;    // float4 prefetch registers per thread
+    constexpr int TILE_F = kTile * DC;             // floats of one channel tile of a piece
+    constexpr int PIECE = 2 * TILE_F;              // LDS ring slot: up to two tiles
+    constexpr int NLD = (PIECE / 4 + 255) / 256;   // float4 prefetch registers per thread
     const int XR = kTile + P.KF - 1;               // token rows per wave slab
-    float* Ws = smem;                              // [2][32][DC]
+    float* Ws = smem;                              // [2][2][32][DC]
     float* Xs = smem + 2 * PIECE;                  // [4 waves][XR][DC]
 
     const int tid = threadIdx.x;
@@ -111,8 +110,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const int i = lane & 31, h = lane >> 5;
     const int L = P.L, D = P.D;
     float* Xw = Xs + wave * XR * DC;
-    const long per_tile = (long)P.KF * P.nchunks * PIECE;
-    const float* wbase = packed + (long)P.tile_base * per_tile;
+    const float* wbase = packed + (long)P.tile_base * TILE_F;
     const int nitems = (P.total_wt + kWavesPerWG - 1) / kWavesPerWG;
 
   // Persistent workgroups walk the items (4 consecutive wave-tiles each) with a fixed stride.  All items
@@ -133,10 +131,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    int pre_v4 = 0;   // float4 count of the piece being prefetched (wave-uniform)
     auto piece_src = [&](int dc, int pi) -> const float* {
         const int st = P.piece_st[pi];
-        const int s = st & 0xff, t = st >> 8;
-        return wbase + ((long)(t * P.KF + s) * P.nchunks + dc) * PIECE;
+        const int s = st & 0xff, t = (st >> 8) & 0xff;
+        pre_v4 = (st >> 16) * (TILE_F / 4);
+        return wbase + (((long)s * P.nchunks + dc) * P.tiles_total + t) * TILE_F;
     };
 
     f32x4 pre[NLD];
@@ -144,14 +144,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int v = tid + 256 * k;
-            if (v < PIECE_V4) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * v);
+            if (v < pre_v4) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * v);
         }
     };
     auto commit = [&](float* dst) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int v = tid + 256 * k;
-            if (v < PIECE_V4) *reinterpret_cast<f32x4*>(dst + 4 * v) = pre[k];
+            if (v < pre_v4) *reinterpret_cast<f32x4*>(dst + 4 * v) = pre[k];
         }
     };
 
@@ -206,12 +206,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             }
             if (active) {
                 const int st = P.piece_st[pi];
-                const int s = st & 0xff, t = st >> 8;
-                const float* xa = Xw + (i + s) * DC + 4 * h;
+                const int s = st & 0xff, t = (st >> 8) & 0xff, nt = st >> 16;
                 const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
+                Frag<DC> a, b;
+                a.load(Xw + (i + s) * DC + 4 * h, h);
+                b.load(wb, h);
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-                    if (tt == t) mma_piece<DC>(acc[tt], xa, wb, h);
+                for (int tt = 0; tt < NT; ++tt) {
+                    if (tt == t) {
+                        mma_chain<DC>(acc[tt], a, b);
+                        if (tt + 1 < NT && nt == 2) {     // second tile of the pair: same token rows
+                            b.load(wb + TILE_F, h);
+                            mma_chain<DC>(acc[tt + 1], a, b);
+                        }
+                    }
+                }
             }
             if (!last) commit(Ws + (cur ^ 1) * PIECE);
             __syncthreads();
@@ -289,7 +298,7 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
                           const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
     const int XR = kTile + p.KF - 1;
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
-    const size_t smem = (size_t)(2 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) + extra_lds;
+    const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) + extra_lds;
     static int occ = 0;   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
     if (occ == 0) {
         int nb = 0;
@@ -318,7 +327,7 @@ static int launch_conv(const ConvPlan& p, const long long* ids, const unsigned c
 }
 
 static size_t packed_floats(const ConvPlan& p0) {
-    return (size_t)(p0.nslots_total / kTile) * p0.KF * p0.nchunks * kTile * p0.DC;
+    return (size_t)p0.tiles_total * p0.KF * p0.nchunks * kTile * p0.DC;
 }
 
 }  // namespace rbr
