@@ -170,6 +170,35 @@ int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids
                              const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                              float* db0, float* dtable, float* ws, void* stream);
 
+/* ---- nn.Linear (+ReLU, + dropout multiplier) on the f32 MFMA pipe: y = (relu?)(x @ W^T + b) * drop
+ *      replaces D-ATT's shared fc (dual_att/dual_att.py:31-35,51,57) and HierPooling's projection
+ *      (deepconn/layers.py:76-79,96).  x [N,IN], W [OUT,IN] (torch layout), b [OUT] or NULL,
+ *      drop [N,OUT] multiplier or NULL, y [N,OUT].
+ *      Backward: d_x [N,IN] (NULL to skip), dW [OUT,IN], db [OUT] (NULL to skip) overwritten;
+ *      ws: rbr_linear_bwd_ws_floats(N, OUT) floats.                                           ---- */
+int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b, int32_t relu,
+                   const float* drop, float* y, void* stream);
+size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT);
+int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
+                   int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, void* stream);
+
+/* ---- standalone word-embedding row gather / scatter-add (WordEmbedding.forward, deepconn/layers.py:22-24).
+ *      The models never call these (the gather is fused into the conv kernel); they serve callers that
+ *      want the materialised rows.  out [n_tok, D];  dtable ACCUMULATED, row pad_idx excluded.   ---- */
+int rbr_embedding_fwd(int64_t n_tok, int32_t D, const int64_t* ids, const float* table, float* out, void* stream);
+int rbr_embedding_bwd(int64_t n_tok, int32_t D, const int64_t* ids, const float* d_out, int32_t pad_idx, float* dtable,
+                      void* stream);
+
+/* ---- NgramFeat arch="HierPooling" (deepconn/layers.py:62-98,110-114): pooled[doc,d] =
+ *      max_l mean_{j<k} x[doc,l+j,d] over l in [0, L-k], x = mask * table[ids]; relu != 0 applies the
+ *      trailing ReLU when there is no projection layer.  argmax[doc,d] = first maximising window start.
+ *      Backward: dtable ACCUMULATED (each of the k rows of the winning window gets g/k).          ---- */
+int rbr_hier_pool_fwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
+                      const float* table, int32_t relu, float* pooled, int32_t* argmax, void* stream);
+int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
+                      const int32_t* argmax, const float* pooled, const float* d_pooled, int32_t relu, int32_t pad_idx,
+                      float* dtable, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,15 @@ SIGNATURES = {
                                           c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_datt_global_gate_bwd": (C.c_int, [i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p,
                                            c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_linear_fwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_stream]),
+    "rbr_linear_bwd_ws_floats": (C.c_size_t, [i32, i32]),
+    "rbr_linear_bwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                 c_f32p, c_stream]),
+    "rbr_embedding_fwd": (C.c_int, [C.c_int64, i32, c_i64p, c_f32p, c_f32p, c_stream]),
+    "rbr_embedding_bwd": (C.c_int, [C.c_int64, i32, c_i64p, c_f32p, i32, c_f32p, c_stream]),
+    "rbr_hier_pool_fwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_u8p, c_f32p, i32, c_f32p, c_i32p, c_stream]),
+    "rbr_hier_pool_bwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_u8p, c_i32p, c_f32p, c_f32p, i32, i32, c_f32p,
+                                    c_stream]),
 }
 
 _lib = None
@@ -111,8 +120,6 @@ def lib() -> C.CDLL:
             try:
                 fn = getattr(handle, name)
             except AttributeError as e:
-                if os.environ.get("RBR_DEV_PARTIAL_LIB") == "1":   # bring-up only: symbol raises when called
-                    continue
                 raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,264 @@
+// dense_misc.hip -- the remaining small layers of the path:
+//   * nn.Linear (+ReLU, +dropout multiplier) forward/backward on the f32 MFMA pipe:
+//       D-ATT's shared fc (dual_att.py:31-35: Linear 500->500, ReLU, Dropout, Linear 500->50) and
+//       HierPooling's optional projection (deepconn/layers.py:76-79,96);
+//   * standalone embedding row gather / scatter-add (WordEmbedding.forward, layers.py:22-24), for
+//     callers that want the materialised rows;
+//   * NgramFeat arch="HierPooling" (layers.py:62-98,110-114): sliding-window mean + global max.
+#include "rbr_common.h"
+
+namespace rbr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------ GEMM
+// C[M,N] = A . B^T-like with arbitrary element strides: A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk].
+// 64x64 output tile per workgroup (4 waves x 32x32 MFMA tile), K in chunks of 32 staged through LDS
+// (row stride 36 floats = 4*odd: conflict-free ds_read_b128).  Sizes here are tiny (<= 1 GFLOP), so the
+// kernel is written for generality (any strides / bounds), not for the last 20 % of the MFMA roofline.
+constexpr int GK = 32, GS = 36;
+
+struct Epi {
+    const float* bias;   // [N] or null
+    const float* mul;    // [M,N] multiplier (dropout) or null
+    int relu;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long sam, long sak,
+                                                   const float* __restrict__ B, long sbn, long sbk, float* __restrict__ C,
+                                                   long ldc, const Epi ep) {
+    __shared__ __attribute__((aligned(16))) float As[64 * GS];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            {   // A: lanes along the contiguous dimension
+                const int row = (sak == 1) ? e / GK : e % 64, kk = (sak == 1) ? e % GK : e / 64;
+                const int m = m0 + row, k = k0 + kk;
+                As[row * GS + kk] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+            }
+            {
+                const int row = (sbk == 1) ? e / GK : e % 64, kk = (sbk == 1) ? e % GK : e / 64;
+                const int n = n0 + row, k = k0 + kk;
+                Bs[row * GS + kk] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
+            }
+        }
+        __syncthreads();
+        const float* pa = As + (wm * 32 + i) * GS + 4 * h;
+        const float* pb = Bs + (wn * 32 + i) * GS + 4 * h;
+#pragma unroll
+        for (int q = 0; q < GK / 8; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pa + 8 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(pb + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    const int n = n0 + wn * 32 + i;
+    if (n >= N) return;
+    const float bv = ep.bias ? ep.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) {
+            float v = acc[r] + bv;
+            if (ep.relu) v = fmaxf(v, 0.f);
+            if (ep.mul) v *= ep.mul[(long)m * N + n];
+            C[(long)m * ldc + n] = v;
+        }
+    }
+}
+
+static int launch_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
+                       long ldc, Epi ep, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, C,
+                       ldc, ep);
+    RBR_CHECK_LAUNCH("gemm launch");
+    return 0;
+}
+
+// dyeff = dy * mul * (y > 0 when relu);  y is the layer OUTPUT (post relu, post mul)
+__global__ __launch_bounds__(256) void act_bwd_kernel(long n, const float* __restrict__ dy, const float* __restrict__ y,
+                                                      const float* __restrict__ mul, int relu, float* __restrict__ out) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        float v = dy[k];
+        if (mul) v *= mul[k];
+        if (relu) {
+            // y = relu(z) * mul: z > 0  <=>  y != 0 unless mul == 0 (then v is already 0)
+            const bool pos = mul ? (y[k] != 0.f) : (y[k] > 0.f);
+            if (!pos) v = 0.f;
+        }
+        out[k] = v;
+    }
+}
+
+// db[n] = sum_m g[m, n]   (fixed order)
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ g, float* __restrict__ db) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += g[(long)m * N + n];
+    db[n] = s;
+}
+
+// ------------------------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(256) void emb_fwd_kernel(long n_tok, int D, const long long* __restrict__ ids,
+                                                      const float* __restrict__ table, float* __restrict__ out) {
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const float* row = table + ids[tok] * (long)D;
+    for (int d = threadIdx.x & 63; d < D; d += 64) out[tok * D + d] = row[d];
+}
+
+__global__ __launch_bounds__(256) void emb_bwd_kernel(long n_tok, int D, const long long* __restrict__ ids,
+                                                      const float* __restrict__ d_out, int pad_idx, float* __restrict__ dtable) {
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= n_tok) return;
+    const long id = ids[tok];
+    if (id == pad_idx) return;
+    for (int d = threadIdx.x & 63; d < D; d += 64) atomicAdd(dtable + id * D + d, d_out[tok * D + d]);
+}
+
+// ------------------------------------------------------------------------------------ HierPooling
+// pooled[doc, d] = max_{l in [0, L-k]} (sum_{j<k} x[doc, l+j, d]) / k, x = mask * table[ids]; first argmax kept.
+// The window sum is re-formed in the reference's order (j ascending) at every l, so values match avg_pool1d.
+__global__ __launch_bounds__(256) void hier_fwd_kernel(int n_docs, int L, int D, int k, const long long* __restrict__ ids,
+                                                       const unsigned char* __restrict__ mask, const float* __restrict__ table,
+                                                       int relu, float* __restrict__ pooled, int* __restrict__ argmax) {
+    extern __shared__ long s_row[];   // [L] table row offset or -1
+    const int doc = blockIdx.x, tid = threadIdx.x;
+    for (int l = tid; l < L; l += 256) {
+        const long tok = (long)doc * L + l;
+        s_row[l] = (mask == nullptr || mask[tok]) ? ids[tok] * (long)D : -1;
+    }
+    __syncthreads();
+    const float inv = 1.f;  // division below, as ATen does (sum / k)
+    (void)inv;
+    for (int d = tid; d < D; d += 256) {
+        float best = -__builtin_huge_valf();
+        int bidx = 0;
+        for (int l = 0; l + k <= L; ++l) {
+            float s = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const long row = s_row[l + j];
+                s += (row >= 0) ? table[row + d] : 0.f;
+            }
+            const float v = s / (float)k;
+            if (v > best) { best = v; bidx = l; }
+        }
+        pooled[(long)doc * D + d] = relu ? fmaxf(best, 0.f) : best;
+        argmax[(long)doc * D + d] = bidx;
+    }
+}
+
+__global__ __launch_bounds__(256) void hier_bwd_kernel(int n_docs, int L, int D, int k, const long long* __restrict__ ids,
+                                                       const unsigned char* __restrict__ mask, const int* __restrict__ argmax,
+                                                       const float* __restrict__ pooled, const float* __restrict__ d_pooled,
+                                                       int relu, int pad_idx, float* __restrict__ dtable) {
+    const int doc = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float g = d_pooled[(long)doc * D + d];
+        if (relu && !(pooled[(long)doc * D + d] > 0.f)) g = 0.f;
+        if (g == 0.f) continue;
+        g /= (float)k;
+        const int l0 = argmax[(long)doc * D + d];
+        for (int j = 0; j < k; ++j) {
+            const long tok = (long)doc * L + l0 + j;
+            if (mask != nullptr && !mask[tok]) continue;
+            const long id = ids[tok];
+            if (id == pad_idx) continue;
+            atomicAdd(dtable + id * D + d, g);
+        }
+    }
+}
+
+}  // namespace rbr
+
+using namespace rbr;
+
+extern "C" int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b,
+                              int32_t relu, const float* drop, float* y, void* stream) {
+    if (N <= 0 || IN <= 0 || OUT <= 0) { set_error("bad linear shape"); return RBR_ERR_BAD_ARG; }
+    if (!x || !W || !y) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    Epi ep{b, drop, relu};
+    return launch_gemm(N, OUT, IN, x, IN, 1, W, IN, 1, y, OUT, ep, (hipStream_t)stream);
+}
+
+extern "C" size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT) { return (size_t)N * OUT; }
+
+extern "C" int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y,
+                              const float* d_y, int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws,
+                              void* stream) {
+    if (N <= 0 || IN <= 0 || OUT <= 0) { set_error("bad linear shape"); return RBR_ERR_BAD_ARG; }
+    if (!x || !W || !y || !d_y || !dW || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const float* g = d_y;
+    if (relu || drop) {
+        const long n = (long)N * OUT;
+        hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st, n, d_y, y,
+                           drop, relu, ws);
+        RBR_CHECK_LAUNCH("linear act_bwd launch");
+        g = ws;
+    }
+    Epi none{nullptr, nullptr, 0};
+    // dW[OUT, IN] = g^T[OUT, N] . x[N, IN]:  A(m=o, k=n) = g[n*OUT + o], B(n=i, k=n) = x[n*IN + i]
+    if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st)) return e;
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((OUT + 255) / 256), dim3(256), 0, st, N, OUT, g, db);
+        RBR_CHECK_LAUNCH("linear colsum launch");
+    }
+    // d_x[N, IN] = g[N, OUT] . W[OUT, IN]:  A(m=n, k=o) = g[n*OUT + o], B(n=i, k=o) = W[o*IN + i]
+    if (d_x) return launch_gemm(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, st);
+    return 0;
+}
+
+extern "C" int rbr_embedding_fwd(int64_t n_tok, int32_t D, const int64_t* ids, const float* table, float* out, void* stream) {
+    if (n_tok <= 0 || D <= 0 || !ids || !table || !out) { set_error("bad embedding arguments"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(emb_fwd_kernel, dim3((unsigned)((n_tok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)n_tok, D,
+                       reinterpret_cast<const long long*>(ids), table, out);
+    RBR_CHECK_LAUNCH("embedding fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_embedding_bwd(int64_t n_tok, int32_t D, const int64_t* ids, const float* d_out, int32_t pad_idx,
+                                 float* dtable, void* stream) {
+    if (n_tok <= 0 || D <= 0 || !ids || !d_out || !dtable) { set_error("bad embedding arguments"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(emb_bwd_kernel, dim3((unsigned)((n_tok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (long)n_tok, D,
+                       reinterpret_cast<const long long*>(ids), d_out, pad_idx, dtable);
+    RBR_CHECK_LAUNCH("embedding bwd launch");
+    return 0;
+}
+
+extern "C" int rbr_hier_pool_fwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
+                                 const float* table, int32_t relu, float* pooled, int32_t* argmax, void* stream) {
+    if (n_docs <= 0 || L <= 0 || D <= 0 || k <= 0 || k > L) { set_error("bad hier_pool shape"); return RBR_ERR_BAD_ARG; }
+    if (!ids || !table || !pooled || !argmax) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if ((size_t)L * sizeof(long) > 60 * 1024) { set_error("doc_len %d too large", L); return RBR_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(hier_fwd_kernel, dim3(n_docs), dim3(256), (size_t)L * sizeof(long), (hipStream_t)stream, n_docs, L, D, k,
+                       reinterpret_cast<const long long*>(ids), mask, table, relu, pooled, argmax);
+    RBR_CHECK_LAUNCH("hier_pool fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
+                                 const int32_t* argmax, const float* pooled, const float* d_pooled, int32_t relu,
+                                 int32_t pad_idx, float* dtable, void* stream) {
+    if (n_docs <= 0 || L <= 0 || D <= 0 || k <= 0) { set_error("bad hier_pool shape"); return RBR_ERR_BAD_ARG; }
+    if (!ids || !argmax || !pooled || !d_pooled || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(hier_bwd_kernel, dim3(n_docs), dim3(256), 0, (hipStream_t)stream, n_docs, L, D, k,
+                       reinterpret_cast<const long long*>(ids), mask, argmax, pooled, d_pooled, relu, pad_idx, dtable);
+    RBR_CHECK_LAUNCH("hier_pool bwd launch");
+    return 0;
+}

@@ -199,9 +199,233 @@ def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torc
     return torch.empty(shape, dtype=F32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
+
+# --------------------------------------------------------------------------- NARRE attention pool
+class _ReviewAttn(torch.autograd.Function):
+    """out[B,H], att[B,R,1] = LinearAttention(feat[B,R,H], other_id[B,R])  -- rbr_review_attn_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd):
+        B, R, H = feat.shape
+        A = W_rv.shape[1]
+        dev = feat.device
+        L_ = _lib.lib()
+        feat = feat.contiguous()
+        other_id = other_id.contiguous()
+        params = [t.contiguous() for t in (W_rv, W_id, h, b1, b2, ebd)]
+        names = ("W_rv", "W_id", "h", "b1", "b2", "ebd")
+        ap = _lib.AttnParams(*[dev_ptr(t, F32, n) for t, n in zip(params, names)])
+        out = torch.empty(B, H, dtype=F32, device=dev)
+        att = torch.empty(B, R, 1, dtype=F32, device=dev)
+        hid = torch.empty(B, R, A, dtype=F32, device=dev)
+        check(L_.rbr_review_attn_fwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(ap),
+                                     dev_ptr(out, F32, "out"), dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"),
+                                     current_stream()), "rbr_review_attn_fwd")
+        ctx.dims = (B, R, H, A, int(pad_idx))
+        ctx.save_for_backward(feat, other_id, att, hid, *params)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, d_out, d_att):
+        B, R, H, A, pad_idx = ctx.dims
+        feat, other_id, att, hid = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        names = ("W_rv", "W_id", "h", "b1", "b2", "ebd")
+        dev = feat.device
+        L_ = _lib.lib()
+        ap = _lib.AttnParams(*[dev_ptr(t, F32, n) for t, n in zip(params, names)])
+        grads = [torch.zeros_like(t) if n == "ebd" else torch.empty_like(t) for t, n in zip(params, names)]
+        ag = _lib.AttnGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
+        d_feat = torch.empty_like(feat)
+        ws = torch.empty(L_.rbr_review_attn_bwd_ws_floats(B, R, H, A), dtype=F32, device=dev)
+        d_out = d_out.contiguous()
+        d_att = d_att.contiguous() if d_att is not None else None
+        check(L_.rbr_review_attn_bwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(ap),
+                                     dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"), dev_ptr(d_out, F32, "d_out"),
+                                     dev_ptr(d_att, F32, "d_att"), pad_idx, C.byref(ag), dev_ptr(d_feat, F32, "d_feat"),
+                                     dev_ptr(ws, F32, "ws"), current_stream()), "rbr_review_attn_bwd")
+        return (d_feat, None, None, *grads)
+
+
+def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0):
+    """NARRE LinearAttention: returns (out [B,H], att [B,R,1])."""
+    return _ReviewAttn.apply(feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd)
+
+
+# --------------------------------------------------------------------------- nn.Linear on MFMA
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, relu, drop):
+        N, IN = x.shape
+        OUT = W.shape[0]
+        L_ = _lib.lib()
+        x, W = x.contiguous(), W.contiguous()
+        b = b.contiguous() if b is not None else None
+        drop = drop.contiguous() if drop is not None else None
+        y = torch.empty(N, OUT, dtype=F32, device=x.device)
+        check(L_.rbr_linear_fwd(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(b, F32, "b"), int(relu),
+                                dev_ptr(drop, F32, "drop"), dev_ptr(y, F32, "y"), current_stream()), "rbr_linear_fwd")
+        ctx.relu = int(relu)
+        ctx.has_b = b is not None
+        ctx.has_drop = drop is not None
+        ctx.save_for_backward(x, W, y, *([drop] if drop is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, W, y = ctx.saved_tensors[:3]
+        drop = ctx.saved_tensors[3] if ctx.has_drop else None
+        N, IN = x.shape
+        OUT = W.shape[0]
+        L_ = _lib.lib()
+        dev = x.device
+        d_y = d_y.contiguous()
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty(OUT, dtype=F32, device=dev) if ctx.has_b else None
+        ws = torch.empty(L_.rbr_linear_bwd_ws_floats(N, OUT), dtype=F32, device=dev)
+        check(L_.rbr_linear_bwd(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(y, F32, "y"),
+                                dev_ptr(d_y, F32, "d_y"), ctx.relu, dev_ptr(drop, F32, "drop"), dev_ptr(d_x, F32, "d_x"),
+                                dev_ptr(dW, F32, "dW"), dev_ptr(db, F32, "db"), dev_ptr(ws, F32, "ws"), current_stream()),
+              "rbr_linear_bwd")
+        return d_x, dW, db, None, None
+
+
+def linear(x, W, b=None, *, relu=False, drop=None):
+    """y = (relu)(x @ W^T + b) * drop  with torch's nn.Linear weight layout [OUT, IN]."""
+    return _Linear.apply(x, W, b, relu, drop)
+
+
+# --------------------------------------------------------------------------- standalone embedding
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, padding_idx):
+        L_ = _lib.lib()
+        table = table.contiguous()
+        flat = ids.contiguous().view(-1)
+        D = table.shape[1]
+        out = torch.empty(flat.numel(), D, dtype=F32, device=table.device)
+        if flat.numel():
+            check(L_.rbr_embedding_fwd(flat.numel(), D, dev_ptr(flat, I64, "ids"), dev_ptr(table, F32, "table"),
+                                       dev_ptr(out, F32, "out"), current_stream()), "rbr_embedding_fwd")
+        ctx.pad = -1 if padding_idx is None else int(padding_idx)
+        ctx.shape = table.shape
+        ctx.save_for_backward(flat)
+        return out.view(*ids.shape, D)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (flat,) = ctx.saved_tensors
+        L_ = _lib.lib()
+        D = ctx.shape[1]
+        dtable = torch.zeros(ctx.shape, dtype=F32, device=d_out.device)
+        d_out = d_out.contiguous().view(-1, D)
+        if flat.numel():
+            check(L_.rbr_embedding_bwd(flat.numel(), D, dev_ptr(flat, I64, "ids"), dev_ptr(d_out, F32, "d_out"), ctx.pad,
+                                       dev_ptr(dtable, F32, "dtable"), current_stream()), "rbr_embedding_bwd")
+        return dtable, None, None
+
+
 def embedding(table, ids, padding_idx=0):
-    raise RuntimeError("standalone embedding gather kernel is not part of this build yet")
+    """Materialised row gather table[ids] -> [*ids.shape, D] (WordEmbedding.forward)."""
+    return _Embedding.apply(table, ids, padding_idx)
+
+
+# --------------------------------------------------------------------------- HierPooling
+class _HierPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, mask, k, relu, padding_idx):
+        n_docs, L = ids.shape
+        V, D = table.shape
+        L_ = _lib.lib()
+        table = table.contiguous()
+        ids = ids.contiguous()
+        mask8 = _mask_u8(mask)
+        pooled = torch.empty(n_docs, D, dtype=F32, device=table.device)
+        argmax = torch.empty(n_docs, D, dtype=I32, device=table.device)
+        check(L_.rbr_hier_pool_fwd(n_docs, L, D, int(k), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                   dev_ptr(table, F32, "table"), int(relu), dev_ptr(pooled, F32, "pooled"),
+                                   dev_ptr(argmax, I32, "argmax"), current_stream()), "rbr_hier_pool_fwd")
+        ctx.args = (n_docs, L, D, int(k), int(relu), -1 if padding_idx is None else int(padding_idx), tuple(table.shape))
+        ctx.has_mask = mask8 is not None
+        ctx.save_for_backward(ids, argmax, pooled, *([mask8] if mask8 is not None else []))
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        n_docs, L, D, k, relu, pad, shape = ctx.args
+        ids, argmax, pooled = ctx.saved_tensors[:3]
+        mask8 = ctx.saved_tensors[3] if ctx.has_mask else None
+        L_ = _lib.lib()
+        dtable = torch.zeros(shape, dtype=F32, device=d_pooled.device)
+        d_pooled = d_pooled.contiguous()
+        check(L_.rbr_hier_pool_bwd(n_docs, L, D, k, dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                   dev_ptr(argmax, I32, "argmax"), dev_ptr(pooled, F32, "pooled"),
+                                   dev_ptr(d_pooled, F32, "d_pooled"), relu, pad, dev_ptr(dtable, F32, "dtable"),
+                                   current_stream()), "rbr_hier_pool_bwd")
+        return dtable, None, None, None, None, None
 
 
 def hier_pool(table, ids, masks, kernel_size, proj_w, proj_b, padding_idx=0):
-    raise RuntimeError("HierPooling kernel is not part of this build yet")
+    """NgramFeat arch="HierPooling": window mean -> global max -> optional Linear -> ReLU.  [n_docs, H]."""
+    if proj_w is None:
+        return _HierPool.apply(table, ids, masks, kernel_size, True, padding_idx)
+    pooled = _HierPool.apply(table, ids, masks, kernel_size, False, padding_idx)
+    return linear(pooled, proj_w, proj_b, relu=True)
+
+
+# --------------------------------------------------------------------------- D-ATT gates
+class _DattGate(torch.autograd.Function):
+    """gate[B,L] of LocalAttention (win odd) or GlobalAttention (is_global) -- rbr_datt_*_gate_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, table, w, b0, ids, is_global, padding_idx):
+        B, L = ids.shape
+        E = table.shape[1]
+        win = w.shape[2]
+        L_ = _lib.lib()
+        table, w, b0, ids = table.contiguous(), w.contiguous(), b0.contiguous(), ids.contiguous()
+        gate = torch.empty(B, L, dtype=F32, device=table.device)
+        if is_global:
+            if win != L:
+                raise RuntimeError(f"GlobalAttention weight spans {win} positions but documents have {L}")
+            check(L_.rbr_datt_global_gate_fwd(B, L, E, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                              dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
+                                              current_stream()), "rbr_datt_global_gate_fwd")
+        else:
+            check(L_.rbr_datt_local_gate_fwd(B, L, E, win, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                             dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
+                                             current_stream()), "rbr_datt_local_gate_fwd")
+        ctx.args = (B, L, E, win, bool(is_global), -1 if padding_idx is None else int(padding_idx))
+        ctx.save_for_backward(table, w, ids, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        B, L, E, win, is_global, pad = ctx.args
+        table, w, ids, gate = ctx.saved_tensors
+        L_ = _lib.lib()
+        dev = table.device
+        dgate = dgate.contiguous()
+        dw = torch.empty_like(w)
+        db0 = torch.empty(1, dtype=F32, device=dev)
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(max(1, L_.rbr_datt_gate_bwd_ws_floats(B, L, E, win, int(is_global))), dtype=F32, device=dev)
+        if is_global:
+            check(L_.rbr_datt_global_gate_bwd(B, L, E, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                              dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"), dev_ptr(dgate, F32, "dgate"),
+                                              pad, dev_ptr(dw, F32, "dw"), dev_ptr(db0, F32, "db0"),
+                                              dev_ptr(dtable, F32, "dtable"), dev_ptr(ws, F32, "ws"), current_stream()),
+                  "rbr_datt_global_gate_bwd")
+        else:
+            check(L_.rbr_datt_local_gate_bwd(B, L, E, win, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                             dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"), dev_ptr(dgate, F32, "dgate"),
+                                             pad, dev_ptr(dw, F32, "dw"), dev_ptr(db0, F32, "db0"),
+                                             dev_ptr(dtable, F32, "dtable"), dev_ptr(ws, F32, "ws"), current_stream()),
+                  "rbr_datt_local_gate_bwd")
+        return dtable, dw, db0, None, None, None
+
+
+def datt_gate(table, w, b0, ids, *, is_global, padding_idx=0):
+    """sigmoid attention gate [B,L]; w is the Conv1d weight [1,E,win] (local) or [1,E,L] (global)."""
+    return _DattGate.apply(table, w, b0, ids, is_global, padding_idx)
