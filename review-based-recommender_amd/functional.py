@@ -29,6 +29,7 @@ class _TextCNN(torch.autograd.Function):
     def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *wb):
         n = len(kernel_sizes)
         weights, biases = wb[:n], wb[n:]
+        dev_ptr(table.contiguous(), F32, "word table")   # device / dtype gate before anything touches HIP
         if ids.dim() != 2:
             raise RuntimeError("ids must be [n_docs, L]")
         n_docs, L = ids.shape

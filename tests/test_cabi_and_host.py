@@ -1,0 +1,103 @@
+"""CPU-only checks of the drop-in boundary: the shared library loads and exports every symbol that
+include/rbr_hip.h declares, the ctypes table mirrors the header, plan queries work without a GPU, and
+the host-side modules keep the reference's names / keys / error behaviour.  No kernel is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import synth
+from helpers import quiet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "rbr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from review_based_recommender_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 25
+    handle = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, f"librbr_hip.so lacks {missing}"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    L = _lib.lib()
+    assert L.rbr_version() >= 1
+
+
+def test_plan_queries_and_error_reporting_without_gpu():
+    from review_based_recommender_amd import _lib
+    L = _lib.lib()
+    d = _lib.make_desc(512, 512, 300, 50002, [3, 5, 7], [50, 50, 50], _lib.PAD_SAME, _lib.ACT_RELU, 0)
+    # 5 channel tiles x 7 taps x 5 chunks x 32 slots x 60 floats
+    assert L.rbr_textcnn_packed_floats(C.byref(d)) == 5 * 7 * 5 * 32 * 60
+    assert L.rbr_textcnn_partial_elems(C.byref(d)) == 512 * 16 * 160
+    assert L.rbr_textcnn_bwd_ws_floats(C.byref(d)) > 0
+    bad = _lib.make_desc(4, 16, 8, 20, [4], [6], _lib.PAD_SAME, _lib.ACT_RELU, 0)     # even 'same' width
+    assert L.rbr_textcnn_packed_floats(C.byref(bad)) == 0
+    assert b"odd" in L.rbr_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "demo")
+
+
+def test_product_refuses_cpu_tensors():
+    from review_based_recommender_amd import functional as RF
+    cfg = synth.DEEPCONN_CFGS["tiny"]
+    p = synth.deepconn_params(cfg, 0)
+    b = synth.deepconn_batch(cfg, 1)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        RF.textcnn(p["word_embeddings.embedding.weight"], b["u_docs"], b["u_masks"],
+                   [p["ngram.feature_layer.0.list_of_conv1d.0.weight"]], [p["ngram.feature_layer.0.list_of_conv1d.0.bias"]])
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "review-based-recommender_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("which", ["deepconn", "narre", "datt"])
+def test_state_dict_keys_and_init(which):
+    from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
+    from review_based_recommender_amd.models.dual_att.dual_att import DualAtt
+    from review_based_recommender_amd.models.narre.narre import NARRE
+    if which == "deepconn":
+        c = synth.DEEPCONN_CFGS["tiny"]
+        m = quiet(DeepCoNNpp, c["U"], c["I"], c["V"], c["kz"], c["D"], c["H"], c["K"], c["L"], None, 0.5)
+        ref = synth.deepconn_params(c, 0)
+        assert float(m.word_embeddings.embedding.weight[0].abs().max()) == 0.0   # pad row zero at init
+        assert float(m.user_feat.ebd.weight[0].abs().max()) > 0.0                 # quirk 4: re-initialised non-zero
+        assert torch.all(m.user_feat.b == 0.1) and float(m.fm.g_bias) == pytest.approx(0.1)
+    elif which == "narre":
+        c = synth.NARRE_CFGS["tiny"]
+        m = quiet(NARRE, c["U"], c["I"], c["V"], c["kz"], c["H"], c["D"], c["A"], c["K"], c["R"], c["T"], 0.5, 0, 0, 0,
+                  None, "CNN")
+        ref = synth.narre_params(c, 0)
+        assert m.user_att.ebd_vals.weight.shape[0] == c["I"]      # user tower keyed by ITEM ids
+    else:
+        c = synth.DATT_CFGS["tiny"]
+        m = quiet(DualAtt, c["V"], c["L"], c["win"], c["l_out"], c["g_out"], c["E"], c["h1"], c["h2"], 0.5, None)
+        ref = synth.datt_params(c, 0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    m.load_state_dict(ref)   # reference checkpoints load unchanged
+
+
+def test_pretrained_embeddings_and_freeze():
+    from review_based_recommender_amd.models.deepconn.layers import WordEmbedding
+    w = torch.arange(12, dtype=torch.float32).view(4, 3) + 1.0
+    e = quiet(WordEmbedding, 4, 3, pretrained_embeddings=w.numpy(), freeze_embeddings=True)
+    assert torch.equal(e.embedding.weight.detach(), w)       # pad row NOT zeroed when pretrained rows are loaded
+    assert not e.embedding.weight.requires_grad
