@@ -43,6 +43,18 @@ def conv_fwd_flops(cfg) -> float:
     return 2.0 * cfg["B"] * 2.0 * cfg["L"] * cfg["D"] * per_w * sum(cfg["kz"])
 
 
+def measured_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r01_conv_fwd_pmc.json:
+    FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 correction) -- not measurable from inside this
+    process; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_fwd_pmc.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def build_model(cfg, device):
     from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
     import contextlib
@@ -190,7 +202,8 @@ def main():
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel (gather+conv+max-pool, v_mfma_f32_32x32x2_f32)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
+                         "traffic_source": "profiles/r01_conv_fwd_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "flops_per_launch": flops, "avg_launch_ms": round(conv_ms, 4), "launches_timed": conv_calls},
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
         }
