@@ -9,6 +9,8 @@
 // One output channel => no GEMM shape; these are HBM/L2-bound row dot products on the VALU.
 #include "rbr_common.h"
 
+#include <algorithm>
+
 namespace rbr {
 
 __device__ __forceinline__ float wsum(float v) {
@@ -39,27 +41,132 @@ __global__ __launch_bounds__(256) void local_gate_fwd_kernel(int B, int L, int E
     if (lane == 0) gate[tok] = sigmoidf_(s + b0[0]);
 }
 
-// dtable[id(b,p), e] += sum_j dpre[b, p - j + pad] * w[e, j]      (one wave per token p)
-__global__ __launch_bounds__(256) void local_gate_bwd_dx_kernel(int B, int L, int E, int win,
-                                                                const long long* __restrict__ ids, const float* __restrict__ w,
-                                                                const float* __restrict__ gate, const float* __restrict__ dgate,
-                                                                int pad_idx, float* __restrict__ dtable) {
-    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (tok >= (long)B * L) return;
-    const int b = (int)(tok / L), p = (int)(tok % L);
-    const long id = ids[tok];
-    if (id == pad_idx) return;
+// ---- token-folded embedding gradient of a gate -----------------------------------------------------------
+// dtable[id, :] += sum over the positions p of the window that carry token `id` of  row_p[:], with
+//   local : row_p[e] = sum_j dpre[b, p - j + pad] * w[e, j]   ==>  sum_p row_p[e] = sum_j c_j * w[e, j],
+//           c_j = sum_p dpre[b, p - j + pad]                        (win scalars per token)
+//   global: row_p[e] = dpre[b] * w[e, p]                        ==>  dpre[b] * sum_p wT[p, e]
+// One workgroup per (document, window of <= 256 positions): positions are bucketed by token through an LDS
+// hash table, one wave per distinct token builds the folded row and issues ONE row of contiguous f32 atomics
+// (a per-token atomic row for each of the 1 M tokens of cfg4 ran 1.3 ms: Zipf-hot rows serialise).
+constexpr int kGWin = 256, kGHash = 1024;
+
+__global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, int win, int is_global, int nwin,
+                                                          const long long* __restrict__ ids, const float* __restrict__ w,
+                                                          const float* __restrict__ wT, const float* __restrict__ gate,
+                                                          const float* __restrict__ dgate, const float* __restrict__ dpre_g,
+                                                          int pad_idx, float* __restrict__ dtable) {
+    __shared__ int s_tok[kGWin];
+    __shared__ short s_leader[kGWin], s_cnt[kGWin], s_start[kGWin], s_sorted[kGWin];
+    __shared__ int s_fill[kGWin];
+    __shared__ int s_hkey[kGHash], s_hval[kGHash];
+    __shared__ float s_dpre[kGWin + 2 * kMaxKF];     // local: dpre of the window plus a halo of `pad` each side
+    const int b = blockIdx.x / nwin, p0 = (blockIdx.x % nwin) * kGWin;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pad = (win - 1) / 2;
-    for (int e = lane; e < E; e += 64) {
-        float s = 0.f;
-        for (int j = 0; j < win; ++j) {
-            const int l = p - j + pad;
-            if (l < 0 || l >= L) continue;
-            const float gv = gate[(long)b * L + l];
-            s = fmaf(dgate[(long)b * L + l] * gv * (1.f - gv), w[(long)e * win + j], s);
+    const int nrow = min(kGWin, L - p0);
+
+    for (int k = tid; k < kGHash; k += 256) { s_hkey[k] = -1; s_hval[k] = kGWin; }
+    for (int r = tid; r < kGWin; r += 256) {
+        int t = -1;
+        if (r < nrow) { t = (int)ids[(long)b * L + p0 + r]; if (t == pad_idx) t = -1; }
+        s_tok[r] = t;
+        s_fill[r] = 0;
+    }
+    if (!is_global) {
+        for (int k = tid; k < kGWin + 2 * pad; k += 256) {
+            const int l = p0 - pad + k;
+            float v = 0.f;
+            if (l >= 0 && l < L) { const float gv = gate[(long)b * L + l]; v = dgate[(long)b * L + l] * gv * (1.f - gv); }
+            s_dpre[k] = v;
         }
-        atomicAdd(dtable + id * E + e, s);
+    }
+    __syncthreads();
+    for (int r = tid; r < kGWin; r += 256) {
+        const int t = s_tok[r];
+        int slot = -1;
+        if (t >= 0) {
+            unsigned hh = ((unsigned)t * 2654435761u) >> 22;
+            for (;;) {
+                const int old = atomicCAS(&s_hkey[hh], -1, t);
+                if (old == -1 || old == t) break;
+                hh = (hh + 1) & (kGHash - 1);
+            }
+            atomicMin(&s_hval[hh], r);
+            slot = (int)hh;
+        }
+        s_leader[r] = (short)slot;
+    }
+    __syncthreads();
+    for (int r = tid; r < kGWin; r += 256) {
+        const int slot = s_leader[r];
+        const int lead = slot >= 0 ? s_hval[slot] : -1;
+        s_leader[r] = (short)lead;
+        if (lead >= 0) atomicAdd(&s_fill[lead], 1);
+    }
+    __syncthreads();
+    if (wave == 0) {   // exclusive scan of the per-token counts
+        int run = 0;
+        for (int r0 = 0; r0 < kGWin; r0 += 64) {
+            const int r = r0 + lane;
+            const int c = s_fill[r];
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o);
+                if (lane >= o) inc += v;
+            }
+            s_start[r] = (short)(run + inc - c);
+            s_cnt[r] = (short)c;
+            s_fill[r] = 0;
+            run += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < kGWin; r += 256) {
+        const int lead = s_leader[r];
+        if (lead >= 0) s_sorted[s_start[lead] + atomicAdd(&s_fill[lead], 1)] = (short)r;
+    }
+    __syncthreads();
+    const float dp = is_global ? dpre_g[b] : 0.f;
+    for (int key = wave; key < kGWin; key += 4) {
+        const int cnt = s_cnt[key];
+        if (cnt == 0) continue;                      // wave-uniform
+        const int base = s_start[key];
+        float* drow = dtable + (long)s_tok[key] * E;
+        if (is_global) {
+            for (int e = lane; e < E; e += 64) {
+                float s = 0.f;
+                for (int q = 0; q < cnt; ++q) s += wT[(long)(p0 + s_sorted[base + q]) * E + e];
+                atomicAdd(drow + e, dp * s);
+            }
+        } else {
+            for (int j0 = 0; j0 < win; j0 += kMaxKF) {
+                float c[kMaxKF];
+#pragma unroll
+                for (int j = 0; j < kMaxKF; ++j) {
+                    c[j] = 0.f;
+                    if (j0 + j < win)
+                        for (int q = 0; q < cnt; ++q) c[j] += s_dpre[s_sorted[base + q] - (j0 + j) + 2 * pad];
+                }
+                for (int e = lane; e < E; e += 64) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < kMaxKF; ++j)
+                        if (j0 + j < win) s = fmaf(c[j], w[(long)e * win + j0 + j], s);
+                    atomicAdd(drow + e, s);
+                }
+            }
+        }
+    }
+}
+
+// wT[l, e] = w[e, l]   (global gate: coalesced reads of the per-position weight columns)
+__global__ __launch_bounds__(256) void transpose_w_kernel(int E, int L, const float* __restrict__ w, float* __restrict__ wT) {
+    const long n = (long)E * L;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        const int l = (int)(k / E), e = (int)(k % E);
+        wT[k] = w[(long)e * L + l];
     }
 }
 
@@ -174,20 +281,6 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, i
     }
 }
 
-// dtable[id(b,l), e] += dpre[b] * w[e, l]      (one wave per token)
-__global__ __launch_bounds__(256) void global_gate_bwd_dx_kernel(int B, int L, int E, const long long* __restrict__ ids,
-                                                                 const float* __restrict__ w, const float* __restrict__ dpre,
-                                                                 int pad_idx, float* __restrict__ dtable) {
-    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (tok >= (long)B * L) return;
-    const int b = (int)(tok / L), l = (int)(tok % L);
-    const long id = ids[tok];
-    if (id == pad_idx) return;
-    const float dp = dpre[b];
-    for (int e = lane; e < E; e += 64) atomicAdd(dtable + id * E + e, dp * w[(long)e * L + l]);
-}
-
 }  // namespace rbr
 
 using namespace rbr;
@@ -220,8 +313,7 @@ extern "C" int rbr_datt_global_gate_fwd(int32_t B, int32_t L, int32_t E, const i
 }
 
 extern "C" size_t rbr_datt_gate_bwd_ws_floats(int32_t B, int32_t L, int32_t E, int32_t win, int32_t is_global) {
-    (void)L;
-    return is_global ? (size_t)B : (size_t)B * ((size_t)win * E + 1);
+    return is_global ? (size_t)B + (size_t)E * L : (size_t)B * ((size_t)win * E + 1);
 }
 
 extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
@@ -230,6 +322,7 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
     if (!gate_args_ok(B, L, E, win)) return RBR_ERR_BAD_ARG;
     if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if ((size_t)L * sizeof(float) > 60 * 1024) { set_error("doc_len %d too large for the LDS strip", L); return RBR_ERR_UNSUPPORTED; }
+    if (win > 2 * kMaxKF + 1) { set_error("local attention window %d exceeds the supported %d", win, 2 * kMaxKF + 1); return RBR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     hipLaunchKernelGGL(local_gate_bwd_dw_kernel, dim3(B), dim3(256), (size_t)L * sizeof(float), st, B, L, E, win, ids64, table,
@@ -239,9 +332,9 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
                        ws, dw, db0);
     RBR_CHECK_LAUNCH("datt local gate bwd reduce launch");
     if (dtable != nullptr) {
-        const long ntok = (long)B * L;
-        hipLaunchKernelGGL(local_gate_bwd_dx_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, B, L, E, win, ids64,
-                           w, gate, dgate, pad_idx, dtable);
+        const int nwin = (L + kGWin - 1) / kGWin;
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
+                           (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable);
         RBR_CHECK_LAUNCH("datt local gate bwd dx launch");
     }
     return 0;
@@ -259,9 +352,13 @@ extern "C" int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const i
     hipLaunchKernelGGL(global_gate_bwd_dw_kernel, dim3(L + 1), dim3(256), 0, st, B, L, E, ids64, table, ws, dw, db0);
     RBR_CHECK_LAUNCH("datt global gate bwd dw launch");
     if (dtable != nullptr) {
-        const long ntok = (long)B * L;
-        hipLaunchKernelGGL(global_gate_bwd_dx_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, st, B, L, E, ids64, w,
-                           ws, pad_idx, dtable);
+        float* wT = ws + B;
+        hipLaunchKernelGGL(transpose_w_kernel, dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0,
+                           st, E, L, w, wT);
+        RBR_CHECK_LAUNCH("datt global gate transpose launch");
+        const int nwin = (L + kGWin - 1) / kGWin;
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, 1, 1, nwin, ids64, w,
+                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable);
         RBR_CHECK_LAUNCH("datt global gate bwd dx launch");
     }
     return 0;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -60,7 +61,18 @@ int check_hip(hipError_t e, const char* what);
 // Builds the launch plans for `d`.  Returns the number of groups (0 on error, see rbr_last_error()).
 int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */);
 
-inline int choose_dc(int D) { return (D % 60 == 0) ? 60 : 20; }
+// Embedding-dim chunk per weight piece: 60, 52 or 20 floats (all 4*odd: conflict-free b128 reads).  The largest
+// chunk whose zero padding of D stays within 8 % of the best candidate wins (10-MFMA pieces of the 20-float chunk
+// spend a third of their time in barriers).  D % 4 != 0 uses the scalar-gather instantiation (20 only).
+inline int choose_dc(int D) {
+    if (D % 4 != 0) return 20;
+    const int cands[3] = {60, 52, 20};
+    int best_pad = 1 << 30;
+    for (int c : cands) best_pad = std::min(best_pad, ((D + c - 1) / c) * c);
+    for (int c : cands)
+        if (((D + c - 1) / c) * c * 100 <= best_pad * 108) return c;
+    return 20;
+}
 
 }  // namespace rbr
 

@@ -48,8 +48,12 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
     int ch_off[RBR_MAX_WIDTHS];
     for (int w = 0; w < d->n_widths; ++w) { ch_off[w] = C; C += d->ch[w]; KF = std::max(KF, d->kz[w]); }
     const int tiles_total = (C + kTile - 1) / kTile;
-    const int ngroups = (tiles_total + kMaxTiles - 1) / kMaxTiles;
-    if (ngroups > kMaxGroups) { set_error("%d output channels exceed the supported %d", C, kMaxGroups * kMaxSlots); return 0; }
+    // <= 7 tiles per launch keeps the kernel at 2 waves/SIMD (8 tiles = 128 accumulator + ~140 other VGPRs spills
+    // past 256); groups are balanced (10 tiles -> 5 + 5, not 8 + 2)
+    constexpr int kPreferredTiles = 7;
+    const int ngroups = (tiles_total + kPreferredTiles - 1) / kPreferredTiles;
+    const int per_group = (tiles_total + ngroups - 1) / ngroups;
+    if (ngroups > kMaxGroups) { set_error("%d output channels exceed the supported %d", C, kMaxGroups * kPreferredTiles * kTile); return 0; }
 
     std::vector<int> order(d->n_widths);
     for (int w = 0; w < d->n_widths; ++w) order[w] = w;
@@ -69,8 +73,8 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
         p.wpd = (d->L + kTile - 1) / kTile;
         p.total_wt = d->n_docs * p.wpd;
         p.nslots_total = tiles_total * kTile;
-        p.tile_base = g * kMaxTiles;
-        p.ntiles = std::min(kMaxTiles, tiles_total - p.tile_base);
+        p.tile_base = g * per_group;
+        p.ntiles = std::min(per_group, tiles_total - p.tile_base);
         p.pad_mode = d->pad_mode; p.act = d->act;
         p.n_widths = d->n_widths;
         for (int w = 0; w < d->n_widths; ++w) { p.kz[w] = d->kz[w]; p.ch[w] = d->ch[w]; p.ch_off[w] = ch_off[w]; }

@@ -374,10 +374,11 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
         int e;
         const ConvPlan& p = plans[g];
         const long long* ids64 = reinterpret_cast<const long long*>(ids);
+        if (p.DC != 20 && !vec) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
         if (p.DC == 60) {
-            e = vec ? launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream)
-                    : RBR_ERR_UNSUPPORTED;   // D % 60 == 0 implies D % 4 == 0; only a misaligned table gets here
-            if (e == RBR_ERR_UNSUPPORTED && !vec) { set_error("word table must be 16-byte aligned"); }
+            e = launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
+        } else if (p.DC == 52) {
+            e = launch_conv<52, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
         } else {
             e = vec ? launch_conv<20, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream)
                     : launch_conv<20, false>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
