@@ -15,7 +15,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// one wave per pair; lanes stride over the latent dimension K
+// one wave per pair: lanes 0-31 run the user tower, lanes 32-63 the item tower (k = lane & 31, looped for K > 32);
+// the H-long dots are unrolled 4x so four independent L2 loads per tower are in flight
 __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
                                                        const float* __restrict__ itf, const long long* __restrict__ uid,
                                                        const long long* __restrict__ iid, const rbr_head_params p,
@@ -24,23 +25,39 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= B) return;
-    const long u = uid[b], it = iid[b];
+    const int side = lane >> 5, kk = lane & 31;
+    const long id = side ? iid[b] : uid[b];
+    const float* ft = (side ? itf : uf) + (long)b * H;
+    const float* W = side ? p.Wi : p.Wu;
+    const float* bias = side ? p.bi : p.bu;
+    const float* E = side ? p.Ei : p.Eu;
+    float* outl = (side ? il : ul) + (long)b * K;
     float part = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        float su = p.bu[k] + p.Eu[u * K + k];
-        float si = p.bi[k] + p.Ei[it * K + k];
-        for (int hh = 0; hh < H; ++hh) {
-            su = fmaf(uf[(long)b * H + hh], p.Wu[(long)hh * K + k], su);
-            si = fmaf(itf[(long)b * H + hh], p.Wi[(long)hh * K + k], si);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k = k0 + kk;
+        float s = 0.f;
+        if (k < K) {
+            float s0 = bias[k] + E[id * K + k], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int hh = 0;
+            for (; hh + 4 <= H; hh += 4) {
+                s0 = fmaf(ft[hh], W[(long)hh * K + k], s0);
+                s1 = fmaf(ft[hh + 1], W[(long)(hh + 1) * K + k], s1);
+                s2 = fmaf(ft[hh + 2], W[(long)(hh + 2) * K + k], s2);
+                s3 = fmaf(ft[hh + 3], W[(long)(hh + 3) * K + k], s3);
+            }
+            for (; hh < H; ++hh) s0 = fmaf(ft[hh], W[(long)hh * K + k], s0);
+            s = (s0 + s1) + (s2 + s3);
+            outl[k] = s;
         }
-        ul[(long)b * K + k] = su;
-        il[(long)b * K + k] = si;
-        float z = fmaxf(su * si, 0.f);
-        if (drop != nullptr) z *= drop[(long)b * K + k];
-        part = fmaf(z, p.h[k], part);
+        const float other = __shfl_xor(s, 32);      // user lanes get the item value and vice versa
+        if (side == 0 && k < K) {
+            float z = fmaxf(s * other, 0.f);
+            if (drop != nullptr) z *= drop[(long)b * K + k];
+            part = fmaf(z, p.h[k], part);
+        }
     }
     part = wave_sum(part);
-    if (lane == 0) pred[b] = part + p.ub[u] + p.ib[it] + p.g[0];
+    if (lane == 0) pred[b] = part + p.ub[uid[b]] + p.ib[iid[b]] + p.g[0];
 }
 
 // per-pair part of the backward: d_ul, d_il (to workspace), embedding-row grads, d_feat

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const int i = lane & 31, h = lane >> 5;
     const int L = P.L, D = P.D;
     float* Xw = Xs + wave * XR * DC;
+    long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * (kTile + kMaxKF);   // [XR] per wave
     const float* wbase = packed + (long)P.tile_base * TILE_F;
     const int nitems = (P.total_wt + kWavesPerWG - 1) / kWavesPerWG;
 
@@ -158,39 +159,44 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     issue(piece_src(0, 0));
     commit(Ws);
     int cur = 0;
+    if (active) {   // table row offset of every slab row (-1: outside the document or masked), once per item
+        for (int row = lane; row < XR; row += 64) {
+            const int p = l0 - P.P + row;
+            long ro = -1;
+            if (p >= 0 && p < L) {
+                const long tok = (long)doc * L + p;
+                if (mask == nullptr || mask[tok]) ro = ids[tok] * (long)D;
+            }
+            s_row[row] = ro;
+        }
+    }
 
     for (int dc = 0; dc < P.nchunks; ++dc) {
         // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) -------------------------
+        // (row offsets were resolved once per item into s_row: one L2 round trip per chunk instead of three)
         if (active) {
             if (VEC) {
                 constexpr int QPR = DC / 4;
                 for (int idx = lane; idx < XR * QPR; idx += 64) {
                     const int row = idx / QPR, q = idx - row * QPR;
-                    const int p = l0 - P.P + row;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     const int d = dc * DC + 4 * q;
-                    if (p >= 0 && p < L && d < D) {
-                        const long tok = (long)doc * L + p;
-                        if (mask == nullptr || mask[tok]) {
-                            const long id = ids[tok];
-                            v = *reinterpret_cast<const f32x4*>(table + id * D + d);
-                            if (gate != nullptr) v *= gate[tok];
-                        }
+                    const long ro = s_row[row];
+                    if (ro >= 0 && d < D) {
+                        v = *reinterpret_cast<const f32x4*>(table + ro + d);
+                        if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
                     }
                     *reinterpret_cast<f32x4*>(Xw + row * DC + 4 * q) = v;
                 }
             } else {
                 for (int idx = lane; idx < XR * DC; idx += 64) {
                     const int row = idx / DC, dd = idx - row * DC;
-                    const int p = l0 - P.P + row;
                     float v = 0.f;
                     const int d = dc * DC + dd;
-                    if (p >= 0 && p < L && d < D) {
-                        const long tok = (long)doc * L + p;
-                        if (mask == nullptr || mask[tok]) {
-                            v = table[ids[tok] * D + d];
-                            if (gate != nullptr) v *= gate[tok];
-                        }
+                    const long ro = s_row[row];
+                    if (ro >= 0 && d < D) {
+                        v = table[ro + d];
+                        if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
                     }
                     Xw[row * DC + dd] = v;
                 }
@@ -298,7 +304,8 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
                           const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
     const int XR = kTile + p.KF - 1;
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
-    const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) + extra_lds;
+    const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) +
+                        (size_t)kWavesPerWG * (kTile + kMaxKF) * sizeof(long) + extra_lds;
     static int occ = 0;   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
     if (occ == 0) {
         int nb = 0;

@@ -19,9 +19,15 @@ LR = 2e-3            # default_deepconn_pp.json:24
 MAX_GRAD_NORM = 5.0  # default_deepconn_pp.json:27
 
 
-def make_optimizer(model: nn.Module, lr: float = LR) -> torch.optim.Optimizer:
-    """torch.optim.Adam(model.parameters(), lr=args.lr)  (train_deepconn_pp.py:135)."""
-    return torch.optim.Adam(model.parameters(), lr=lr)
+def make_optimizer(model: nn.Module, lr: float = LR, fused: bool | None = None) -> torch.optim.Optimizer:
+    """torch.optim.Adam(model.parameters(), lr=args.lr)  (train_deepconn_pp.py:135).
+
+    `fused=None` picks torch's single-kernel ("fused") Adam implementation when every parameter lives on
+    a HIP device and the default multi-kernel one otherwise; both compute the same update."""
+    params = list(model.parameters())
+    if fused is None:
+        fused = len(params) > 0 and all(p.is_cuda for p in params)
+    return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
 
 
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, ratings: torch.Tensor,
