@@ -1,0 +1,264 @@
+"""Trainer-equivalent entry point: the behaviour of the reference's
+trainer/train_{deepconn_pp,narre,dual_att}.py on top of the HIP modules.
+
+    python -m review_based_recommender_amd.trainer --model deepconn --config cfg.json
+    python -m torch.distributed.run --nproc-per-node 8 -m review_based_recommender_amd.trainer --model deepconn --config cfg.json
+
+Kept from the reference: the flat JSON config keys (models/*/default_*.json), output directory
+`./{log_dir}/{dataset}/{model_name}/{uid}` with `log.txt` (experiment.py:64-83), the args / parameter
+tables (experiment.py:101-123), the step (train_deepconn_pp.py:161-168), the log line
+`epoch: e/E, step: s/S, loss: ..., rmse: ..., lr: ..., gnorm: ..., time: ...` every `log_idx` steps
+(:176-184), validation RMSE with best-model checkpoint `{"model","optimizer","updates","args"}`
+(experiment.py:127-139, train_deepconn_pp.py:214-217) and patience early stop by raising `EarlyStop`
+(:226-232).  Deliberate differences: `kernel_sizes` / `hidden_dim` come from the config unless
+`--reference-quirks` restores the trainers' hard-coded `[3]` / 150 (train_deepconn_pp.py:125,
+train_narre.py:124-125); `parallel: true` means one process per GPU with an RCCL gradient all-reduce
+(launch with torch.distributed.run) instead of nn.DataParallel; running loss / gnorm are accumulated on
+the device and read back only at log lines (the reference calls loss.item() twice per step).
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import json
+import math
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from . import data as D
+from .train_step import make_optimizer, train_step
+
+
+class Args:
+    """experiment.py:30-37 -- flat JSON -> attribute bag."""
+
+    def __init__(self, cfg: dict):
+        self.__dict__.update(cfg)
+
+
+def parse_args(config_file: str) -> Args:
+    with open(config_file) as f:
+        return Args(json.load(f))
+
+
+class EarlyStop(Exception):
+    pass
+
+
+DEFAULTS = dict(log_dir="logs", dataset="dataset", log=True, log_idx=500, verbose=False, parallel=False, epochs=64,
+                batch_size=50, lr=0.002, max_grad_norm=5.0, patience=5, dropout=0.5, arch="CNN", use_pretrain=False,
+                num_workers=0, device_cache=True)
+
+
+class ReviewExperiment:
+    KINDS = ("deepconn", "narre", "dual_att")
+
+    def __init__(self, kind: str, args: Args, reference_quirks: bool = False, uid: str | None = None):
+        if kind not in self.KINDS:
+            raise ValueError(f"{kind} is not one of {self.KINDS}")
+        for k, v in DEFAULTS.items():
+            if not hasattr(args, k):
+                setattr(args, k, v)
+        if getattr(args, "use_pretrain", False):
+            raise RuntimeError("use_pretrain needs gensim + a word2vec file (train_deepconn_pp.py:105-119): pass "
+                               "pretrained rows through the model's `pretrained_embeddings` argument instead")
+        self.kind, self.args, self.quirks = kind, args, reference_quirks
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise RuntimeError("the HIP path needs an MI355X: there is no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        self.uid = uid or datetime.datetime.now().strftime("%y%m%d_%H%M%S")
+        self.updates = 0
+        self.best_rmse = 1e3
+        self.patience = 0
+        self.grad_sync = None
+
+        cls = D.ReviewDataset if kind == "narre" else D.DocDataset
+        kw = {} if kind == "narre" else {"with_ids": kind == "deepconn"}
+        self.train_set = cls(args.data_dir, "train", **kw)
+        self.valid_set = cls(args.data_dir, "valid", **kw)
+        self._make_dir()
+        self.build_model()
+        self.optimizer = make_optimizer(self.model, lr=args.lr)
+        self.loss_func = nn.MSELoss()
+        if self.world > 1 and args.parallel:
+            from .distributed import GradAllReduce, broadcast_parameters, init_process_group_from_env
+            init_process_group_from_env("nccl")
+            broadcast_parameters(self.model)
+            self.grad_sync = GradAllReduce(self.model)
+        self.print_args()
+        self.print_model_stats()
+
+    # ------------------------------------------------------------------ bookkeeping (experiment.py:64-123)
+    def _make_dir(self):
+        a = self.args
+        self.out_dir = "./{}/{}/{}/{}".format(a.log_dir, a.dataset, a.model_name, self.uid)
+        os.makedirs(self.out_dir, exist_ok=True)
+        self.log_path = os.path.join(self.out_dir, "log.txt")
+
+    def print_write_to_log(self, text: str):
+        if self.rank != 0:
+            return
+        if self.args.log:
+            try:
+                with open(self.log_path, "a") as f:
+                    f.write(text + "\n")
+            except IOError:
+                print("Cannot write a line into {}".format(self.log_path))
+        print(text, flush=True)
+
+    def print_args(self):
+        for name, val in self.args.__dict__.items():
+            self.print_write_to_log("{}: {}".format(name, val))
+        self.print_write_to_log("=" * 50)
+
+    def print_model_stats(self):
+        self.print_write_to_log("List of all Trainable Variables")
+        for i, (name, p) in enumerate(self.model.named_parameters()):
+            if p.requires_grad:
+                self.print_write_to_log("param {:3}: {:15} {}".format(i, str(tuple(p.shape)), name))
+        n = sum(p.numel() for p in self.model.parameters())
+        self.print_write_to_log("The total number of trainable parameters: {:,d}".format(n))
+        self.print_write_to_log("=" * 50)
+
+    def save(self, name: str):
+        if self.rank != 0:
+            return
+        if not name.endswith(".pt"):
+            name += ".pt"
+        torch.save({"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "updates": self.updates,
+                    "args": dict(self.args.__dict__)}, os.path.join(self.out_dir, name))
+
+    # ------------------------------------------------------------------ model (train_*.py build_model)
+    def build_model(self):
+        a, ds = self.args, self.train_set
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            if self.kind == "deepconn":
+                from .models.deepconn.deepconn import DeepCoNNpp
+                ks = [3] if self.quirks else a.kernel_sizes
+                self.model = DeepCoNNpp(user_size=ds.user_num, item_size=ds.item_num, vocab_size=ds.vocab_size, kernel_sizes=ks,
+                                        hidden_dim=a.hidden_dim, embedding_dim=a.embedding_dim, dropout=a.dropout,
+                                        latent_dim=a.latent_dim, doc_len=ds.doc_len, pretrained_embeddings=None, arch=a.arch)
+            elif self.kind == "narre":
+                from .models.narre.narre import NARRE
+                ks = [3] if self.quirks else a.kernel_sizes
+                hd = 150 if self.quirks else a.hidden_dim
+                self.model = NARRE(user_size=ds.user_num, item_size=ds.item_num, vocab_size=ds.vocab_size, kernel_sizes=ks,
+                                   hidden_dim=hd, embedding_dim=a.embedding_dim, att_dim=a.att_dim, latent_dim=a.latent_dim,
+                                   max_doc_num=ds.rv_num, max_doc_len=ds.rv_len, dropout=a.dropout, word_padding_idx=0,
+                                   user_padding_idx=0, item_padding_idx=0, pretrained_embeddings=None, arch=a.arch)
+            else:
+                from .models.dual_att.dual_att import DualAtt
+                self.model = DualAtt(vocab_size=ds.vocab_size, doc_len=ds.doc_len, l_window_size=a.l_window_size,
+                                     l_out_size=a.l_out_size, g_out_size=a.g_out_size, emb_size=a.emb_size,
+                                     hidden_size_1=a.hidden_size_1, hidden_size_2=a.hidden_size_2, dropout=a.dropout,
+                                     pretrained_embeddings=None)
+        self.model.to(self.device)
+
+    # ------------------------------------------------------------------ data
+    def _loader(self, ds, shuffle):
+        sampler = None
+        if self.world > 1 and self.args.parallel:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
+                                                                      shuffle=shuffle, drop_last=shuffle)
+        return torch.utils.data.DataLoader(ds, batch_size=self.args.batch_size, shuffle=shuffle and sampler is None,
+                                           sampler=sampler, collate_fn=ds.collate_fn, num_workers=self.args.num_workers,
+                                           drop_last=bool(sampler is not None and shuffle))
+
+    def _to_device(self, batch):
+        batch = [t.to(self.device, non_blocking=True) for t in batch]
+        return tuple(batch[:-1]), batch[-1]
+
+    # ------------------------------------------------------------------ loops (train_deepconn_pp.py:143-232)
+    def train_one_epoch(self, epoch: int):
+        a = self.args
+        loader = self._loader(self.train_set, shuffle=True)
+        loss_sum = torch.zeros((), device=self.device)
+        sq_err = torch.zeros((), device=self.device)
+        gnorm = torch.zeros((), device=self.device)
+        steps = count = 0
+        start = time.time()
+        self.model.train()
+        for i, batch in enumerate(loader):
+            inputs, ratings = self._to_device(batch)
+            loss, gnorm, _ = train_step(self.model, self.optimizer, inputs, ratings, a.max_grad_norm, self.grad_sync)
+            self.updates += 1
+            loss_sum += loss
+            sq_err += loss * ratings.size(0)
+            steps += 1
+            count += ratings.size(0)
+            if (i + 1) % a.log_idx == 0 and a.log:
+                elapsed = (time.time() - start) / a.log_idx
+                rmse = math.sqrt(float(sq_err) / count)
+                self.print_write_to_log(
+                    "epoch: {}/{}, step: {}/{}, loss: {:.3f}, rmse: {:.3f}, lr: {}, gnorm: {:3f}, time: {:.3f}".format(
+                        epoch, a.epochs, i + 1, len(loader), float(loss_sum) / steps, rmse,
+                        self.optimizer.param_groups[0]["lr"], float(gnorm), elapsed))
+                loss_sum.zero_()
+                sq_err.zero_()
+                steps = count = 0
+                start = time.time()
+
+    def valid_one_epoch(self):
+        loader = self._loader(self.valid_set, shuffle=False)
+        sq_err = torch.zeros((), device=self.device, dtype=torch.float64)
+        loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
+        count = torch.zeros((), device=self.device, dtype=torch.float64)
+        steps = 0
+        self.model.eval()
+        with torch.no_grad():
+            for batch in loader:
+                inputs, ratings = self._to_device(batch)
+                out = self.model(*inputs)
+                pred = out[0] if isinstance(out, tuple) else out
+                loss = self.loss_func(pred, ratings)
+                sq_err += loss.double() * ratings.size(0)
+                loss_sum += loss.double()
+                count += ratings.size(0)
+                steps += 1
+        if self.world > 1 and self.args.parallel:
+            import torch.distributed as dist
+            for t in (sq_err, count):
+                dist.all_reduce(t)
+        rmse = math.sqrt(float(sq_err) / max(float(count), 1.0))
+        if rmse < self.best_rmse:
+            self.best_rmse = rmse
+            self.save("best_model.pt")
+            self.patience = 0
+        else:
+            self.patience += 1
+        self.print_write_to_log("valid loss: {:.3f}, valid rmse: {:.3f}, best rmse: {:.3f}".format(
+            float(loss_sum) / max(steps, 1), rmse, self.best_rmse))
+        if self.patience >= self.args.patience:
+            raise EarlyStop("early stop")
+
+    def train(self):
+        self.print_write_to_log("start training ...")
+        for epoch in range(self.args.epochs):
+            self.train_one_epoch(epoch)
+            self.valid_one_epoch()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--model", required=True, choices=ReviewExperiment.KINDS)
+    ap.add_argument("--config", required=True, help="flat JSON config with the reference's keys")
+    ap.add_argument("--reference-quirks", action="store_true", help="hard-code kernel_sizes=[3] (and NARRE hidden_dim=150)")
+    a = ap.parse_args(argv)
+    exp = ReviewExperiment(a.model, parse_args(a.config), reference_quirks=a.reference_quirks)
+    try:
+        exp.train()
+    except EarlyStop:
+        exp.print_write_to_log("early stop (patience {})".format(exp.args.patience))
+
+
+if __name__ == "__main__":
+    main()
