@@ -64,7 +64,9 @@ const char* rbr_last_error(void);
  *      convs of dual_att/layers.py:37-40,68-79.                                            ---- */
 
 /* number of floats of the packed-weight buffer / number of elements of EACH of the two partial-max
- * workspaces (pval: float, pidx: int32) for `d` */
+ * workspaces (pval: float, pidx: int32) for `d`.  The count includes a scheduling region at the end of pidx
+ * (flags | work list | counter) that rbr_textcnn_conv_fwd fills and rbr_textcnn_pool_finalize reads: wave-tiles
+ * whose tokens are all masked are not computed, their pooled value is exactly 0 */
 size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d);
 size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d);
 

@@ -58,6 +58,34 @@ __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrAr
     }
 }
 
+// ------------------------------------------------------------------------------------ tile scan
+// Mask-aware work list.  A wave-tile (32 positions + halo) whose tokens are ALL masked gathers only zero rows:
+// every accumulator stays exactly 0.0f, so its pooled value is known (0 at the tile's first position) without
+// issuing a single MFMA.  Right-padded review documents make ~1/3 of the tiles of the cfg2 batch such tiles.
+// sched layout (int32, tail of the pidx workspace): flags[total_wt] | list[total_wt] | counter[16].
+__global__ __launch_bounds__(256) void tile_scan_kernel(const ConvPlan P, const unsigned char* __restrict__ mask,
+                                                        int* __restrict__ sched) {
+    const int wt = blockIdx.x * 256 + threadIdx.x;
+    int act = 0;
+    if (wt < P.total_wt) {
+        act = 1;
+        if (mask != nullptr) {
+            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
+            const int lo = max(0, l0 - P.P), hi = min(P.L, l0 + kTile + P.KF - 1 - P.P);
+            act = 0;
+            for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
+            act = act ? 1 : 0;
+        }
+        sched[wt] = act;
+    }
+    const unsigned long long b = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(sched + 2 * (long)P.total_wt, __popcll(b));
+    base = __shfl(base, 0);
+    if (act) sched[(long)P.total_wt + base + __popcll(b & ((1ull << lane) - 1))] = wt;
+}
+
 // ------------------------------------------------------------------------------------ conv
 template <int DC>
 struct Frag {   // one operand of a piece: DC/8 ds_read_b128 plus a b64 tail when DC % 8 == 4
@@ -94,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                                                        const unsigned char* __restrict__ mask,
                                                        const float* __restrict__ gate, const float* __restrict__ table,
                                                        const float* __restrict__ packed, float* __restrict__ pval,
-                                                       int* __restrict__ pidx) {
+                                                       int* __restrict__ pidx, const int* __restrict__ sched) {
     static_assert(DC % 4 == 0 && (DC / 4) % 2 == 1, "row stride must be 4*odd floats (bank-conflict-free b128 reads)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE_F = kTile * DC;             // floats of one channel tile of a piece
@@ -112,7 +140,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     float* Xw = Xs + wave * XR * DC;
     long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * (kTile + kMaxKF);   // [XR] per wave
     const float* wbase = packed + (long)P.tile_base * TILE_F;
-    const int nitems = (P.total_wt + kWavesPerWG - 1) / kWavesPerWG;
+    const int n_active = sched[2 * (long)P.total_wt];            // wave-tiles with at least one unmasked token
+    const int* worklist = sched + P.total_wt;
+    const int nitems = (n_active + kWavesPerWG - 1) / kWavesPerWG;
 
   // Persistent workgroups walk the items (4 consecutive wave-tiles each) with a fixed stride.  All items
   // cost the same; with 3 resident workgroups per CU and e.g. 8 items per CU the blocks b, b+G/3, b+2G/3
@@ -121,10 +151,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
   // and the earliest CUs grab 3 more items each).
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     __syncthreads();   // every wave is done with the LDS ring of the previous item
-    const int wt = item * kWavesPerWG + wave;         // global wave-tile
-    const bool active = wt < P.total_wt;              // wave-uniform
-    const int doc = active ? wt / P.wpd : 0;
-    const int l0 = active ? (wt % P.wpd) * kTile : 0;
+    const int slot_in_list = item * kWavesPerWG + wave;
+    const bool active = slot_in_list < n_active;      // wave-uniform
+    const int wt = active ? worklist[slot_in_list] : 0;   // global wave-tile
+    const int doc = wt / P.wpd;
+    const int l0 = (wt % P.wpd) * kTile;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -268,6 +299,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 __global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, const float* __restrict__ pval,
                                                             const int* __restrict__ pidx, const PtrArray bias,
                                                             float* __restrict__ feat, int* __restrict__ argmax) {
+    const int* flags = pidx + (long)P.total_wt * P.nslots_total;   // sched region written by tile_scan_kernel
     const int nslots = P.ntiles * kTile;
     const long total = (long)P.n_docs * nslots;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -277,9 +309,15 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, co
         const long base = (long)doc * P.wpd * P.nslots_total + (long)P.tile_base * kTile + ls;
         float best = -__builtin_huge_valf();
         int bidx = 0;
+        const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
         for (int w = 0; w < P.wpd; ++w) {
-            const float v = pval[base + (long)w * P.nslots_total];
-            if (v > best) { best = v; bidx = pidx[base + (long)w * P.nslots_total]; }
+            if (flags[doc * P.wpd + w]) {
+                const float v = pval[base + (long)w * P.nslots_total];
+                if (v > best) { best = v; bidx = pidx[base + (long)w * P.nslots_total]; }
+            } else if (w * kTile < Lv && 0.f > best) {      // all-masked tile: conv sum is exactly 0 everywhere
+                best = 0.f;
+                bidx = w * kTile;
+            }
         }
         const int bw = P.slot_w[ls];
         const float y = best + bias.p[bw][chan - P.ch_off[bw]];
@@ -301,7 +339,7 @@ static int num_cus() {
 
 template <int NT, int DC, bool VEC>
 static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
-                          const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
+                          const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st) {
     const int XR = kTile + p.KF - 1;
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
     const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) +
@@ -316,16 +354,16 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
     const int nitems = (p.total_wt + kWavesPerWG - 1) / kWavesPerWG;
     const dim3 grid(std::min(nitems, num_cus() * occ)), block(256);
     hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,
-                       pidx);
+                       pidx, sched);
     RBR_CHECK_LAUNCH("textcnn conv_fwd launch");
     return 0;
 }
 
 template <int DC, bool VEC>
 static int launch_conv(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
-                       const float* table, const float* packed, float* pval, int* pidx, hipStream_t st) {
+                       const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st) {
 #define RBR_LAUNCH(NT) \
-    case NT: return launch_conv_nt<NT, DC, VEC>(p, ids, mask, gate, table, packed, pval, pidx, st);
+    case NT: return launch_conv_nt<NT, DC, VEC>(p, ids, mask, gate, table, packed, pval, pidx, sched, st);
     switch (p.ntiles) {
         RBR_LAUNCH(1) RBR_LAUNCH(2) RBR_LAUNCH(3) RBR_LAUNCH(4) RBR_LAUNCH(5) RBR_LAUNCH(6) RBR_LAUNCH(7) RBR_LAUNCH(8)
         default: set_error("ntiles=%d", p.ntiles); return RBR_ERR_UNSUPPORTED;
@@ -350,7 +388,8 @@ extern "C" size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d) {
 extern "C" size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return 0;
-    return (size_t)plans[0].total_wt * plans[0].nslots_total;
+    // partial (max, argmax) pairs + the scheduling region flags[total_wt] | list[total_wt] | counter[16]
+    return (size_t)plans[0].total_wt * plans[0].nslots_total + 2 * (size_t)plans[0].total_wt + 16;
 }
 
 extern "C" int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* packed, void* stream) {
@@ -377,18 +416,24 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
     if (!ng) return RBR_ERR_BAD_ARG;
     if (!ids || !table || !packed || !pval || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     const bool vec = (d->D % 4 == 0) && (((uintptr_t)table & 15) == 0);
+    int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
+    if (int e = check_hip(hipMemsetAsync(sched + 2 * (size_t)plans[0].total_wt, 0, 16 * sizeof(int), (hipStream_t)stream),
+                          "work-list counter memset")) return e;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((plans[0].total_wt + 255) / 256), dim3(256), 0, (hipStream_t)stream, plans[0],
+                       mask, sched);
+    RBR_CHECK_LAUNCH("textcnn tile_scan launch");
     for (int g = 0; g < ng; ++g) {
         int e;
         const ConvPlan& p = plans[g];
         const long long* ids64 = reinterpret_cast<const long long*>(ids);
         if (p.DC != 20 && !vec) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
         if (p.DC == 60) {
-            e = launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
+            e = launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
         } else if (p.DC == 52) {
-            e = launch_conv<52, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
+            e = launch_conv<52, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
         } else {
-            e = vec ? launch_conv<20, true>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream)
-                    : launch_conv<20, false>(p, ids64, mask, gate, table, packed, pval, pidx, (hipStream_t)stream);
+            e = vec ? launch_conv<20, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream)
+                    : launch_conv<20, false>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
         }
         if (e) return e;
     }
