@@ -34,6 +34,7 @@ struct ConvPlan {
     int total_wt;       // n_docs * wpd
     int nslots_total;   // 32 * (tiles over all groups): row pitch of the partial-max workspace
     int tile_base;      // first tile of this group in the packed image / workspace
+    int group;          // launch index of this plan (selects its work counter)
     int ntiles;         // tiles in this group
     int npieces;        // (tap, tile) pairs streamed per embedding chunk
     int pad_mode, act;

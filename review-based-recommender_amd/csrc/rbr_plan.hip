@@ -74,6 +74,7 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
         p.total_wt = d->n_docs * p.wpd;
         p.nslots_total = tiles_total * kTile;
         p.tile_base = g * per_group;
+        p.group = g;
         p.ntiles = std::min(per_group, tiles_total - p.tile_base);
         p.pad_mode = d->pad_mode; p.act = d->act;
         p.n_widths = d->n_widths;

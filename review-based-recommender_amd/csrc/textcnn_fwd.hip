@@ -139,18 +139,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const int L = P.L, D = P.D;
     float* Xw = Xs + wave * XR * DC;
     long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * (kTile + kMaxKF);   // [XR] per wave
+    int* s_item = reinterpret_cast<int*>(reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + kWavesPerWG * (kTile + kMaxKF));
     const float* wbase = packed + (long)P.tile_base * TILE_F;
     const int n_active = sched[2 * (long)P.total_wt];            // wave-tiles with at least one unmasked token
     const int* worklist = sched + P.total_wt;
     const int nitems = (n_active + kWavesPerWG - 1) / kWavesPerWG;
 
-  // Persistent workgroups walk the items (4 consecutive wave-tiles each) with a fixed stride.  All items
-  // cost the same; with 3 resident workgroups per CU and e.g. 8 items per CU the blocks b, b+G/3, b+2G/3
-  // of one CU run 3+3+2 items, so the last round shares each MFMA pipe between 2 waves instead of idling
-  // a third of the CUs (a global work counter does NOT achieve this: a CU's workgroups finish together
-  // and the earliest CUs grab 3 more items each).
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    __syncthreads();   // every wave is done with the LDS ring of the previous item
+  // Persistent workgroups pull items (4 wave-tiles of the work list) from a device counter.  Items cost the same,
+  // but their number per CU is fractional (e.g. 1357 items on 512 resident workgroups): with dynamic pulling the
+  // last items run on CUs whose other workgroup has already drained, i.e. with the MFMA pipe to themselves.
+  int* item_counter = const_cast<int*>(sched) + 2 * (long)P.total_wt + 1 + P.group;
+  for (;;) {
+    __syncthreads();   // every wave is done with the LDS ring (and with *s_item) of the previous item
+    if (tid == 0) *s_item = atomicAdd(item_counter, 1);
+    __syncthreads();
+    const int item = *s_item;
+    if (item >= nitems) break;
     const int slot_in_list = item * kWavesPerWG + wave;
     const bool active = slot_in_list < n_active;      // wave-uniform
     const int wt = active ? worklist[slot_in_list] : 0;   // global wave-tile
@@ -343,7 +347,7 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
     const int XR = kTile + p.KF - 1;
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
     const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) +
-                        (size_t)kWavesPerWG * (kTile + kMaxKF) * sizeof(long) + extra_lds;
+                        (size_t)kWavesPerWG * (kTile + kMaxKF) * sizeof(long) + 16 + extra_lds;
     static int occ = 0;   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
     if (occ == 0) {
         int nb = 0;
