@@ -166,6 +166,10 @@ def main():
     from review_based_recommender_amd.train_step import make_optimizer, train_step
     _lib.lib()   # fail loudly now if librbr_hip.so is missing
 
+    # rehearsal aids for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
+    if os.environ.get("RBR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("RBR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     cfg = synth.DEEPCONN_CFGS[WORKLOAD]
@@ -174,7 +178,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from review_based_recommender_amd.distributed import GradAllReduce, init_process_group_from_env
-        init_process_group_from_env("nccl")
+        init_process_group_from_env(backend)
 
     model = build_model(cfg, device)          # identical parameters on every rank (same seed)
     model.train()
