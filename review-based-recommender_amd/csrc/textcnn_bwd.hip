@@ -40,7 +40,8 @@ struct BwdArgs {
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
     int rank_off[RBR_MAX_WIDTHS];   // first slot (kz-sorted channel order) of bank w in the packed image
-    int NCH, DPC;                   // document chunks of dw_partial and documents per chunk
+    int NCH, DPC;                   // document chunks of the dW kernels and documents per chunk
+    int doc_centric;                // 1: dw_doc_kernel (short documents), 0: dw_partial_kernel
     int dev_flags;                  // tuning aid (RBR_DEV_DX_ABLATE): 1 = no atomics, 2 = no accumulation phase
 };
 
@@ -133,6 +134,102 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
         }
     }
     if (tid == 0) ws_b[(long)chunk * C + c] = bsum;
+}
+
+// Document-centric dW for SHORT documents (NARRE reviews: L = 50, 150 channels x 3 taps = 450 windows rows drawn
+// from <= 50 distinct token rows per review).  dw_partial reads every (doc, channel, tap) row from L2/Infinity Cache
+// (2.76 GB at cfg3); here a workgroup owns a 32-float slice of the embedding dim, stages each document's rows for
+// that slice ONCE in LDS and accumulates all (channel, tap) items in registers (thread (grp, lane) owns items
+// grp, grp+8, ...).  Writes the same per-chunk slabs as dw_partial, so dw_reduce finishes it.
+constexpr int kDocSlice = 32;       // floats of the embedding dim per workgroup
+constexpr int kDocItems = 512;      // max C * KF handled (64 register accumulators x 8 item groups)
+constexpr int kDocMaxL = 128;
+
+__global__ __launch_bounds__(256) void dw_doc_kernel(const BwdArgs A, const long long* __restrict__ ids,
+                                                     const unsigned char* __restrict__ mask, const float* __restrict__ gate,
+                                                     const float* __restrict__ table, const float* __restrict__ feat,
+                                                     const int* __restrict__ argmax, const float* __restrict__ d_feat,
+                                                     float* __restrict__ ws_w, float* __restrict__ ws_b) {
+    __shared__ float xs[kDocMaxL * kDocSlice];
+    __shared__ float s_g[kDocItems];
+    __shared__ short s_p[kDocItems];
+    __shared__ long s_row[kDocMaxL];
+    __shared__ float s_gate[kDocMaxL];
+    const int slice = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int grp = tid >> 5, lane = tid & 31;
+    const int L = A.L, D = A.D, C = A.C, KF = A.KF;
+    const int nitems = C * KF;
+    const int d = slice * kDocSlice + lane;
+    const int doc_begin = chunk * A.DPC, doc_end = min(A.n_docs, doc_begin + A.DPC);
+    float acc[kDocItems / 8];
+#pragma unroll
+    for (int k = 0; k < kDocItems / 8; ++k) acc[k] = 0.f;
+    float gb[2] = {0.f, 0.f};   // dbias partials of the items this thread resolves (tid, tid + 256)
+    for (int e = tid; e < kDocItems; e += 256) { s_g[e] = 0.f; s_p[e] = 0; }   // slots >= nitems stay (0, row 0)
+
+    for (int doc = doc_begin; doc < doc_end; ++doc) {
+        __syncthreads();
+        // phase A: one round of independent loads -- token rows of the document and the (channel, tap) items
+        if (tid < L) {
+            const long tok = (long)doc * L + tid;
+            const long id = ids[tok];
+            const bool ok = (mask == nullptr) || mask[tok];
+            s_row[tid] = ok ? id * (long)D : -1;
+            s_gate[tid] = (gate != nullptr) ? gate[tok] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q;
+            if (e < nitems) {
+                const int c = e / KF, j = e - c * KF;
+                const int w = bank_of(A, c);
+                const int kz = A.kz[w];
+                float g = 0.f;
+                int p = 0;
+                if (j < kz) {
+                    const long o = (long)doc * C + c;
+                    g = act_grad(A.act, feat[o], d_feat[o]);
+                    if (j == 0) gb[q] += g;
+                    p = argmax[o] + j - ((A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0);
+                    if (p < 0 || p >= L) { g = 0.f; p = 0; }
+                }
+                s_g[e] = g;
+                s_p[e] = (short)p;
+            }
+        }
+        __syncthreads();
+        // phase B: stage the 32-float slice of every row (all loads of a thread are independent)
+#pragma unroll
+        for (int q = 0; q < kDocMaxL * kDocSlice / 256; ++q) {
+            const int r = q * (256 / kDocSlice) + grp;      // idx = q*256 + tid = r*32 + lane
+            if (r < L) {
+                const long ro = s_row[r];
+                xs[r * kDocSlice + lane] = (ro >= 0 && d < D) ? table[ro + d] * s_gate[r] : 0.f;
+            }
+        }
+        __syncthreads();
+        // phase C: register accumulation, no predicates (padding slots carry g = 0)
+#pragma unroll
+        for (int k = 0; k < kDocItems / 8; ++k) {
+            const int e = grp + 8 * k;
+            acc[k] = fmaf(s_g[e], xs[s_p[e] * kDocSlice + lane], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kDocItems / 8; ++k) {
+        const int e = grp + 8 * k;
+        if (e < nitems && d < D) {
+            const int c = e / KF, j = e - c * KF;
+            ws_w[(((long)chunk * C + c) * KF + j) * D + d] = acc[k];
+        }
+    }
+    if (slice == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 256 * q;
+            if (e < nitems && e % KF == 0) ws_b[(long)chunk * C + e / KF] = gb[q];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const float* __restrict__ ws_w,
@@ -414,7 +511,12 @@ static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
             if (d->kz[v] < d->kz[w] || (d->kz[v] == d->kz[w] && v < w)) r += d->ch[v];
         A.rank_off[w] = r;
     }
-    A.NCH = std::min(kMaxChunksBwd, (d->n_docs + kDocsPerBatch - 1) / kDocsPerBatch);
+    A.doc_centric = (d->L <= kDocMaxL && p.C * p.KF <= kDocItems && d->n_docs >= 64) ? 1 : 0;
+    if (A.doc_centric) {
+        A.NCH = std::min(128, (d->n_docs + 15) / 16);       // many small chunks: one workgroup per (slice, chunk)
+    } else {
+        A.NCH = std::min(kMaxChunksBwd, (d->n_docs + kDocsPerBatch - 1) / kDocsPerBatch);
+    }
     A.DPC = (d->n_docs + A.NCH - 1) / A.NCH;
     A.NCH = (d->n_docs + A.DPC - 1) / A.DPC;
     static const int flags = getenv("RBR_DEV_DX_ABLATE") ? atoi(getenv("RBR_DEV_DX_ABLATE")) : 0;
@@ -447,9 +549,15 @@ extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, co
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     float* ws_w = ws;
     float* ws_b = ws + (size_t)A.NCH * A.C * A.KF * A.D;
-    hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
-                       d_feat, ws_w, ws_b);
-    RBR_CHECK_LAUNCH("textcnn dw_partial launch");
+    if (A.doc_centric) {
+        hipLaunchKernelGGL(dw_doc_kernel, dim3((A.D + kDocSlice - 1) / kDocSlice, A.NCH), dim3(256), 0, st, A, ids64, mask,
+                           gate, table, feat, argmax, d_feat, ws_w, ws_b);
+        RBR_CHECK_LAUNCH("textcnn dw_doc launch");
+    } else {
+        hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
+                           d_feat, ws_w, ws_b);
+        RBR_CHECK_LAUNCH("textcnn dw_partial launch");
+    }
     MutPtrArray dWp{}, dbp{};
     for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
     const long total = (long)A.C * A.KF * A.D;
