@@ -20,6 +20,10 @@ class DeepCoNNpp(nn.Module):
         self.user_feat = LastFeat(user_size, hidden_dim, latent_dim, padding_idx=0)
         self.item_feat = LastFeat(item_size, hidden_dim, latent_dim, padding_idx=0)
         self.fm = FM(user_size, item_size, latent_dim, dropout, user_padding_idx=0, item_padding_idx=0)
+        # encode each distinct user / item document of the batch once.  Valid when a
+        # document is a function of its id (the doc split builds one document per user / item); the reference
+        # re-encodes the same document for every pair it appears in (deepconn.py:46-47).
+        self.dedup_by_id = False
 
     def forward(self, u_revs, i_revs, u_rev_masks, i_rev_masks, u_ids, i_ids):
         """u_revs/i_revs [bz, doc_len] int64, masks [bz, doc_len] bool, ids [bz] -> preds [bz].
@@ -27,9 +31,27 @@ class DeepCoNNpp(nn.Module):
         Both towers share the table and the TextCNN (deepconn.py:43-47), so the user and item
         documents go through ONE launch of the fused gather+conv+pool kernel as a 2*bz batch."""
         bz = u_revs.shape[0]
-        ids = torch.cat([u_revs, i_revs], dim=0)
-        masks = torch.cat([u_rev_masks, i_rev_masks], dim=0)
-        feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
-        u_rev_feats, i_rev_feats = feats[:bz], feats[bz:]
+        if self.dedup_by_id:
+            u_first, u_inv = _first_occurrence(u_ids)
+            i_first, i_inv = _first_occurrence(i_ids)
+            nu = u_first.shape[0]
+            ids = torch.cat([u_revs.index_select(0, u_first), i_revs.index_select(0, i_first)], dim=0)
+            masks = torch.cat([u_rev_masks.index_select(0, u_first), i_rev_masks.index_select(0, i_first)], dim=0)
+            feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
+            u_rev_feats = feats[:nu].index_select(0, u_inv)
+            i_rev_feats = feats[nu:].index_select(0, i_inv)
+        else:
+            ids = torch.cat([u_revs, i_revs], dim=0)
+            masks = torch.cat([u_rev_masks, i_rev_masks], dim=0)
+            feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
+            u_rev_feats, i_rev_feats = feats[:bz], feats[bz:]
         preds = rating_head(self.user_feat, self.item_feat, self.fm, u_rev_feats, i_rev_feats, u_ids, i_ids)
         return preds.view(bz)
+
+
+def _first_occurrence(ids: torch.Tensor):
+    """(rows of the first occurrence of every distinct id, inverse map) -- torch index plumbing on the device."""
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    first = torch.full((uniq.shape[0],), ids.shape[0], dtype=torch.int64, device=ids.device)
+    first.scatter_reduce_(0, inv, torch.arange(ids.shape[0], device=ids.device), reduce="amin")
+    return first, inv

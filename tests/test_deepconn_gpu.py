@@ -133,3 +133,27 @@ def test_cpu_tensors_are_rejected():
     with pytest.raises(RuntimeError):
         RF.textcnn(p["word_embeddings.embedding.weight"], b["u_docs"], b["u_masks"],
                    [p["ngram.feature_layer.0.list_of_conv1d.0.weight"]], [p["ngram.feature_layer.0.list_of_conv1d.0.bias"]])
+
+
+def test_dedup_by_id_equals_plain_path():
+    """f-3: encoding each distinct user / item document once gives the same predictions and gradients."""
+    cfg = synth.DEEPCONN_CFGS["small"]
+    b = synth.deepconn_batch(cfg, 1)
+    # make the batch hit few users / items, each always with the same document (as the doc split guarantees)
+    u_ids = torch.tensor([1, 2, 1, 3, 2, 1, 3, 3]); i_ids = torch.tensor([4, 4, 5, 5, 4, 6, 6, 4])
+    b["u_ids"], b["i_ids"] = u_ids, i_ids
+    b["u_docs"], b["u_masks"] = b["u_docs"][u_ids], b["u_masks"][u_ids]
+    b["i_docs"], b["i_masks"] = b["i_docs"][i_ids], b["i_masks"][i_ids]
+    args, ratings = _batch(b)
+    outs = []
+    for dedup in (False, True):
+        model = _model(cfg, synth.deepconn_params(cfg, 0))
+        model.dedup_by_id = dedup
+        model.train()
+        pred = model(*args)
+        torch.nn.functional.mse_loss(pred, ratings).backward()
+        outs.append((pred.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-6
+    for k in outs[0][1]:
+        ref = outs[0][1][k]
+        assert float((ref - outs[1][1][k]).abs().max()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
