@@ -48,9 +48,9 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
     int ch_off[RBR_MAX_WIDTHS];
     for (int w = 0; w < d->n_widths; ++w) { ch_off[w] = C; C += d->ch[w]; KF = std::max(KF, d->kz[w]); }
     const int tiles_total = (C + kTile - 1) / kTile;
-    // <= 7 tiles per launch keeps the kernel at 2 waves/SIMD (8 tiles = 128 accumulator + ~140 other VGPRs spills
+    // <= 5 tiles per launch keeps the kernel at 2 waves/SIMD (6 tiles = 96 accumulator + ~176 other VGPRs goes
     // past 256); groups are balanced (10 tiles -> 5 + 5, not 8 + 2)
-    constexpr int kPreferredTiles = 7;
+    constexpr int kPreferredTiles = 5;
     const int ngroups = (tiles_total + kPreferredTiles - 1) / kPreferredTiles;
     const int per_group = (tiles_total + ngroups - 1) / ngroups;
     if (ngroups > kMaxGroups) { set_error("%d output channels exceed the supported %d", C, kMaxGroups * kPreferredTiles * kTile); return 0; }

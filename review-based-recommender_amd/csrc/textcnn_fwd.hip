@@ -87,6 +87,15 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const ConvPlan P, const 
 }
 
 // ------------------------------------------------------------------------------------ conv
+// LDS-DMA: 16 bytes per lane straight from global memory into LDS (no VGPR staging).  The LDS destination is
+// `lds_base` (wave-uniform) + lane * 16; the global source is per lane, which is what makes it a row gather.
+__device__ float g_zero_row[64];   // source of masked / out-of-document rows (zero-initialised, never written)
+
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
 template <int DC>
 struct Frag {   // one operand of a piece: DC/8 ds_read_b128 plus a b64 tail when DC % 8 == 4
     f32x4 v[DC / 8];
@@ -102,20 +111,36 @@ struct Frag {   // one operand of a piece: DC/8 ds_read_b128 plus a b64 tail whe
 
 // All LDS operands of a piece are requested up front: one wave alone then keeps the MFMA pipe fed (issuing each
 // read pair behind the previous MFMA group left ~40 % of the pipe idle).
-template <int DC>
-__device__ __forceinline__ void mma_chain(f32x16& acc, const Frag<DC>& a, const Frag<DC>& b) {
+// `between(r)` is invoked after every second k-step (r = 0, 1, ...): the chain is one dependent accumulator, so the
+// wave has ~60 idle issue cycles behind each MFMA -- the LDS-DMA requests of the next piece are slipped in there
+// instead of being paid for (~100 cycles each) in front of the chain.
+template <int DC, class Between>
+__device__ __forceinline__ void mma_chain(f32x16& acc, const Frag<DC>& a, const Frag<DC>& b, Between&& between) {
 #pragma unroll
     for (int q = 0; q < DC / 8; ++q) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].x, b.v[q].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].y, b.v[q].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].z, b.v[q].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, b.v[q].w, acc, 0, 0, 0);
+        if (q & 1) between(q >> 1);
     }
     if (DC % 8 == 4) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.x, b.t.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.y, b.t.y, acc, 0, 0, 0);
     }
 }
+
+#ifdef RBR_DIAG
+#define RBR_STAMP(slot)                                                                         \
+    do {                                                                                        \
+        unsigned long long _t;                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");             \
+        diag[slot] += _t - t_last;                                                              \
+        t_last = _t;                                                                            \
+    } while (0)
+#else
+#define RBR_STAMP(slot) do { } while (0)
+#endif
 
 template <int NT, int DC, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const long long* __restrict__ ids,
@@ -149,12 +174,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
   // but their number per CU is fractional (e.g. 1357 items on 512 resident workgroups): with dynamic pulling the
   // last items run on CUs whose other workgroup has already drained, i.e. with the MFMA pipe to themselves.
   int* item_counter = const_cast<int*>(sched) + 2 * (long)P.total_wt + 1 + P.group;
+#ifdef RBR_DIAG
+  unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
   for (;;) {
     __syncthreads();   // every wave is done with the LDS ring (and with *s_item) of the previous item
     if (tid == 0) *s_item = atomicAdd(item_counter, 1);
     __syncthreads();
     const int item = *s_item;
     if (item >= nitems) break;
+    RBR_STAMP(0);   // item pull
     const int slot_in_list = item * kWavesPerWG + wave;
     const bool active = slot_in_list < n_active;      // wave-uniform
     const int wt = active ? worklist[slot_in_list] : 0;   // global wave-tile
@@ -167,32 +198,33 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    int pre_v4 = 0;   // float4 count of the piece being prefetched (wave-uniform)
-    auto piece_src = [&](int dc, int pi) -> const float* {
-        const int st = P.piece_st[pi];
+    // Weight pieces and token rows travel global -> LDS by LDS-DMA (global_load_lds_dwordx4): piece q+1 is
+    // requested into the free ring slot before piece q computes and is waited for (vmcnt(0), emitted by
+    // __syncthreads) at the end of piece q.  No staging registers, no ds_write pass; the packed image is already
+    // laid out exactly as the ring slot (lane-linear), and so is the token slab ([row][DC] = 16-byte granules in
+    // gather order).  `st` = tap | first tile << 8 | tile count << 16; q+1, q+2 live in SGPRs, q+3 is in flight.
+    const int np = P.npieces;
+    const int T = P.nchunks * np;                       // pieces of one item
+    auto piece_src = [&](int dcq, int st) -> const float* {
         const int s = st & 0xff, t = (st >> 8) & 0xff;
-        pre_v4 = (st >> 16) * (TILE_F / 4);
-        return wbase + (((long)s * P.nchunks + dc) * P.tiles_total + t) * TILE_F;
+        return wbase + (long)((s * P.nchunks + dcq) * P.tiles_total + t) * TILE_F;
+    };
+    auto nv4_of = [&](int st) -> int { return (st >> 16) * (TILE_F / 4); };
+    auto issue_round = [&](int k, float* dst, const float* src, int nv4) {   // all 4 waves: 256 float4 per round
+        const int v0 = 256 * k + 64 * wave;                       // wave-uniform first granule of this instruction
+        if (v0 + lane < nv4) dma16(src + 4 * (v0 + lane), dst + 4 * v0);
+    };
+    auto issue = [&](float* dst, const float* src, int nv4) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) issue_round(k, dst, src, nv4);
+    };
+    auto wrap = [&](int k) -> int {           // k mod np for 0 <= k < np + 3, without an integer division
+        while (k >= np) k -= np;
+        return k;
     };
 
-    f32x4 pre[NLD];
-    auto issue = [&](const float* src) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int v = tid + 256 * k;
-            if (v < pre_v4) pre[k] = *reinterpret_cast<const f32x4*>(src + 4 * v);
-        }
-    };
-    auto commit = [&](float* dst) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int v = tid + 256 * k;
-            if (v < pre_v4) *reinterpret_cast<f32x4*>(dst + 4 * v) = pre[k];
-        }
-    };
-
-    issue(piece_src(0, 0));
-    commit(Ws);
+    int st0 = P.piece_st[0], st1 = P.piece_st[wrap(1)], st2 = P.piece_st[wrap(2)];
+    issue(Ws, piece_src(0, st0), nv4_of(st0));
     int cur = 0;
     if (active) {   // table row offset of every slab row (-1: outside the document or masked), once per item
         for (int row = lane; row < XR; row += 64) {
@@ -205,68 +237,93 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             s_row[row] = ro;
         }
     }
+    RBR_STAMP(1);   // item prologue: first piece request + row offsets
 
-    for (int dc = 0; dc < P.nchunks; ++dc) {
-        // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) -------------------------
-        // (row offsets were resolved once per item into s_row: one L2 round trip per chunk instead of three)
-        if (active) {
-            if (VEC) {
-                constexpr int QPR = DC / 4;
-                for (int idx = lane; idx < XR * QPR; idx += 64) {
-                    const int row = idx / QPR, q = idx - row * QPR;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    const int d = dc * DC + 4 * q;
-                    const long ro = s_row[row];
-                    if (ro >= 0 && d < D) {
-                        v = *reinterpret_cast<const f32x4*>(table + ro + d);
-                        if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
-                    }
-                    *reinterpret_cast<f32x4*>(Xw + row * DC + 4 * q) = v;
-                }
-            } else {
-                for (int idx = lane; idx < XR * DC; idx += 64) {
-                    const int row = idx / DC, dd = idx - row * DC;
-                    float v = 0.f;
-                    const int d = dc * DC + dd;
-                    const long ro = s_row[row];
-                    if (ro >= 0 && d < D) {
-                        v = table[ro + d];
-                        if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
-                    }
-                    Xw[row * DC + dd] = v;
-                }
-            }
-        }
-        __syncthreads();  // token rows + the pending weight piece are visible
-
-        for (int pi = 0; pi < P.npieces; ++pi) {
-            const bool last = (dc == P.nchunks - 1) && (pi == P.npieces - 1);
-            if (!last) {
-                const bool wrap = (pi + 1 == P.npieces);
-                issue(piece_src(wrap ? dc + 1 : dc, wrap ? 0 : pi + 1));  // lands while this piece computes
-            }
+    int pi = 0, dc = 0;                       // piece q = dc * np + pi, tracked incrementally (no divisions)
+    for (int q = 0; q < T; ++q) {
+        if (pi == 0) {
+            // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) --------------------------------
             if (active) {
-                const int st = P.piece_st[pi];
-                const int s = st & 0xff, t = (st >> 8) & 0xff, nt = st >> 16;
-                const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
-                Frag<DC> a, b;
-                a.load(Xw + (i + s) * DC + 4 * h, h);
-                b.load(wb, h);
+                if (VEC && gate == nullptr) {
+                    constexpr int QPR = DC / 4;
+                    constexpr int NX = ((kTile + kMaxKF - 1) * QPR + 63) / 64;
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    if (tt == t) {
-                        mma_chain<DC>(acc[tt], a, b);
-                        if (tt + 1 < NT && nt == 2) {     // second tile of the pair: same token rows
-                            b.load(wb + TILE_F, h);
-                            mma_chain<DC>(acc[tt + 1], a, b);
+                    for (int k = 0; k < NX; ++k) {
+                        const int idx = lane + 64 * k;
+                        if (idx < XR * QPR) {
+                            const int row = idx / QPR, qq = idx - row * QPR;
+                            const int d = dc * DC + 4 * qq;
+                            const long ro = s_row[row];
+                            const float* src = (ro >= 0 && d < D) ? table + ro + d : g_zero_row;
+                            dma16(src, Xw + 256 * k);     // granule idx lands at Xw + 4*idx = row*DC + 4*qq
                         }
                     }
+                } else if (VEC) {     // gated rows (D-ATT) are scaled on the way: register path
+                    constexpr int QPR = DC / 4;
+                    for (int idx = lane; idx < XR * QPR; idx += 64) {
+                        const int row = idx / QPR, qq = idx - row * QPR;
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        const int d = dc * DC + 4 * qq;
+                        const long ro = s_row[row];
+                        if (ro >= 0 && d < D) {
+                            v = *reinterpret_cast<const f32x4*>(table + ro + d);
+                            v *= gate[(long)doc * L + l0 - P.P + row];
+                        }
+                        *reinterpret_cast<f32x4*>(Xw + 4 * idx) = v;
+                    }
+                } else {
+                    for (int idx = lane; idx < XR * DC; idx += 64) {
+                        const int row = idx / DC, dd = idx - row * DC;
+                        float v = 0.f;
+                        const int d = dc * DC + dd;
+                        const long ro = s_row[row];
+                        if (ro >= 0 && d < D) {
+                            v = table[ro + d];
+                            if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
+                        }
+                        Xw[idx] = v;
+                    }
                 }
             }
-            if (!last) commit(Ws + (cur ^ 1) * PIECE);
-            __syncthreads();
-            cur ^= 1;
+            __syncthreads();  // vmcnt(0) + barrier: token rows and the pending weight piece have landed
+            RBR_STAMP(2);   // row gather of the chunk (+ its barrier)
         }
+        const int st3 = P.piece_st[wrap(pi + 3)];         // consumed three pieces from now
+        // piece q+1 goes into the other ring slot (free since the last barrier); its DMA requests are issued from
+        // inside the MFMA chain of the first tile (inactive waves issue them up front)
+        const bool more = q + 1 < T;
+        float* nxt_dst = Ws + (cur ^ 1) * PIECE;
+        const float* nxt_src = piece_src((pi + 1 == np) ? dc + 1 : dc, st1);
+        const int nxt_nv4 = more ? nv4_of(st1) : 0;
+        constexpr int RC = (DC / 8) / 2;                  // DMA rounds that fit inside one chain
+        RBR_STAMP(3);   // prefetch address setup
+        if (active) {
+            const int s = st0 & 0xff, t = (st0 >> 8) & 0xff, nt = st0 >> 16;
+            const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
+            Frag<DC> a, b;
+            a.load(Xw + (i + s) * DC + 4 * h, h);
+            b.load(wb, h);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                if (tt == t) {
+                    mma_chain<DC>(acc[tt], a, b, [&](int r) { if (r < NLD) issue_round(r, nxt_dst, nxt_src, nxt_nv4); });
+#pragma unroll
+                    for (int r = RC; r < NLD; ++r) issue_round(r, nxt_dst, nxt_src, nxt_nv4);
+                    if (tt + 1 < NT && nt == 2) {     // second tile of the pair: same token rows
+                        b.load(wb + TILE_F, h);
+                        mma_chain<DC>(acc[tt + 1], a, b, [](int) {});
+                    }
+                }
+            }
+        } else {
+            issue(nxt_dst, nxt_src, nxt_nv4);
+        }
+        RBR_STAMP(4);   // LDS operand reads + MFMA chains
+        __syncthreads();    // vmcnt(0): piece q+1 has landed; barrier: every wave is done reading slot `cur`
+        RBR_STAMP(6);   // wait + barrier
+        cur ^= 1;
+        st0 = st1; st1 = st2; st2 = st3;
+        if (++pi == np) { pi = 0; ++dc; }
     }
 
     // ---- epilogue: max + first argmax over this wave's 32 positions, per channel slot --------------
@@ -295,7 +352,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             }
         }
     }
+    RBR_STAMP(7);   // epilogue
   }  // item loop
+#ifdef RBR_DIAG
+    if (tid == 0) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(pval + (long)P.total_wt * P.nslots_total) + 8 * blockIdx.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = diag[k];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ finalize
