@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
         if (pi == 0) {
             // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) --------------------------------
             if (active) {
-                if (VEC && gate == nullptr) {
+                if (VEC) {
                     constexpr int QPR = DC / 4;
                     constexpr int NX = ((kTile + kMaxKF - 1) * QPR + 63) / 64;
 #pragma unroll
@@ -258,18 +258,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                             dma16(src, Xw + 256 * k);     // granule idx lands at Xw + 4*idx = row*DC + 4*qq
                         }
                     }
-                } else if (VEC) {     // gated rows (D-ATT) are scaled on the way: register path
-                    constexpr int QPR = DC / 4;
-                    for (int idx = lane; idx < XR * QPR; idx += 64) {
-                        const int row = idx / QPR, qq = idx - row * QPR;
-                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                        const int d = dc * DC + 4 * qq;
-                        const long ro = s_row[row];
-                        if (ro >= 0 && d < D) {
-                            v = *reinterpret_cast<const f32x4*>(table + ro + d);
-                            v *= gate[(long)doc * L + l0 - P.P + row];
+                    if (gate != nullptr) {
+                        // gated rows (D-ATT: x * score): scale the slab in place once the wave's own DMA has landed
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (int idx = lane; idx < XR * QPR; idx += 64) {
+                            const int row = idx / QPR;
+                            const int p = l0 - P.P + row;
+                            if (p >= 0 && p < L) {
+                                f32x4* cell = reinterpret_cast<f32x4*>(Xw + 4 * idx);
+                                *cell = *cell * gate[(long)doc * L + p];
+                            }
                         }
-                        *reinterpret_cast<f32x4*>(Xw + 4 * idx) = v;
                     }
                 } else {
                     for (int idx = lane; idx < XR * DC; idx += 64) {
