@@ -21,24 +21,40 @@ __device__ __forceinline__ float wsum(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------- local gate
-// one wave per token; lanes stride the embedding dim; w is the Conv1d weight [1, E, win]
-__global__ __launch_bounds__(256) void local_gate_fwd_kernel(int B, int L, int E, int win, const long long* __restrict__ ids,
+// One workgroup per (document, tile of 64 tokens): the 64 + win - 1 token rows are staged ONCE in LDS (each row is
+// needed by `win` neighbouring tokens), then every wave reduces 16 tokens: lanes stride the embedding dim, win taps
+// per lane, shuffle reduction.  w is the Conv1d weight [1, E, win].
+constexpr int kGTile = 64;
+
+__global__ __launch_bounds__(256) void local_gate_fwd_kernel(int B, int L, int E, int win, int ntile,
+                                                             const long long* __restrict__ ids,
                                                              const float* __restrict__ table, const float* __restrict__ w,
                                                              const float* __restrict__ b0, float* __restrict__ gate) {
-    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (tok >= (long)B * L) return;
-    const int b = (int)(tok / L), l = (int)(tok % L);
-    const int pad = (win - 1) / 2;
-    float s = 0.f;
-    for (int j = 0; j < win; ++j) {
-        const int p = l + j - pad;
-        if (p < 0 || p >= L) continue;                     // zero padding
-        const float* row = table + ids[(long)b * L + p] * (long)E;
-        for (int e = lane; e < E; e += 64) s = fmaf(row[e], w[(long)e * win + j], s);
+    extern __shared__ float s_rows[];                  // [kGTile + win - 1][E]
+    __shared__ long s_off[kGTile + 2 * kMaxKF + 2];
+    const int b = blockIdx.x / ntile, l0 = (blockIdx.x % ntile) * kGTile;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pad = (win - 1) / 2, R = kGTile + win - 1;
+    for (int r = tid; r < R; r += 256) {
+        const int p = l0 - pad + r;
+        s_off[r] = (p >= 0 && p < L) ? ids[(long)b * L + p] * (long)E : -1;     // zero padding outside the document
     }
-    s = wsum(s);
-    if (lane == 0) gate[tok] = sigmoidf_(s + b0[0]);
+    __syncthreads();
+    for (int idx = tid; idx < R * E; idx += 256) {
+        const int r = idx / E, e = idx - r * E;
+        const long o = s_off[r];
+        s_rows[idx] = (o >= 0) ? table[o + e] : 0.f;
+    }
+    __syncthreads();
+    const float bias = b0[0];
+    for (int t = wave; t < kGTile; t += 4) {
+        if (l0 + t >= L) break;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64)
+            for (int j = 0; j < win; ++j) s = fmaf(s_rows[(t + j) * E + e], w[(long)e * win + j], s);
+        s = wsum(s);
+        if (lane == 0) gate[(long)b * L + l0 + t] = sigmoidf_(s + bias);
+    }
 }
 
 // ---- token-folded embedding gradient of a gate -----------------------------------------------------------
@@ -170,22 +186,31 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(int E, int L, const fl
     }
 }
 
-// per-document partial of dw[e, j] = sum_p x[b,p,e] * dpre[b, p - j + pad]  and of db0; thread e owns column e
+// per-document partial of dw[e, j] = sum_p x[b,p,e] * dpre[b, p - j + pad] and of db0.  The document is walked in
+// tiles of 64 tokens staged in LDS; thread (e, half) owns column e for 32 tokens of each tile and keeps the win
+// partial sums in registers; the two halves meet in LDS at the end.
 __global__ __launch_bounds__(256) void local_gate_bwd_dw_kernel(int B, int L, int E, int win,
                                                                 const long long* __restrict__ ids, const float* __restrict__ table,
                                                                 const float* __restrict__ gate, const float* __restrict__ dgate,
                                                                 float* __restrict__ ws /* [B][win*E + 1] */) {
-    extern __shared__ float s_dpre[];   // [L]
+    extern __shared__ float sm[];                      // dpre [L + 2*pad] | rows [kGTile][E]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int pad = (win - 1) / 2;
-    float part = 0.f;
-    for (int l = tid; l < L; l += 256) {
-        const float gv = gate[(long)b * L + l];
-        const float v = dgate[(long)b * L + l] * gv * (1.f - gv);
-        s_dpre[l] = v;
-        part += v;
-    }
+    float* s_dpre = sm;                                // index l + pad; zero halo
+    float* s_rows = sm + L + 2 * pad;
+    __shared__ long s_off[kGTile];
     __shared__ float s_red[256];
+    float part = 0.f;
+    for (int k = tid; k < L + 2 * pad; k += 256) {
+        const int l = k - pad;
+        float v = 0.f;
+        if (l >= 0 && l < L) {
+            const float gv = gate[(long)b * L + l];
+            v = dgate[(long)b * L + l] * gv * (1.f - gv);
+            part += v;
+        }
+        s_dpre[k] = v;
+    }
     s_red[tid] = part;
     __syncthreads();
     if (tid == 0) {
@@ -193,36 +218,69 @@ __global__ __launch_bounds__(256) void local_gate_bwd_dw_kernel(int B, int L, in
         for (int k = 0; k < 256; ++k) t += s_red[k];
         ws[(long)b * (win * E + 1) + win * E] = t;
     }
-    for (int e = tid; e < E; e += 256) {
+    const int half = tid >> 7, e0 = tid & 127;          // two halves x 128 column lanes
+    for (int ebase = 0; ebase < E; ebase += 128) {
+        const int e = ebase + e0;
         for (int j0 = 0; j0 < win; j0 += kMaxKF) {
             float acc[kMaxKF];
 #pragma unroll
             for (int j = 0; j < kMaxKF; ++j) acc[j] = 0.f;
-            for (int p = 0; p < L; ++p) {
-                const float x = table[ids[(long)b * L + p] * (long)E + e];
+            for (int l0 = 0; l0 < L; l0 += kGTile) {
+                __syncthreads();
+                if (tid < kGTile) s_off[tid] = (l0 + tid < L) ? ids[(long)b * L + l0 + tid] * (long)E : -1;
+                __syncthreads();
+                for (int idx = tid; idx < kGTile * E; idx += 256) {
+                    const int r = idx / E, ee = idx - r * E;
+                    const long o = s_off[r];
+                    s_rows[idx] = (o >= 0) ? table[o + ee] : 0.f;
+                }
+                __syncthreads();
+                if (e < E) {
+                    for (int t = half * 32; t < half * 32 + 32; ++t) {
+                        const float x = s_rows[t * E + e];
+                        const int p = l0 + t;
 #pragma unroll
-                for (int j = 0; j < kMaxKF; ++j) {
-                    const int l = p - (j0 + j) + pad;
-                    if (j0 + j < win && l >= 0 && l < L) acc[j] = fmaf(x, s_dpre[l], acc[j]);
+                        for (int j = 0; j < kMaxKF; ++j)
+                            if (j0 + j < win) acc[j] = fmaf(x, s_dpre[p - (j0 + j) + 2 * pad], acc[j]);
+                    }
                 }
             }
+            // combine the two halves (fixed order) and store
+            __syncthreads();
+            float* s_acc = s_rows;                                // reuse: [2][kMaxKF][128]
 #pragma unroll
-            for (int j = 0; j < kMaxKF; ++j)
-                if (j0 + j < win) ws[(long)b * (win * E + 1) + (long)(j0 + j) * E + e] = acc[j];
+            for (int j = 0; j < kMaxKF; ++j) s_acc[(half * kMaxKF + j) * 128 + e0] = acc[j];
+            __syncthreads();
+            if (half == 0 && e < E) {
+#pragma unroll
+                for (int j = 0; j < kMaxKF; ++j)
+                    if (j0 + j < win)
+                        ws[(long)b * (win * E + 1) + (long)(j0 + j) * E + e] = s_acc[j * 128 + e0] + s_acc[(kMaxKF + j) * 128 + e0];
+            }
         }
     }
 }
 
-// dw[e*win + j] = sum_b ws[b][j*E + e];  db0 = sum_b ws[b][win*E]   (fixed order)
+// dw[e*win + j] = sum_b ws[b][j*E + e];  db0 = sum_b ws[b][win*E]   (fixed partition and order).
+// One workgroup per 32 outputs: 8 thread groups stride the documents.
 __global__ __launch_bounds__(256) void local_gate_bwd_reduce_kernel(int B, int E, int win, const float* __restrict__ ws,
                                                                     float* __restrict__ dw, float* __restrict__ db0) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][32];
     const int n = win * E + 1;
-    if (idx >= n) return;
+    const int kk = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + kk;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += ws[(long)b * n + idx];
-    if (idx == win * E) db0[0] = s;
-    else { const int j = idx / E, e = idx - j * E; dw[(long)e * win + j] = s; }
+    if (idx < n)
+        for (int b = grp; b < B; b += 8) s += ws[(long)b * n + idx];
+    red[grp][kk] = s;
+    __syncthreads();
+    if (grp == 0 && idx < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][kk];
+        if (idx == win * E) db0[0] = t;
+        else { const int j = idx / E, e = idx - j * E; dw[(long)e * win + j] = t; }
+    }
 }
 
 // ---------------------------------------------------------------------------------- global gate
@@ -295,9 +353,12 @@ extern "C" int rbr_datt_local_gate_fwd(int32_t B, int32_t L, int32_t E, int32_t 
     if (!gate_args_ok(B, L, E, win)) return RBR_ERR_BAD_ARG;
     if (win % 2 == 0) { set_error("local attention window must be odd, got %d", win); return RBR_ERR_BAD_ARG; }
     if (!ids || !table || !w || !b0 || !gate) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    const long ntok = (long)B * L;
-    hipLaunchKernelGGL(local_gate_fwd_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, L, E,
-                       win, reinterpret_cast<const long long*>(ids), table, w, b0, gate);
+    if (win > 2 * kMaxKF + 1) { set_error("local attention window %d exceeds the supported %d", win, 2 * kMaxKF + 1); return RBR_ERR_UNSUPPORTED; }
+    const size_t smem = (size_t)(kGTile + win - 1) * E * sizeof(float);
+    if (smem > 120 * 1024) { set_error("embedding dim %d too large for the local-gate LDS tile", E); return RBR_ERR_UNSUPPORTED; }
+    const int ntile = (L + kGTile - 1) / kGTile;
+    hipLaunchKernelGGL(local_gate_fwd_kernel, dim3((unsigned)(B * ntile)), dim3(256), smem, (hipStream_t)stream, B, L, E, win,
+                       ntile, reinterpret_cast<const long long*>(ids), table, w, b0, gate);
     RBR_CHECK_LAUNCH("datt local gate fwd launch");
     return 0;
 }
@@ -325,10 +386,11 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
     if (win > 2 * kMaxKF + 1) { set_error("local attention window %d exceeds the supported %d", win, 2 * kMaxKF + 1); return RBR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
-    hipLaunchKernelGGL(local_gate_bwd_dw_kernel, dim3(B), dim3(256), (size_t)L * sizeof(float), st, B, L, E, win, ids64, table,
-                       gate, dgate, ws);
+    const size_t smem_dw = (size_t)(L + 2 * ((win - 1) / 2) + std::max(kGTile * E, 2 * kMaxKF * 128)) * sizeof(float);
+    if (smem_dw > 140 * 1024) { set_error("doc_len %d x emb %d too large for the local-gate LDS tiles", L, E); return RBR_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(local_gate_bwd_dw_kernel, dim3(B), dim3(256), smem_dw, st, B, L, E, win, ids64, table, gate, dgate, ws);
     RBR_CHECK_LAUNCH("datt local gate bwd dw launch");
-    hipLaunchKernelGGL(local_gate_bwd_reduce_kernel, dim3((unsigned)((win * E + 1 + 255) / 256)), dim3(256), 0, st, B, E, win,
+    hipLaunchKernelGGL(local_gate_bwd_reduce_kernel, dim3((unsigned)((win * E + 1 + 31) / 32)), dim3(256), 0, st, B, E, win,
                        ws, dw, db0);
     RBR_CHECK_LAUNCH("datt local gate bwd reduce launch");
     if (dtable != nullptr) {
