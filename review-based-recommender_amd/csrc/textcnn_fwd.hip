@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                     }
                 }
             }
-            __syncthreads();  // vmcnt(0) + barrier: token rows and the pending weight piece have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA requests have landed ...
+            __syncthreads();                                   // ... and so have everyone else's
             RBR_STAMP(2);   // row gather of the chunk (+ its barrier)
         }
         const int st3 = P.piece_st[wrap(pi + 3)];         // consumed three pieces from now
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             issue(nxt_dst, nxt_src, nxt_nv4);
         }
         RBR_STAMP(4);   // LDS operand reads + MFMA chains
-        __syncthreads();    // vmcnt(0): piece q+1 has landed; barrier: every wave is done reading slot `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // piece q+1: this wave's share has landed (explicit: LDS-DMA
+        __syncthreads();                                   // is ordered for readers only by vmcnt + a barrier)
         RBR_STAMP(6);   // wait + barrier
         cur ^= 1;
         st0 = st1; st1 = st2; st2 = st3;

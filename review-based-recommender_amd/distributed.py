@@ -54,26 +54,21 @@ class GradAllReduce:
         params = [p for p in model.parameters() if p.requires_grad]
         self.big: List[nn.Parameter] = [p for p in params if p.numel() >= BIG_BUCKET_ELEMS]
         self.small: List[nn.Parameter] = [p for p in params if p.numel() < BIG_BUCKET_ELEMS]
-        self._flat: Optional[torch.Tensor] = None
 
     def __call__(self, model: nn.Module = None) -> None:
         if self.world == 1:
             return
+        # RCCL/NCCL averages in the collective itself; gloo (CPU tests) sums and the mean is taken afterwards
+        native_avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
         inv = 1.0 / self.world
         handles = []
         small = [p for p in self.small if p.grad is not None]
         flat = None
         if small:
-            n = sum(p.grad.numel() for p in small)
-            if self._flat is None or self._flat.numel() != n or self._flat.device != small[0].grad.device:
-                self._flat = torch.empty(n, dtype=torch.float32, device=small[0].grad.device)
-            flat = self._flat
-            o = 0
-            for p in small:
-                k = p.grad.numel()
-                flat[o:o + k].copy_(p.grad.reshape(-1))
-                o += k
-            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            # one cat kernel in, one multi-tensor copy kernel out (not 2 x 17 small copies per step)
+            flat = torch.cat([p.grad.reshape(-1) for p in small])
+            handles.append(dist.all_reduce(flat, op=op, group=self.group, async_op=True))
         staged = []
         for p in self.big:
             if p.grad is None:
@@ -81,23 +76,22 @@ class GradAllReduce:
             if self.comm_dtype is not None and self.comm_dtype != p.grad.dtype:
                 buf = p.grad.to(self.comm_dtype)
                 staged.append((p, buf))
-                handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                handles.append(dist.all_reduce(buf, op=op, group=self.group, async_op=True))
             else:
-                handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                handles.append(dist.all_reduce(p.grad, op=op, group=self.group, async_op=True))
         for h in handles:
             h.wait()
         if flat is not None:
-            flat.mul_(inv)
-            o = 0
-            for p in small:
-                k = p.grad.numel()
-                p.grad.copy_(flat[o:o + k].view_as(p.grad))
-                o += k
+            if not native_avg:
+                flat.mul_(inv)
+            views = [v.view_as(p.grad) for v, p in zip(flat.split([p.grad.numel() for p in small]), small)]
+            torch._foreach_copy_([p.grad for p in small], views)
         for p, buf in staged:
             p.grad.copy_(buf)
-        for p in self.big:
-            if p.grad is not None:
-                p.grad.mul_(inv)
+        if not native_avg:
+            for p in self.big:
+                if p.grad is not None:
+                    p.grad.mul_(inv)
 
 
 def shard_batch(tensors, rank: int, world: int):
