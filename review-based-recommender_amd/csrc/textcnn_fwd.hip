@@ -8,14 +8,19 @@
 // is ever written to HBM: the only outputs are (max, argmax) per document and channel.
 //
 // Work decomposition
-//   wave-tile  = 32 consecutive token positions of one document (one MFMA M-block);
-//   workgroup  = 4 waves = 4 consecutive wave-tiles; one wave per SIMD, ~3 workgroups per CU;
+//   wave-tile  = 32 consecutive token positions of one document (one MFMA M-block); tiles whose tokens are all
+//                masked are never computed (tile_scan_kernel builds the work list, their pooled value is exactly 0);
+//   item       = 4 wave-tiles of the work list = one pass of a 4-wave workgroup; persistent workgroups (2 per CU,
+//                i.e. 2 waves per SIMD) pull items from a device counter;
 //   GEMM view  : out[pos, chan] = sum_{tap s} sum_{d} X[pos + s - P, d] * Wf[chan, s, d]
 //                M = positions, N = channel slots (tiles of 32), K = (tap, d).
-//   The K loop is cut into "pieces" = (embedding chunk dc of DC floats, tap s, channel tile t):
-//   a [32 slots][DC] weight block that all 4 waves share through a 2-deep LDS ring, 30 MFMAs per
-//   wave and piece (DC = 60).  Each wave keeps its own [32 + KF - 1][DC] slab of gathered token
-//   rows in LDS and re-reads it for every tap and tile of the chunk.
+//   The K loop is cut into "pieces" = (embedding chunk dc of DC floats, tap s, one or two adjacent channel tiles):
+//   [32 slots][DC] weight blocks that all 4 waves share through a 2-slot LDS ring, 60 MFMAs per wave and paired
+//   piece (DC = 60).  Each wave keeps its own [32 + KF - 1][DC] slab of gathered token rows in LDS and re-reads
+//   it for every tap and tile of the chunk.
+//   Both the weight pieces and the token rows reach LDS by LDS-DMA (global_load_lds_dwordx4: no staging
+//   registers; per-lane source address = row gather); the requests for piece q+1 are issued from inside the
+//   dependent MFMA chain of piece q, where the wave has idle issue slots.
 //
 // MFMA operand mapping (v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k][j = l&31]):
 //   both operands are fetched with ONE ds_read_b128 per 4 MFMAs: lane (i, h) reads floats
