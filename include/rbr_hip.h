@@ -74,11 +74,19 @@ size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d);
  * MFMA tile-major image the conv kernel streams.  `W` is a HOST array of device pointers. */
 int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* packed, void* stream);
 
-/* Stage 2 (the dominant kernel): gather rows table[ids] (zero where mask==0 or out of range, scaled
- * by gate[doc,l] when gate != NULL), run every conv width on the f32 MFMA pipe and max-pool each
- * 32-token slab.  Writes partial (max, first-argmax) pairs: pval/pidx[partial_elems]. */
+/* Stage 2 (the dominant stage): (max, first-argmax) of every conv channel over each 32-token slab:
+ * pval/pidx[partial_elems].  Rows are table[ids], zero where mask == 0 or out of range, scaled by gate[doc,l]
+ * when gate != NULL.  Two exact formulations, chosen per call:
+ *   dense  : gather the rows and run every conv width on the f32 MFMA pipe (what the reference computes);
+ *   product: when `ws` (rbr_textcnn_fwd_ws_bytes(d) bytes, > 0 only when worthwhile) and `W` (HOST array of the
+ *            torch-layout conv weights) are given: T[token][tap, channel] = <table[token], W[channel, :, tap]> for
+ *            the DISTINCT tokens of the batch on the MFMA pipe, then a gather-add of kz rows of T per position.
+ * rbr_set_conv_mode: 0 auto (default; env RBR_CONV_MODE=dense|product overrides), 1 dense, 2 product. */
+size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d);
+void rbr_set_conv_mode(int32_t mode);
 int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                         const float* table, const float* packed, float* pval, int32_t* pidx, void* stream);
+                         const float* table, const float* const* W, const float* packed, float* pval, int32_t* pidx,
+                         void* ws, void* stream);
 
 /* Stage 3: reduce the slabs of each document, add the conv bias, apply the activation.
  * feat[n_docs, C] (C = sum ch[w]); argmax[n_docs, C] = first position attaining the max.

@@ -62,7 +62,10 @@ SIGNATURES = {
     "rbr_textcnn_packed_floats": (C.c_size_t, [_DESC]),
     "rbr_textcnn_partial_elems": (C.c_size_t, [_DESC]),
     "rbr_textcnn_pack": (C.c_int, [_DESC, _PP, c_f32p, c_stream]),
-    "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
+    "rbr_textcnn_fwd_ws_bytes": (C.c_size_t, [_DESC]),
+    "rbr_set_conv_mode": (None, [i32]),
+    "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, _PP, c_f32p, c_f32p, c_i32p, C.c_void_p,
+                                       c_stream]),
     "rbr_textcnn_pool_finalize": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, c_stream]),
     "rbr_textcnn_bwd_ws_floats": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,

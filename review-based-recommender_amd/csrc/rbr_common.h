@@ -15,11 +15,12 @@ namespace rbr {
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kTile = 32;        // MFMA 32x32x2 f32: 32 token positions x 32 channel slots
 constexpr int kMaxTiles = 8;     // channel tiles per launch (8 x 16 accumulator VGPRs)
-constexpr int kMaxGroups = 4;    // launches per conv (<= 1024 output channels)
+constexpr int kMaxGroups = 32;   // launches per conv (<= 5 tiles = 160 channel slots each)
 constexpr int kMaxSlots = kMaxTiles * kTile;
 constexpr int kMaxKF = 9;        // widest conv window
 constexpr int kMaxPieces = kMaxTiles * kMaxKF;
 constexpr int kWavesPerWG = 4;
+constexpr int kSchedCounters = 64;   // ints behind the work list: [0] active tiles, [1 + g] item counter of group g
 
 // One launch of the conv kernel: <= kMaxTiles channel tiles over all wave-tiles of the batch.
 // Passed BY VALUE as a kernel argument (lives in SGPRs / the scalar cache).
@@ -35,6 +36,7 @@ struct ConvPlan {
     int nslots_total;   // 32 * (tiles over all groups): row pitch of the partial-max workspace
     int tile_base;      // first tile of this group in the packed image / workspace
     int group;          // launch index of this plan (selects its work counter)
+    int store_rows;     // 1: write the [32 x 32] accumulator tiles to out[row, slot] (token-product table) instead of pooling
     int ntiles;         // tiles in this group
     int npieces;        // (tap, tile) pairs streamed per embedding chunk
     int pad_mode, act;
@@ -61,6 +63,17 @@ int check_hip(hipError_t e, const char* what);
 
 // Builds the launch plans for `d`.  Returns the number of groups (0 on error, see rbr_last_error()).
 int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */);
+
+// Launches the fused gather + conv kernel for every group of `plans` (textcnn_fwd.hip).  `sched` must have been
+// filled by scan_tiles() for the same document set.  In store_rows mode `pval` is the output table.
+int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, const unsigned char* mask, const float* gate,
+                    const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st);
+// Token-product forward (textcnn_prod.hip): returns 1 when it produced pval/pidx, 0 when the dense conv must run.
+int run_token_product(const rbr_textcnn_desc* d, const ConvPlan* plans, int ngroups, const long long* ids,
+                      const unsigned char* mask, const float* gate, const float* table, const float* const* W, float* pval,
+                      int* pidx, const int* sched, void* ws, hipStream_t st);
+// Zeroes the counters of `sched` and builds flags | work list | counter for the documents of `p`.
+int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st);
 
 // Embedding-dim chunk per weight piece: 60, 52 or 20 floats (all 4*odd: conflict-free b128 reads).  The largest
 // chunk whose zero padding of D stays within 8 % of the best candidate wins (10-MFMA pieces of the 20-float chunk

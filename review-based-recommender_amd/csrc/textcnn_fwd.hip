@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrAr
 // Mask-aware work list.  A wave-tile (32 positions + halo) whose tokens are ALL masked gathers only zero rows:
 // every accumulator stays exactly 0.0f, so its pooled value is known (0 at the tile's first position) without
 // issuing a single MFMA.  Right-padded review documents make ~1/3 of the tiles of the cfg2 batch such tiles.
-// sched layout (int32, tail of the pidx workspace): flags[total_wt] | list[total_wt] | counter[16].
+// sched layout (int32, tail of the pidx workspace): flags[total_wt] | list[total_wt] | counter[kSchedCounters]
+// (counter[0] = active tiles, counter[1 + g] = next work item of launch group g).
 __global__ __launch_bounds__(256) void tile_scan_kernel(const ConvPlan P, const unsigned char* __restrict__ mask,
                                                         int* __restrict__ sched) {
     const int wt = blockIdx.x * 256 + threadIdx.x;
@@ -332,7 +333,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
         if (++pi == np) { pi = 0; ++dc; }
     }
 
-    // ---- epilogue: max + first argmax over this wave's 32 positions, per channel slot --------------
+    // ---- epilogue -----------------------------------------------------------------------------------------
+    if (P.store_rows) {
+        // token-product table: out[row, slot] = accumulator (rows of the pseudo-document = distinct tokens)
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            if (active && tt < P.ntiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = l0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < L) pval[(long)row * P.nslots_total + (long)(P.tile_base + tt) * kTile + i] = acc[tt][r];
+                }
+            }
+        }
+        continue;
+    }
+    // max + first argmax over this wave's 32 positions, per channel slot
     const float NEG = -__builtin_huge_valf();
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
@@ -463,8 +479,8 @@ extern "C" size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d) {
 extern "C" size_t rbr_textcnn_partial_elems(const rbr_textcnn_desc* d) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return 0;
-    // partial (max, argmax) pairs + the scheduling region flags[total_wt] | list[total_wt] | counter[16]
-    return (size_t)plans[0].total_wt * plans[0].nslots_total + 2 * (size_t)plans[0].total_wt + 16;
+    // partial (max, argmax) pairs + the scheduling region flags[total_wt] | list[total_wt] | counters
+    return (size_t)plans[0].total_wt * plans[0].nslots_total + 2 * (size_t)plans[0].total_wt + kSchedCounters;
 }
 
 extern "C" int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* packed, void* stream) {
@@ -484,36 +500,54 @@ extern "C" int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W
 }
 
 extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
-                                    const float* gate, const float* table, const float* packed, float* pval,
-                                    int32_t* pidx, void* stream) {
+                                    const float* gate, const float* table, const float* const* W, const float* packed,
+                                    float* pval, int32_t* pidx, void* ws, void* stream) {
     ConvPlan plans[kMaxGroups];
     const int ng = build_plans(d, plans);
     if (!ng) return RBR_ERR_BAD_ARG;
     if (!ids || !table || !packed || !pval || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    const bool vec = (d->D % 4 == 0) && (((uintptr_t)table & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const long long* ids64 = reinterpret_cast<const long long*>(ids);
     int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
-    if (int e = check_hip(hipMemsetAsync(sched + 2 * (size_t)plans[0].total_wt, 0, 16 * sizeof(int), (hipStream_t)stream),
-                          "work-list counter memset")) return e;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3((plans[0].total_wt + 255) / 256), dim3(256), 0, (hipStream_t)stream, plans[0],
-                       mask, sched);
+    if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
+    if (ws != nullptr && W != nullptr) {
+        const int r = run_token_product(d, plans, ng, ids64, mask, gate, table, W, pval, pidx, sched, ws, st);
+        if (r != 0) return r == 1 ? 0 : r;
+    }
+    return run_conv_groups(plans, ng, ids64, mask, gate, table, packed, pval, pidx, sched, st);
+}
+
+namespace rbr {
+
+int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st) {
+    if (int e = check_hip(hipMemsetAsync(sched + 2 * (size_t)p.total_wt, 0, kSchedCounters * sizeof(int), st), "work-list counter memset"))
+        return e;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((p.total_wt + 255) / 256), dim3(256), 0, st, p, mask, sched);
     RBR_CHECK_LAUNCH("textcnn tile_scan launch");
-    for (int g = 0; g < ng; ++g) {
+    return 0;
+}
+
+int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, const unsigned char* mask, const float* gate,
+                    const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st) {
+    const bool vec = (plans[0].D % 4 == 0) && (((uintptr_t)table & 15) == 0);
+    for (int g = 0; g < ngroups; ++g) {
         int e;
         const ConvPlan& p = plans[g];
-        const long long* ids64 = reinterpret_cast<const long long*>(ids);
         if (p.DC != 20 && !vec) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
         if (p.DC == 60) {
-            e = launch_conv<60, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
+            e = launch_conv<60, true>(p, ids, mask, gate, table, packed, pval, pidx, sched, st);
         } else if (p.DC == 52) {
-            e = launch_conv<52, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
+            e = launch_conv<52, true>(p, ids, mask, gate, table, packed, pval, pidx, sched, st);
         } else {
-            e = vec ? launch_conv<20, true>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream)
-                    : launch_conv<20, false>(p, ids64, mask, gate, table, packed, pval, pidx, sched, (hipStream_t)stream);
+            e = vec ? launch_conv<20, true>(p, ids, mask, gate, table, packed, pval, pidx, sched, st)
+                    : launch_conv<20, false>(p, ids, mask, gate, table, packed, pval, pidx, sched, st);
         }
         if (e) return e;
     }
     return 0;
 }
+
+}  // namespace rbr
 
 extern "C" int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx,
                                          const float* const* bias, float* feat, int32_t* argmax, void* stream) {

@@ -64,11 +64,14 @@ class _TextCNN(torch.autograd.Function):
 
         check(L_.rbr_textcnn_pack(C.byref(desc), ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"), st),
               "rbr_textcnn_pack")
+        ws_bytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))      # > 0: the token-product formulation will run
+        prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         ev = TIMER.record("textcnn_conv_fwd")
         check(L_.rbr_textcnn_conv_fwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
                                       dev_ptr(gate, F32, "gate"), dev_ptr(table_c, F32, "word table"),
-                                      dev_ptr(packed, F32, "packed"), dev_ptr(pval, F32, "pval"),
-                                      dev_ptr(pidx, I32, "pidx"), st), "rbr_textcnn_conv_fwd")
+                                      ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"),
+                                      dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
+                                      prod_ws.data_ptr() if prod_ws is not None else None, st), "rbr_textcnn_conv_fwd")
         if ev is not None:
             ev.record()
         check(L_.rbr_textcnn_pool_finalize(C.byref(desc), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),

@@ -22,3 +22,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_generate_tests(metafunc):
+    """GPU tests that take `conv_mode` run twice: dense conv and token-product formulation (textcnn_prod.hip)."""
+    if "conv_mode" in metafunc.fixturenames and metafunc.definition.get_closest_marker("gpu") is not None:
+        metafunc.parametrize("conv_mode", ["dense", "product"], indirect=True)
+
+
+@pytest.fixture
+def conv_mode(request):
+    from review_based_recommender_amd import _lib
+    mode = getattr(request, "param", "auto")
+    _lib.lib().rbr_set_conv_mode({"auto": 0, "dense": 1, "product": 2}[mode])
+    yield mode
+    _lib.lib().rbr_set_conv_mode(0)

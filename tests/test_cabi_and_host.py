@@ -38,7 +38,7 @@ def test_plan_queries_and_error_reporting_without_gpu():
     d = _lib.make_desc(512, 512, 300, 50002, [3, 5, 7], [50, 50, 50], _lib.PAD_SAME, _lib.ACT_RELU, 0)
     # 5 channel tiles x 7 taps x 5 chunks x 32 slots x 60 floats
     assert L.rbr_textcnn_packed_floats(C.byref(d)) == 5 * 7 * 5 * 32 * 60
-    assert L.rbr_textcnn_partial_elems(C.byref(d)) == 512 * 16 * 160 + 2 * 512 * 16 + 16
+    assert L.rbr_textcnn_partial_elems(C.byref(d)) == 512 * 16 * 160 + 2 * 512 * 16 + 64
     assert L.rbr_textcnn_bwd_ws_floats(C.byref(d)) > 0
     bad = _lib.make_desc(4, 16, 8, 20, [4], [6], _lib.PAD_SAME, _lib.ACT_RELU, 0)     # even 'same' width
     assert L.rbr_textcnn_packed_floats(C.byref(bad)) == 0

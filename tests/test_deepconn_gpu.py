@@ -28,7 +28,7 @@ def _batch(b):
 @pytest.mark.parametrize("name,cfgname,edge", [
     ("deepconn_tiny", "tiny", True), ("deepconn_small", "small", True), ("deepconn_k3", "k3", False),
     ("deepconn_cfg1", "cfg1", False), ("deepconn_cfg2", "cfg2", False)])
-def test_deepconn_matches_reference(golden_dir, name, cfgname, edge):
+def test_deepconn_matches_reference(golden_dir, name, cfgname, edge, conv_mode):
     from review_based_recommender_amd.train_step import make_optimizer, train_step
     g = golden(golden_dir, name)
     cfg = synth.DEEPCONN_CFGS[cfgname]
@@ -57,7 +57,7 @@ def test_deepconn_matches_reference(golden_dir, name, cfgname, edge):
 @pytest.mark.parametrize("name,cfgname,edge", [
     ("deepconn_tiny", "tiny", True), ("deepconn_small", "small", True), ("deepconn_k3", "k3", False),
     ("deepconn_cfg1", "cfg1", False), ("deepconn_cfg2", "cfg2", False)])
-def test_deepconn_gradients_match_reference(golden_dir, name, cfgname, edge):
+def test_deepconn_gradients_match_reference(golden_dir, name, cfgname, edge, conv_mode):
     g = golden(golden_dir, name)
     cfg = synth.DEEPCONN_CFGS[cfgname]
     model = _model(cfg, synth.deepconn_params(cfg, 0))
@@ -71,7 +71,7 @@ def test_deepconn_gradients_match_reference(golden_dir, name, cfgname, edge):
     assert float(model.user_feat.ebd.weight.grad[0].abs().max()) == 0.0
 
 
-def test_ngram_features_match_oracle(golden_dir):
+def test_ngram_features_match_oracle(golden_dir, conv_mode):
     """TextCNN features alone (u_rev_feats / i_rev_feats of the reference forward)."""
     from review_based_recommender_amd import functional as RF
     from oracle import ref_cpu as O
@@ -135,7 +135,7 @@ def test_cpu_tensors_are_rejected():
                    [p["ngram.feature_layer.0.list_of_conv1d.0.weight"]], [p["ngram.feature_layer.0.list_of_conv1d.0.bias"]])
 
 
-def test_dedup_by_id_equals_plain_path():
+def test_dedup_by_id_equals_plain_path(conv_mode):
     """f-3: encoding each distinct user / item document once gives the same predictions and gradients."""
     cfg = synth.DEEPCONN_CFGS["small"]
     b = synth.deepconn_batch(cfg, 1)

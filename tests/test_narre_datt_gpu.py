@@ -26,7 +26,7 @@ def _narre_batch(b):
 
 @pytest.mark.parametrize("name,cfgname,edge", [("narre_tiny", "tiny", True), ("narre_small", "small", True),
                                                ("narre_cfg3", "cfg3", False)])
-def test_narre_matches_reference(golden_dir, name, cfgname, edge):
+def test_narre_matches_reference(golden_dir, name, cfgname, edge, conv_mode):
     from review_based_recommender_amd.train_step import make_optimizer, train_step
     g = golden(golden_dir, name)
     cfg = synth.NARRE_CFGS[cfgname]
@@ -71,7 +71,7 @@ def _datt(cfg, dropout=0.0, scale=1.0):
 
 
 @pytest.mark.parametrize("name,cfgname", [("datt_tiny", "tiny"), ("datt_small", "small")])
-def test_datt_matches_reference(golden_dir, name, cfgname):
+def test_datt_matches_reference(golden_dir, name, cfgname, conv_mode):
     from review_based_recommender_amd.train_step import make_optimizer, train_step
     g = golden(golden_dir, name)
     cfg = synth.DATT_CFGS[cfgname]
@@ -97,7 +97,7 @@ def test_datt_matches_reference(golden_dir, name, cfgname):
             check_params_after(model, g, f"after{step + 1}")
 
 
-def test_datt_cfg4_forward(golden_dir):
+def test_datt_cfg4_forward(golden_dir, conv_mode):
     """BASELINE configs[3]: B=512, 2x1024 tokens, E=100 -- forward against the reference's predictions."""
     g = golden(golden_dir, "datt_cfg4")
     cfg = synth.DATT_CFGS["cfg4"]
@@ -133,7 +133,7 @@ def test_hierpooling_matches_reference(golden_dir):
     check_grads({k: p.grad for k, p in m.named_parameters()}, g)
 
 
-def test_standalone_layers_match_oracle():
+def test_standalone_layers_match_oracle(conv_mode):
     """WordEmbedding.forward and NgramFeat.forward(inputs, masks) with the reference's per-layer signatures."""
     from oracle import ref_cpu as O
     from review_based_recommender_amd.models.deepconn.layers import NgramFeat, WordEmbedding

@@ -69,7 +69,7 @@ def _case(n_docs, L, D, V, kzs, chans, seed, mask_p=0.2, gate=False, valid=False
     dict(n_docs=3, L=30, D=104, V=60, kzs=[2, 3, 4], chans=[20, 20, 20], mask_p=None, gate=True, valid=True, tanh=True),
     dict(n_docs=2, L=37, D=60, V=60, kzs=[1], chans=[70], mask_p=None, gate=True, tanh=True),   # D-ATT local conv shape
 ])
-def test_textcnn_edge_shapes(shape):
+def test_textcnn_edge_shapes(shape, conv_mode):
     _case(seed=11, **shape)
 
 
@@ -95,7 +95,7 @@ def _cfg2_inputs():
     return table, ids, mask, ws, bs
 
 
-def test_fullsize_properties_cfg2():
+def test_fullsize_properties_cfg2(conv_mode):
     """At B=256 x 2 x 512 tokens the oracle is too slow for gradients; check properties instead."""
     from review_based_recommender_amd import functional as RF
     table, ids, mask, ws, bs = _cfg2_inputs()
@@ -116,7 +116,7 @@ def test_fullsize_properties_cfg2():
     assert torch.allclose(fz[0], torch.relu(torch.cat(bs)), atol=0, rtol=0)
 
 
-def test_fullsize_backward_properties_cfg2():
+def test_fullsize_backward_properties_cfg2(conv_mode):
     from review_based_recommender_amd import functional as RF
     table, ids, mask, ws, bs = _cfg2_inputs()
 

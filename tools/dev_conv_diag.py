@@ -21,7 +21,7 @@ packed = torch.empty(npk, device=dev); pval = torch.zeros(npart + 8 * 2048 * 2, 
 st = torch.cuda.current_stream().cuda_stream
 lib.rbr_textcnn_pack(C.byref(d), _lib.ptr_array(ws, torch.float32, "w"), packed.data_ptr(), st)
 for _ in range(3):
-    rc = lib.rbr_textcnn_conv_fwd(C.byref(d), ids.data_ptr(), mask.data_ptr() if mask is not None else None, None, table.data_ptr(), packed.data_ptr(), pval.data_ptr(), pidx.data_ptr(), st)
+    rc = lib.rbr_textcnn_conv_fwd(C.byref(d), ids.data_ptr(), mask.data_ptr() if mask is not None else None, None, table.data_ptr(), None, packed.data_ptr(), pval.data_ptr(), pidx.data_ptr(), None, st)
     assert rc == 0
 torch.cuda.synchronize()
 total_wt = ids.shape[0] * 16
