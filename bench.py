@@ -13,9 +13,11 @@ fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the referenc
 HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
 
 Rank 0 prints ONE JSON line.  `value` = pairs/s over all ranks of the full train step;
-`roofline` prices the dominant kernel (fused gather+conv+max-pool forward, f32 MFMA) with HIP
-events recorded around its launches inside the timed region; `cpu_baseline` times the CPU oracle
-(oracle/ref_cpu.py, torch CPU ops) on the same workload on this host's cores.
+`roofline` prices the longest kernel of the step with HIP events recorded around its launches inside the
+timed region: by default the embedding-gradient scatter (HBM/atomic bound) because the conv runs in its
+token-product form (csrc/textcnn_prod.hip); with RBR_CONV_MODE=dense the fused gather+conv+max-pool
+kernel on the f32 MFMA pipe.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, torch CPU ops) on
+the same workload on this host's cores.
 """
 from __future__ import annotations
 
@@ -59,11 +61,11 @@ def active_tile_fraction(cfg, masks) -> float:
     return act / float(n_docs * wpd)
 
 
-def measured_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (profiles/r01_conv_fwd_pmc.json:
+def measured_traffic(name="r01_conv_fwd_pmc.json"):
+    """HBM bytes per launch of the priced kernel from the committed rocprofv3 PMC passes (profiles/<name>:
     FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 correction) -- not measurable from inside this
     process; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_fwd_pmc.json")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_bytes_per_launch_corrected"])
@@ -224,9 +226,11 @@ def main():
     if rank == 0:
         pairs = cfg["B"] * a.steps * world
         conv_calls, conv_ms = ksum.get("textcnn_conv_fwd", (0, float("nan")))
+        dx_calls, dx_ms = ksum.get("textcnn_bwd_dtable", (0, float("nan")))
         flops = conv_fwd_flops(cfg)
-        ach = flops / (conv_ms * 1e-3) / 1e12
-        act_frac = active_tile_fraction(cfg, torch.cat([args[2], args[3]]))
+        masks = torch.cat([args[2], args[3]])
+        act_frac = active_tile_fraction(cfg, masks)
+        dense_mode = os.environ.get("RBR_CONV_MODE") == "dense"
         out = {
             "metric": "(user,item) pairs/sec, DeepCoNN train step (fwd+MSE+bwd+clip+Adam), bsz256 2x512tok",
             "value": round(pairs / elapsed, 1), "unit": "pairs/s",
@@ -238,18 +242,42 @@ def main():
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
                        "parallelism": f"dp{world}"},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
-            "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel (gather+conv+max-pool, v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
-                         "traffic_source": "profiles/r01_conv_fwd_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                         "flops_per_launch": flops, "avg_launch_ms": round(conv_ms, 4), "launches_timed": conv_calls,
-                         "note": "achieved = ALGORITHMIC dense-conv FLOPs / time (contract). The kernel skips wave-tiles "
-                                 "whose tokens are all padding (their sums are exactly 0): executed_* price only the MFMAs issued",
-                         "executed_tile_fraction": round(act_frac, 4),
-                         "executed_achieved": round(ach * act_frac, 2),
-                         "executed_frac": round(ach * act_frac / PEAK_F32_MFMA_TFLOPS, 4)},
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
         }
+        if dense_mode:
+            ach = flops / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "kernel": "conv_fwd_kernel (dense: gather+conv+max-pool, v_mfma_f32_32x32x2_f32)",
+                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic("r01_conv_fwd_pmc.json"),
+                "traffic_source": "profiles/r01_conv_fwd_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                "flops_per_launch": flops, "avg_launch_ms": round(conv_ms, 4), "launches_timed": conv_calls,
+                "note": "achieved = ALGORITHMIC dense-conv FLOPs / time. Wave-tiles whose tokens are all padding are "
+                        "skipped (their sums are exactly 0): executed_* price only the MFMAs issued",
+                "executed_tile_fraction": round(act_frac, 4), "executed_achieved": round(ach * act_frac, 2),
+                "executed_frac": round(ach * act_frac / PEAK_F32_MFMA_TFLOPS, 4)}
+        else:
+            # default build: the conv runs in its token-product form (a 9x smaller contraction), so the longest kernel
+            # of the step is the embedding-gradient scatter.  Algorithmic bytes = the dense table-gradient
+            # read-modify-write of embedding_dense_backward: 2 * (2 docs * L * D * 4 B) per pair.
+            dx_bytes = cfg["B"] * 2.0 * (2 * cfg["L"] * cfg["D"] * 4)
+            gbs = dx_bytes / (dx_ms * 1e-3) / 1e9
+            ids_all = torch.cat([args[0], args[1]])
+            n_distinct = int(torch.unique(ids_all[masks]).numel())
+            cp = ((sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"]) + 159) // 160) * 160
+            gemm_flops = 2.0 * n_distinct * cfg["D"] * cp
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "dx_window_kernel (token-folded embedding-gradient scatter, f32 atomics)",
+                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                "traffic": measured_traffic("r01_dx_window_pmc.json"),
+                "traffic_source": "profiles/r01_dx_window_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                "bytes_per_launch": dx_bytes, "avg_launch_ms": round(dx_ms, 4), "launches_timed": dx_calls,
+                "note": "dominant kernel of the default (token-product) step; RBR_CONV_MODE=dense prices the dense MFMA conv"}
+            out["conv_stage"] = {
+                "formulation": "token-product: T = table[distinct tokens] @ W (f32 MFMA), then gather-add + max-pool",
+                "ms": round(conv_ms, 4), "distinct_tokens": n_distinct, "positions": int(masks.numel()),
+                "mfma_flops_executed": gemm_flops, "dense_conv_flops_replaced": flops,
+                "dense_equivalent_TFLOPs": round(flops / (conv_ms * 1e-3) / 1e12, 1)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -104,6 +104,13 @@ int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float* pval, cons
  *   dgate    [n_docs, L]        ACCUMULATED (caller zeroes); NULL when gate == NULL
  *   ws       workspace of rbr_textcnn_bwd_ws_floats(d) floats                                  */
 size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d);
+/* the two halves of rbr_textcnn_bwd, callable separately (conv weight / bias gradients; table / gate gradients) */
+int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                       const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
+                       float* const* dW, float* const* dbias, float* ws, void* stream);
+int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                           const float* table, const float* packed, const float* feat, const int32_t* argmax,
+                           const float* d_feat, float* dtable, float* dgate, void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                     const float* table, const float* packed, const float* feat, const int32_t* argmax,
                     const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,

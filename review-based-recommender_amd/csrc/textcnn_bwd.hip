@@ -534,17 +534,12 @@ extern "C" size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d) {
     return (size_t)A.NCH * A.C * A.KF * A.D + (size_t)A.NCH * A.C;
 }
 
-extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                               const float* table, const float* packed, const float* feat, const int32_t* argmax,
-                               const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,
-                               float* ws, void* stream) {
+extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                  const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
+                                  float* const* dW, float* const* dbias, float* ws, void* stream) {
     BwdArgs A;
     if (int e = fill_args(d, A)) return e;
-    if (!ids || !table || !packed || !feat || !argmax || !d_feat || !dW || !dbias || !ws) {
-        set_error("null pointer");
-        return RBR_ERR_BAD_ARG;
-    }
-    if ((long)d->V * d->D <= 0) { set_error("bad table shape"); return RBR_ERR_BAD_ARG; }
+    if (!ids || !table || !feat || !argmax || !d_feat || !dW || !dbias || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     float* ws_w = ws;
@@ -564,14 +559,31 @@ extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, co
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, A,
                        ws_w, ws_b, dWp, dbp);
     RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
-    if (dtable != nullptr || (dgate != nullptr && gate != nullptr)) {
-        static const int win_env = getenv("RBR_DEV_DX_WIN") ? atoi(getenv("RBR_DEV_DX_WIN")) : 0;   // tuning aid
-        int kWin = win_env > 0 ? std::min(win_env, kWinMax) : 256;
-        kWin = std::min(kWin, ((A.L + 63) / 64) * 64);
-        const int nwin = (A.L + kWin - 1) / kWin;
-        hipLaunchKernelGGL(dx_window_kernel, dim3((unsigned)(A.n_docs * nwin)), dim3(256), 0, st, A, kWin, nwin, ids64,
-                           mask, gate, table, packed, feat, argmax, d_feat, dtable, (gate != nullptr) ? dgate : nullptr);
-        RBR_CHECK_LAUNCH("textcnn dx_window launch");
-    }
     return 0;
+}
+
+extern "C" int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                      const float* table, const float* packed, const float* feat, const int32_t* argmax,
+                                      const float* d_feat, float* dtable, float* dgate, void* stream) {
+    BwdArgs A;
+    if (int e = fill_args(d, A)) return e;
+    if (!ids || !table || !packed || !feat || !argmax || !d_feat) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (dtable == nullptr && !(dgate != nullptr && gate != nullptr)) return 0;
+    static const int win_env = getenv("RBR_DEV_DX_WIN") ? atoi(getenv("RBR_DEV_DX_WIN")) : 0;   // tuning aid
+    int kWin = win_env > 0 ? std::min(win_env, kWinMax) : 256;
+    kWin = std::min(kWin, ((A.L + 63) / 64) * 64);
+    const int nwin = (A.L + kWin - 1) / kWin;
+    hipLaunchKernelGGL(dx_window_kernel, dim3((unsigned)(A.n_docs * nwin)), dim3(256), 0, (hipStream_t)stream, A, kWin, nwin,
+                       reinterpret_cast<const long long*>(ids), mask, gate, table, packed, feat, argmax, d_feat, dtable,
+                       (gate != nullptr) ? dgate : nullptr);
+    RBR_CHECK_LAUNCH("textcnn dx_window launch");
+    return 0;
+}
+
+extern "C" int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                               const float* table, const float* packed, const float* feat, const int32_t* argmax,
+                               const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,
+                               float* ws, void* stream) {
+    if (int e = rbr_textcnn_bwd_dw(d, ids, mask, gate, table, feat, argmax, d_feat, dW, dbias, ws, stream)) return e;
+    return rbr_textcnn_bwd_dtable(d, ids, mask, gate, table, packed, feat, argmax, d_feat, dtable, dgate, stream);
 }

@@ -171,10 +171,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     float* Xw = Xs + wave * XR * DC;
     long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * (kTile + kMaxKF);   // [XR] per wave
     int* s_item = reinterpret_cast<int*>(reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + kWavesPerWG * (kTile + kMaxKF));
-    const float* wbase = packed + (long)P.tile_base * TILE_F;
+    // store_rows launches fold all (identical) channel-tile groups into one grid: item -> (row item, group)
+    const int ngroups_in_launch = P.store_rows ? P.tiles_total / P.ntiles : 1;
     const int n_active = sched[2 * (long)P.total_wt];            // wave-tiles with at least one unmasked token
     const int* worklist = sched + P.total_wt;
-    const int nitems = (n_active + kWavesPerWG - 1) / kWavesPerWG;
+    const int nrow_items = (n_active + kWavesPerWG - 1) / kWavesPerWG;
+    const int nitems = nrow_items * ngroups_in_launch;
 
   // Persistent workgroups pull items (4 wave-tiles of the work list) from a device counter.  Items cost the same,
   // but their number per CU is fractional (e.g. 1357 items on 512 resident workgroups): with dynamic pulling the
@@ -192,7 +194,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const int item = *s_item;
     if (item >= nitems) break;
     RBR_STAMP(0);   // item pull
-    const int slot_in_list = item * kWavesPerWG + wave;
+    const int grp = item / nrow_items;                 // 0 unless store_rows
+    const int tile_base = P.tile_base + grp * P.ntiles;
+    const float* wbase = packed + (long)tile_base * TILE_F;
+    const int slot_in_list = (item - grp * nrow_items) * kWavesPerWG + wave;
     const bool active = slot_in_list < n_active;      // wave-uniform
     const int wt = active ? worklist[slot_in_list] : 0;   // global wave-tile
     const int doc = wt / P.wpd;
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = l0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < L) pval[(long)row * P.nslots_total + (long)(P.tile_base + tt) * kTile + i] = acc[tt][r];
+                    if (row < L) pval[(long)row * P.nslots_total + (long)(tile_base + tt) * kTile + i] = acc[tt][r];
                 }
             }
         }
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
             const int oi = __shfl_xor(bidx, 32);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
             if (h == 0) {
-                const long o = (long)wt * P.nslots_total + (long)(P.tile_base + tt) * kTile + i;
+                const long o = (long)wt * P.nslots_total + (long)(tile_base + tt) * kTile + i;
                 pval[o] = best;
                 pidx[o] = bidx;
             }
@@ -442,7 +447,7 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
             nb = 2;
         occ = nb;
     }
-    const int nitems = (p.total_wt + kWavesPerWG - 1) / kWavesPerWG;
+    const int nitems = ((p.total_wt + kWavesPerWG - 1) / kWavesPerWG) * (p.store_rows ? p.tiles_total / p.ntiles : 1);
     const dim3 grid(std::min(nitems, num_cus() * occ)), block(256);
     hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,
                        pidx, sched);

@@ -28,6 +28,7 @@ struct ProdArgs {
     int zrow;                       // index of the all-zero row of T (= cap)
     int pitch;                      // floats per row of T (32 * product tiles)
     int poff[RBR_MAX_WIDTHS];       // first product channel of bank w: channel (w, j, cl) = poff[w] + j*ch[w] + cl
+    int cp_real;                    // product channels before padding to whole launch groups
 };
 
 // ---------------------------------------------------------------------------------- distinct tokens
@@ -40,7 +41,10 @@ __global__ __launch_bounds__(256) void mark_tokens_kernel(long n_tok, const long
 // row_of_token[v] = dense row index (any order) or -1; tok_of_row / row_mask describe the pseudo-document
 __global__ __launch_bounds__(256) void compact_tokens_kernel(int V, int cap, const int* __restrict__ used,
                                                              int* __restrict__ row_of_token, long long* __restrict__ tok_of_row,
-                                                             unsigned char* __restrict__ row_mask, int* __restrict__ counter) {
+                                                             unsigned char* __restrict__ row_mask, int* __restrict__ counter,
+                                                             float* __restrict__ zero_row, int pitch) {
+    if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
+        for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int u = (v < V) ? used[v] : 0;
     const unsigned long long b = __ballot(u);
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void pack_prod_kernel(const ConvPlan P, const 
         const int pc = t * kTile + slot;          // product channel
         const int d = dc * DC + dd;
         float v = 0.f;
-        if (pc < P.C && d < P.D) {
+        if (pc < A.cp_real && d < P.D) {
             int w = 0;
 #pragma unroll
             for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
@@ -198,8 +202,10 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     Lo.cap = (int)std::min<long>(d->V, n_pos);
     long Cp = 0;
     for (int w = 0; w < d->n_widths; ++w) Cp += (long)d->kz[w] * d->ch[w];
+    constexpr int kGroupSlots = 5 * kTile;            // one launch group = 5 tiles (rbr_plan.hip)
+    Cp = ((Cp + kGroupSlots - 1) / kGroupSlots) * kGroupSlots;   // zero-weight padding channels: all groups identical
     Lo.Cp = (int)Cp;
-    Lo.tiles_p = (int)((Cp + kTile - 1) / kTile);
+    Lo.tiles_p = (int)(Cp / kTile);
     memset(&Lo.dp, 0, sizeof(Lo.dp));
     Lo.dp.n_docs = 1; Lo.dp.L = Lo.cap; Lo.dp.D = d->D; Lo.dp.V = d->V;
     Lo.dp.n_widths = 1; Lo.dp.kz[0] = 1; Lo.dp.ch[0] = Lo.Cp;
@@ -208,11 +214,12 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     if (!build_plans(&Lo.dp, plans)) return false;
     const ConvPlan& p = plans[0];
     size_t o = 0;
+    // [used | row_mask | counter] are contiguous: ONE memset node re-initialises them every call
     Lo.used = o;         o += align256((size_t)d->V * sizeof(int));
-    Lo.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
-    Lo.tok_of_row = o;   o += align256((size_t)Lo.cap * sizeof(long long));
     Lo.row_mask = o;     o += align256((size_t)Lo.cap);
     Lo.counter = o;      o += 256;
+    Lo.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
+    Lo.tok_of_row = o;   o += align256((size_t)Lo.cap * sizeof(long long));
     Lo.sched = o;        o += align256((2 * (size_t)p.total_wt + kSchedCounters) * sizeof(int));
     Lo.packed = o;       o += align256((size_t)p.nchunks * p.tiles_total * kTile * p.DC * sizeof(float));
     Lo.table_T = o;      o += align256(((size_t)Lo.cap + 1) * p.nslots_total * sizeof(float));
@@ -255,24 +262,24 @@ int run_token_product(const rbr_textcnn_desc* d, const ConvPlan* plans, int ngro
     ConvPlan pp[kMaxGroups];
     const int ngp = build_plans(&Lo.dp, pp);
     if (!ngp) return RBR_ERR_BAD_ARG;
-    for (int g = 0; g < ngp; ++g) pp[g].store_rows = 1;
+    pp[0].store_rows = 1;      // group 0's plan describes every group; the kernel folds them into one launch
+    (void)ngp;
 
     ProdArgs A{};
     A.n_docs = d->n_docs; A.L = d->L; A.V = d->V; A.cap = Lo.cap; A.zrow = Lo.cap; A.pitch = pp[0].nslots_total;
     {   // product channels follow the plan's bank order of the ORIGINAL problem (bank w, tap j, channel cl)
         int o = 0;
         for (int w = 0; w < d->n_widths; ++w) { A.poff[w] = o; o += d->kz[w] * d->ch[w]; }
+        A.cp_real = o;
     }
     // 1. distinct tokens  (used / row_mask / counter / zero row are re-initialised every call: graph-replay safe)
-    if (int e = check_hip(hipMemsetAsync(base + Lo.used, 0, Lo.row_of_token - Lo.used, st), "token flag memset")) return e;
-    if (int e = check_hip(hipMemsetAsync(base + Lo.row_mask, 0, Lo.sched - Lo.row_mask, st), "row mask memset")) return e;
-    if (int e = check_hip(hipMemsetAsync(T + (size_t)Lo.cap * A.pitch, 0, (size_t)A.pitch * sizeof(float), st), "zero row memset")) return e;
+    if (int e = check_hip(hipMemsetAsync(base + Lo.used, 0, Lo.row_of_token - Lo.used, st), "token-list state memset")) return e;
     const long n_tok = (long)d->n_docs * d->L;
     hipLaunchKernelGGL(mark_tokens_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, n_tok,
                        ids, mask, used);
     RBR_CHECK_LAUNCH("textcnn mark_tokens launch");
     hipLaunchKernelGGL(compact_tokens_kernel, dim3((d->V + 255) / 256), dim3(256), 0, st, d->V, Lo.cap, used, row_of_token,
-                       tok_of_row, row_mask, counter);
+                       tok_of_row, row_mask, counter, T + (size_t)Lo.cap * A.pitch, A.pitch);
     RBR_CHECK_LAUNCH("textcnn compact_tokens launch");
     // 2. product weights
     PtrArray wp{};
@@ -285,7 +292,7 @@ int run_token_product(const rbr_textcnn_desc* d, const ConvPlan* plans, int ngro
     }
     // 3. T = table[tok_of_row] @ Wprod  (rows beyond the distinct count are masked -> their tiles are skipped)
     if (int e = scan_tiles(pp[0], row_mask, sched_p, st)) return e;
-    if (int e = run_conv_groups(pp, ngp, tok_of_row, row_mask, nullptr, table, packed_p, T, nullptr, sched_p, st)) return e;
+    if (int e = run_conv_groups(pp, 1, tok_of_row, row_mask, nullptr, table, packed_p, T, nullptr, sched_p, st)) return e;
     // 4. gather + pool per active wave-tile of the real documents
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
     for (int g = 0; g < ngroups; ++g) {

@@ -110,13 +110,20 @@ class _TextCNN(torch.autograd.Function):
         dgate = torch.zeros_like(gate) if need_gate else None
         wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
         wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
-        ev = TIMER.record("textcnn_bwd")
-        check(L_.rbr_textcnn_bwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                 dev_ptr(gate, F32, "gate"), dev_ptr(table, F32, "table"), dev_ptr(packed, F32, "packed"),
-                                 dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                 dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
-                                 dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"),
-                                 dev_ptr(wsb, F32, "ws"), current_stream()), "rbr_textcnn_bwd")
+        st = current_stream()
+        common = (C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(gate, F32, "gate"),
+                  dev_ptr(table, F32, "table"))
+        ev = TIMER.record("textcnn_bwd_dw")
+        check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                    dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                    dev_ptr(wsb, F32, "ws"), st), "rbr_textcnn_bwd_dw")
+        if ev is not None:
+            ev.record()
+        ev = TIMER.record("textcnn_bwd_dtable")
+        check(L_.rbr_textcnn_bwd_dtable(*common, dev_ptr(packed, F32, "packed"), dev_ptr(feat, F32, "feat"),
+                                        dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                        dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st),
+              "rbr_textcnn_bwd_dtable")
         if ev is not None:
             ev.record()
         return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
