@@ -12,12 +12,16 @@ fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the referenc
 [N>1: RCCL gradient all-reduce] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
 HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
 
+The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed; every timed step first copies
+its batch into the graph's input buffers.  `--no-graph` launches the kernels one by one from Python instead.
+
 Rank 0 prints ONE JSON line.  `value` = pairs/s over all ranks of the full train step;
-`roofline` prices the longest kernel of the step with HIP events recorded around its launches inside the
-timed region: by default the embedding-gradient scatter (HBM/atomic bound) because the conv runs in its
-token-product form (csrc/textcnn_prod.hip); with RBR_CONV_MODE=dense the fused gather+conv+max-pool
-kernel on the f32 MFMA pipe.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, torch CPU ops) on
-the same workload on this host's cores.
+`roofline` prices the longest kernel of the step -- by default the distinct-token GEMM of the token-product
+conv (csrc/textcnn_prod.hip) on the f32 MFMA pipe; with RBR_CONV_MODE=dense the fused gather+conv+max-pool
+kernel -- with HIP events recorded around its launches on the launch stream.  Events cannot be read inside a
+replayed graph, so the event pass re-runs the same K steps eagerly right after the timed region (with
+--no-graph the events sit in the timed region itself).  `cpu_baseline` times the CPU oracle
+(oracle/ref_cpu.py, torch CPU ops) on the same workload on this host's cores.
 """
 from __future__ import annotations
 
@@ -151,6 +155,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -165,7 +170,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     from review_based_recommender_amd import _lib
-    from review_based_recommender_amd.train_step import make_optimizer, train_step
+    from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
     _lib.lib()   # fail loudly now if librbr_hip.so is missing
 
     # rehearsal aids for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
@@ -184,7 +189,8 @@ def main():
 
     model = build_model(cfg, device)          # identical parameters on every rank (same seed)
     model.train()
-    opt = make_optimizer(model)
+    use_graph = not a.no_graph
+    opt = make_optimizer(model, capturable=use_graph)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
         grad_sync = GradAllReduce(model)
@@ -194,15 +200,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:
+        stepper = GraphedTrainStep(model, opt, args, ratings, grad_sync=grad_sync)
+
+        def step():
+            stepper(args, ratings)      # batch copied into the graph's input buffers, then one replay
+    else:
+        def step():
+            train_step(model, opt, args, ratings, grad_sync=grad_sync)
+
     for _ in range(a.warmup):
-        train_step(model, opt, args, ratings, grad_sync=grad_sync)
+        step()
     barrier()
-    _lib.TIMER.start()
+    if not use_graph:
+        _lib.TIMER.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        train_step(model, opt, args, ratings, grad_sync=grad_sync)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if use_graph:
+        # HIP-event pass over the same K steps, launched eagerly (events cannot be read inside a replayed graph)
+        _lib.TIMER.start()
+        for _ in range(a.steps):
+            train_step(model, opt, args, ratings, grad_sync=grad_sync)
+        barrier()
     _lib.TIMER.stop()
     ksum = _lib.TIMER.summary()
 
@@ -225,12 +247,9 @@ def main():
 
     if rank == 0:
         pairs = cfg["B"] * a.steps * world
-        conv_calls, conv_ms = ksum.get("textcnn_conv_fwd", (0, float("nan")))
-        dx_calls, dx_ms = ksum.get("textcnn_bwd_dtable", (0, float("nan")))
         flops = conv_fwd_flops(cfg)
         masks = torch.cat([args[2], args[3]])
-        act_frac = active_tile_fraction(cfg, masks)
-        dense_mode = os.environ.get("RBR_CONV_MODE") == "dense"
+        dense_mode = "textcnn_conv_fwd" in ksum
         out = {
             "metric": "(user,item) pairs/sec, DeepCoNN train step (fwd+MSE+bwd+clip+Adam), bsz256 2x512tok",
             "value": round(pairs / elapsed, 1), "unit": "pairs/s",
@@ -240,11 +259,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
+            "kernel_timing": ("HIP events around the C-ABI launches, eager pass over the same steps after the timed region"
+                              if use_graph else "HIP events around the C-ABI launches inside the timed region"),
         }
         if dense_mode:
+            conv_calls, conv_ms = ksum["textcnn_conv_fwd"]
+            act_frac = active_tile_fraction(cfg, masks)
             ach = flops / (conv_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "kernel": "conv_fwd_kernel (dense: gather+conv+max-pool, v_mfma_f32_32x32x2_f32)",
@@ -257,26 +280,29 @@ def main():
                 "executed_tile_fraction": round(act_frac, 4), "executed_achieved": round(ach * act_frac, 2),
                 "executed_frac": round(ach * act_frac / PEAK_F32_MFMA_TFLOPS, 4)}
         else:
-            # default build: the conv runs in its token-product form (a 9x smaller contraction), so the longest kernel
-            # of the step is the embedding-gradient scatter.  Algorithmic bytes = the dense table-gradient
-            # read-modify-write of embedding_dense_backward: 2 * (2 docs * L * D * 4 B) per pair.
-            dx_bytes = cfg["B"] * 2.0 * (2 * cfg["L"] * cfg["D"] * 4)
-            gbs = dx_bytes / (dx_ms * 1e-3) / 1e9
+            # default build: the conv runs in its token-product form.  Its contraction -- one launch of the MFMA
+            # kernel over the DISTINCT tokens of the batch -- is the longest kernel of the step.  Algorithmic FLOPs of
+            # that formulation: 2 * distinct tokens * D * sum(kz * channels)  (DESIGN.md section 4).
+            gemm_calls, gemm_ms = ksum["textcnn_prod_table"]
             ids_all = torch.cat([args[0], args[1]])
             n_distinct = int(torch.unique(ids_all[masks]).numel())
-            cp = ((sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"]) + 159) // 160) * 160
+            cp = sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"])
             gemm_flops = 2.0 * n_distinct * cfg["D"] * cp
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            conv_ms = sum(ksum[k][1] for k in ("textcnn_prod_prepare", "textcnn_prod_table", "textcnn_prod_pool"))
             out["roofline"] = {
-                "bound": "hbm", "kernel": "dx_window_kernel (token-folded embedding-gradient scatter, f32 atomics)",
-                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                "traffic": measured_traffic("r01_dx_window_pmc.json"),
-                "traffic_source": "profiles/r01_dx_window_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                "bytes_per_launch": dx_bytes, "avg_launch_ms": round(dx_ms, 4), "launches_timed": dx_calls,
-                "note": "dominant kernel of the default (token-product) step; RBR_CONV_MODE=dense prices the dense MFMA conv"}
+                "bound": "mfma", "kernel": "conv_fwd_kernel<5,60> in store mode: T = table[distinct tokens] @ Wprod "
+                                           "(v_mfma_f32_32x32x2_f32, rows gathered by LDS-DMA)",
+                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic("r01_prod_table_pmc.json"),
+                "traffic_source": "profiles/r01_prod_table_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                "flops_per_launch": gemm_flops, "avg_launch_ms": round(gemm_ms, 4), "launches_timed": gemm_calls,
+                "distinct_tokens": n_distinct, "positions": int(masks.numel()),
+                "note": "longest kernel of the default (token-product) step; the dense conv it replaces is "
+                        f"{flops / 1e9:.1f} GFLOP per launch (RBR_CONV_MODE=dense prices that kernel)"}
             out["conv_stage"] = {
                 "formulation": "token-product: T = table[distinct tokens] @ W (f32 MFMA), then gather-add + max-pool",
-                "ms": round(conv_ms, 4), "distinct_tokens": n_distinct, "positions": int(masks.numel()),
-                "mfma_flops_executed": gemm_flops, "dense_conv_flops_replaced": flops,
+                "ms": round(conv_ms, 4), "dense_conv_flops_replaced": flops,
                 "dense_equivalent_TFLOPs": round(flops / (conv_ms * 1e-3) / 1e12, 1)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)

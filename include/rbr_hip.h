@@ -88,6 +88,17 @@ int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const ui
                          const float* table, const float* const* W, const float* packed, float* pval, int32_t* pidx,
                          void* ws, void* stream);
 
+/* The three stages rbr_textcnn_conv_fwd runs for the product formulation, callable separately (same `ws`):
+ *   prepare: distinct unmasked tokens of ids -> list / inverse map, product weight image, work list;
+ *   table  : ONE kernel, T = table[distinct tokens] @ Wprod on the f32 MFMA pipe;
+ *   pool   : per 32-token slab, add the kz rows of T per position (x gate), max / first argmax -> pval / pidx.
+ * They fail with RBR_ERR_UNSUPPORTED when rbr_textcnn_fwd_ws_bytes(d) == 0. */
+int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
+                             void* ws, void* stream);
+int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream);
+int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                          float* pval, int32_t* pidx, void* ws, void* stream);
+
 /* Stage 3: reduce the slabs of each document, add the conv bias, apply the activation.
  * feat[n_docs, C] (C = sum ch[w]); argmax[n_docs, C] = first position attaining the max.
  * `bias` is a HOST array of device pointers (one [ch[w]] vector per width). */
@@ -111,6 +122,16 @@ int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint
 int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                            const float* table, const float* packed, const float* feat, const int32_t* argmax,
                            const float* d_feat, float* dtable, float* dgate, void* stream);
+/* Table gradient through the token-product formulation (same maths as rbr_textcnn_bwd_dtable with gate == NULL):
+ * G[token][tap, channel] = sum of g over the argmax windows touching that token, for the DISTINCT tokens the
+ * forward listed in `fwd_ws` (the workspace rbr_textcnn_conv_fwd was given for the SAME ids/mask, still intact),
+ * then dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product (G is ~2 % dense); each listed row of
+ * `dtable` is written once with plain stores, all other rows are left untouched (the caller zero-fills dtable).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
+ * bytes (0 = formulation not applicable: use rbr_textcnn_bwd_dtable; env RBR_DTABLE_MODE=scatter forces that). */
+size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
+int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
+                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                float* dtable, void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                     const float* table, const float* packed, const float* feat, const int32_t* argmax,
                     const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,

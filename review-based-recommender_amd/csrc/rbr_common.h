@@ -58,6 +58,11 @@ struct MutPtrArray {
     float* p[RBR_MAX_WIDTHS];
 };
 
+// g = d_feat * act'(feat): gradient entering the conv output at the max-pool's argmax
+__device__ __forceinline__ float act_grad(int act, float f, float d) {
+    return (act == RBR_ACT_RELU) ? (f > 0.f ? d : 0.f) : d * (1.f - f * f);
+}
+
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
@@ -69,9 +74,8 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */);
 int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, const unsigned char* mask, const float* gate,
                     const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st);
 // Token-product forward (textcnn_prod.hip): returns 1 when it produced pval/pidx, 0 when the dense conv must run.
-int run_token_product(const rbr_textcnn_desc* d, const ConvPlan* plans, int ngroups, const long long* ids,
-                      const unsigned char* mask, const float* gate, const float* table, const float* const* W, float* pval,
-                      int* pidx, const int* sched, void* ws, hipStream_t st);
+int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const unsigned char* mask, const float* gate,
+                      const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st);
 // Zeroes the counters of `sched` and builds flags | work list | counter for the documents of `p`.
 int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st);
 

@@ -30,10 +30,6 @@ constexpr int kDocsPerBatch = 32;
 constexpr int kMaxChunksBwd = 32;
 constexpr int kChanBatch = 128;   // channels resolved per LDS batch in dx_scatter
 
-__device__ __forceinline__ float act_grad(int act, float f, float d) {
-    return (act == RBR_ACT_RELU) ? (f > 0.f ? d : 0.f) : d * (1.f - f * f);
-}
-
 struct BwdArgs {
     int n_docs, L, D, C, KF, DC, nchunks, tiles_total;
     int pad_mode, act, padding_idx;

@@ -514,11 +514,11 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
-    if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
     if (ws != nullptr && W != nullptr) {
-        const int r = run_token_product(d, plans, ng, ids64, mask, gate, table, W, pval, pidx, sched, ws, st);
+        const int r = run_token_product(d, ids64, mask, gate, table, W, pval, pidx, ws, st);
         if (r != 0) return r == 1 ? 0 : r;
     }
+    if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
     return run_conv_groups(plans, ng, ids64, mask, gate, table, packed, pval, pidx, sched, st);
 }
 

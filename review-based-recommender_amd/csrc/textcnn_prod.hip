@@ -167,6 +167,141 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
     }
 }
 
+// ---------------------------------------------------------------------------------- backward: dtable = G @ Wprod^T
+// The table gradient of the max-pooled conv (textcnn_bwd.hip) is  dtable[t, :] = sum_{(w,j,cl)} G[t][(w,j,cl)] * W_w[cl, :, j]
+// with G[t][(w,j,cl)] = sum of g = d_feat * act'(feat) over the (doc, channel) windows whose tap j sits on token t.
+// G has one row per DISTINCT token (the forward's list).  Building it costs one scalar atomic per (doc, channel, tap)
+// and MERGES repeated (token, tap, channel) hits, so a Zipf-hot token costs at most sum(kz*ch) weight rows however
+// often it occurs.  G is ~2 % dense: each wave compacts the non-zeros of one row into LDS and adds the matching
+// rows of Wprod^T (900 KB, L2-resident) in registers, then writes the table row ONCE with plain stores -- instead of
+// ~6.5 rows of f32 atomics per token in the window scatter.
+struct ProdBwdArgs {
+    int n_docs, L, C, KF, KG, D, cap, padding_idx, pad_mode, act;
+    int n_widths;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G) {
+    const long n = (long)min(*counter, cap) * KG4;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// one thread per (doc, channel, tap)
+__global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const long long* __restrict__ ids,
+                                                      const unsigned char* __restrict__ mask, const int* __restrict__ row_of_token,
+                                                      const float* __restrict__ feat, const int* __restrict__ argmax,
+                                                      const float* __restrict__ d_feat, float* __restrict__ G) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long o = e / A.KF;
+    const int j = (int)(e - o * A.KF);
+    if (o >= (long)A.n_docs * A.C) return;
+    const int doc = (int)(o / A.C), c = (int)(o - (long)doc * A.C);
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < A.n_widths && c >= A.ch_off[k]) w = k;
+    const int kz = A.kz[w];
+    if (j >= kz) return;
+    const float g = act_grad(A.act, feat[o], d_feat[o]);
+    if (g == 0.f) return;
+    const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
+    const int p = argmax[o] + j - padl;
+    if (p < 0 || p >= A.L) return;
+    const long tok = (long)doc * A.L + p;
+    if (mask != nullptr && !mask[tok]) return;          // masked token: x was zeroed, no gradient
+    const long long t = ids[tok];
+    if (t == A.padding_idx) return;                     // nn.Embedding(padding_idx): that row gets no gradient
+    const int row = row_of_token[t];
+    if (row >= 0) atomicAdd(G + (long)row * A.KG + A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]), g);
+}
+
+// WT[(w, j, cl)][d] = W_w[cl, d, j]: the rows the sparse product adds up
+__global__ __launch_bounds__(256) void pack_wrows_kernel(const ProdBwdArgs A, int cp_real, const PtrArray W, float* __restrict__ WT) {
+    const long total = (long)cp_real * A.D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pc = (int)(idx / A.D), d = (int)(idx - (long)pc * A.D);
+        int w = 0;
+#pragma unroll
+        for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+            if (k < A.n_widths && pc >= A.poff[k]) w = k;
+        const int rel = pc - A.poff[w];
+        const int j = rel / A.ch[w], cl = rel - j * A.ch[w];
+        WT[idx] = W.p[w][((long)cl * A.D + d) * A.kz[w] + j];
+    }
+}
+
+constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of the table row
+
+// one wave per distinct-token row (grid-stride).  Dynamic LDS: per wave KG (int column, float value) pairs.
+__global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int* __restrict__ counter,
+                                                        const float* __restrict__ G, const float* __restrict__ WT,
+                                                        const long long* __restrict__ tok_of_row, float* __restrict__ dtable) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int* s_pc = s_dyn + wave * 2 * A.KG;
+    float* s_val = reinterpret_cast<float*>(s_pc + A.KG);
+    const int n = min(*counter, A.cap);
+    const int D = A.D, nq4 = D >> 2;
+    const unsigned long long lt = (1ull << lane) - 1;
+    for (int row = blockIdx.x * kWavesPerWG + wave; row < n; row += gridDim.x * kWavesPerWG) {
+        // 1. non-zeros of the row -> (column, value) list, in column-block order
+        const float* grow = G + (long)row * A.KG;
+        int cnt = 0;
+        for (int k0 = 0; k0 < A.KG; k0 += 256) {
+            const int k = k0 + 4 * lane;
+            const f32x4 v = (k < A.KG) ? *reinterpret_cast<const f32x4*>(grow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cpt = 0; cpt < 4; ++cpt) {
+                const bool nz = v[cpt] != 0.f;
+                const unsigned long long b = __ballot(nz);
+                if (nz) {
+                    const int pos = cnt + __popcll(b & lt);
+                    s_pc[pos] = (k + cpt) * D;
+                    s_val[pos] = v[cpt];
+                }
+                cnt += __popcll(b);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 2. dtable row = sum val * WT[column, :]   (4 weight rows in flight)
+        const long trow = (long)tok_of_row[row] * D;
+        for (int qblk = 0; qblk < nq4; qblk += 64 * kSpQ4) {
+            f32x4 sum[kSpQ4];
+            int doff[kSpQ4];
+#pragma unroll
+            for (int u = 0; u < kSpQ4; ++u) {
+                const int q4 = qblk + lane + 64 * u;
+                doff[u] = (q4 < nq4) ? 4 * q4 : -1;
+                sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int q0 = 0; q0 < cnt; q0 += 4) {
+                f32x4 wv[4][kSpQ4];
+                float gv[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool ok = q0 + v < cnt;
+                    const int it = ok ? q0 + v : q0;
+                    const float* wrow = WT + s_pc[it];
+                    gv[v] = ok ? s_val[it] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < kSpQ4; ++u)
+                        wv[v][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int u = 0; u < kSpQ4; ++u) sum[u] += gv[v] * wv[v][u];
+            }
+#pragma unroll
+            for (int u = 0; u < kSpQ4; ++u)
+                if (doff[u] >= 0) *reinterpret_cast<f32x4*>(dtable + trow + doff[u]) = sum[u];
+        }
+        __builtin_amdgcn_wave_barrier();      // the list is rewritten for the next row
+    }
+}
+
 }  // namespace rbr
 
 using namespace rbr;
@@ -240,66 +375,196 @@ extern "C" size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d) {
     return Lo.total;
 }
 
-namespace rbr {
+namespace {
 
-// returns 1 when the product path ran, 0 when the caller must run the dense conv, < 0 / hip error on failure
-int run_token_product(const rbr_textcnn_desc* d, const ConvPlan* plans, int ngroups, const long long* ids,
-                      const unsigned char* mask, const float* gate, const float* table, const float* const* W, float* pval,
-                      int* pidx, const int* sched, void* ws, hipStream_t st) {
-    if (ws == nullptr || !prod_applicable(d)) return 0;
+struct ProdBwdLayout {
+    size_t WT, G, total;
+    int KG, cp_real;
+};
+
+bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLayout& B) {
+    if (d->D % 4 != 0) return false;                        // float4 rows; other widths keep the window scatter
+    long cp = 0;
+    for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
+    B.cp_real = (int)cp;
+    B.KG = (int)((cp + 3) / 4 * 4);
+    if ((size_t)B.KG * 8 * kWavesPerWG > 60 * 1024) return false;   // per-wave non-zero list must fit in LDS
+    size_t o = 0;
+    B.WT = o; o += align256((size_t)cp * d->D * sizeof(float));
+    B.G = o;  o += align256((size_t)Lo.cap * B.KG * sizeof(float));
+    B.total = o;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return 0;
+    if (!prod_applicable(d)) return 0;
+    static const char* env = getenv("RBR_DTABLE_MODE");
+    if (env && !strcmp(env, "scatter")) return 0;
     ProdLayout Lo;
-    if (!prod_layout(d, Lo)) return RBR_ERR_BAD_ARG;
-    char* base = static_cast<char*>(ws);
-    int* used = reinterpret_cast<int*>(base + Lo.used);
-    int* row_of_token = reinterpret_cast<int*>(base + Lo.row_of_token);
-    long long* tok_of_row = reinterpret_cast<long long*>(base + Lo.tok_of_row);
-    unsigned char* row_mask = reinterpret_cast<unsigned char*>(base + Lo.row_mask);
-    int* counter = reinterpret_cast<int*>(base + Lo.counter);
-    int* sched_p = reinterpret_cast<int*>(base + Lo.sched);
-    float* packed_p = reinterpret_cast<float*>(base + Lo.packed);
-    float* T = reinterpret_cast<float*>(base + Lo.table_T);
+    ProdBwdLayout B;
+    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return 0;
+    return B.total;
+}
 
-    ConvPlan pp[kMaxGroups];
-    const int ngp = build_plans(&Lo.dp, pp);
-    if (!ngp) return RBR_ERR_BAD_ARG;
-    pp[0].store_rows = 1;      // group 0's plan describes every group; the kernel folds them into one launch
-    (void)ngp;
+extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
+                                           const float* const* W, const float* feat, const int32_t* argmax,
+                                           const float* d_feat, void* fwd_ws, void* bwd_ws, float* dtable, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (!ids || !W || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    ProdLayout Lo;
+    ProdBwdLayout B;
+    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* fbase = static_cast<char*>(fwd_ws);
+    const int* row_of_token = reinterpret_cast<const int*>(fbase + Lo.row_of_token);
+    const long long* tok_of_row = reinterpret_cast<const long long*>(fbase + Lo.tok_of_row);
+    const int* counter = reinterpret_cast<const int*>(fbase + Lo.counter);
+    char* bbase = static_cast<char*>(bwd_ws);
+    float* WT = reinterpret_cast<float*>(bbase + B.WT);
+    float* G = reinterpret_cast<float*>(bbase + B.G);
 
-    ProdArgs A{};
-    A.n_docs = d->n_docs; A.L = d->L; A.V = d->V; A.cap = Lo.cap; A.zrow = Lo.cap; A.pitch = pp[0].nslots_total;
-    {   // product channels follow the plan's bank order of the ORIGINAL problem (bank w, tap j, channel cl)
-        int o = 0;
-        for (int w = 0; w < d->n_widths; ++w) { A.poff[w] = o; o += d->kz[w] * d->ch[w]; }
-        A.cp_real = o;
+    ProdBwdArgs A{};
+    A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.KG = B.KG; A.D = d->D; A.cap = Lo.cap;
+    A.padding_idx = d->padding_idx; A.pad_mode = d->pad_mode; A.act = d->act; A.n_widths = d->n_widths;
+    int cp_real = 0;
+    for (int w = 0; w < d->n_widths; ++w) {
+        A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
+        A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
     }
-    // 1. distinct tokens  (used / row_mask / counter / zero row are re-initialised every call: graph-replay safe)
-    if (int e = check_hip(hipMemsetAsync(base + Lo.used, 0, Lo.row_of_token - Lo.used, st), "token-list state memset")) return e;
-    const long n_tok = (long)d->n_docs * d->L;
-    hipLaunchKernelGGL(mark_tokens_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, n_tok,
-                       ids, mask, used);
-    RBR_CHECK_LAUNCH("textcnn mark_tokens launch");
-    hipLaunchKernelGGL(compact_tokens_kernel, dim3((d->V + 255) / 256), dim3(256), 0, st, d->V, Lo.cap, used, row_of_token,
-                       tok_of_row, row_mask, counter, T + (size_t)Lo.cap * A.pitch, A.pitch);
-    RBR_CHECK_LAUNCH("textcnn compact_tokens launch");
-    // 2. product weights
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
     {
-        const long total = (long)pp[0].nchunks * pp[0].tiles_total * kTile * pp[0].DC;
-        hipLaunchKernelGGL(pack_prod_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, pp[0],
-                           plans[0], A, wp, packed_p);
-        RBR_CHECK_LAUNCH("textcnn pack_prod launch");
+        const long total = (long)cp_real * d->D;
+        hipLaunchKernelGGL(pack_wrows_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, A, cp_real,
+                           wp, WT);
+        RBR_CHECK_LAUNCH("textcnn pack_wrows launch");
     }
-    // 3. T = table[tok_of_row] @ Wprod  (rows beyond the distinct count are masked -> their tiles are skipped)
-    if (int e = scan_tiles(pp[0], row_mask, sched_p, st)) return e;
-    if (int e = run_conv_groups(pp, 1, tok_of_row, row_mask, nullptr, table, packed_p, T, nullptr, sched_p, st)) return e;
-    // 4. gather + pool per active wave-tile of the real documents
+    hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
+    RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+    const long n_items = (long)d->n_docs * A.C * A.KF;
+    hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
+                       reinterpret_cast<const long long*>(ids), mask, row_of_token, feat, argmax, d_feat, G);
+    RBR_CHECK_LAUNCH("textcnn build_g launch");
+    const int rows_cap = (Lo.cap + kWavesPerWG - 1) / kWavesPerWG;
+    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(rows_cap, 4096)), dim3(256), (size_t)B.KG * 8 * kWavesPerWG, st, A,
+                       counter, G, WT, tok_of_row, dtable);
+    RBR_CHECK_LAUNCH("textcnn g_times_w launch");
+    return 0;
+}
+
+namespace {
+
+struct ProdState {       // everything the three forward stages share, derived from (d, ws) alone
+    ProdLayout Lo;
+    ConvPlan pp[kMaxGroups];
+    ProdArgs A;
+    int *used, *row_of_token, *counter, *sched_p;
+    long long* tok_of_row;
+    unsigned char* row_mask;
+    float *packed_p, *T;
+    char* base;
+};
+
+int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
+    if (ws == nullptr) { set_error("null workspace"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    if (!prod_layout(d, S.Lo)) return RBR_ERR_BAD_ARG;
+    const ProdLayout& Lo = S.Lo;
+    S.base = static_cast<char*>(ws);
+    S.used = reinterpret_cast<int*>(S.base + Lo.used);
+    S.row_of_token = reinterpret_cast<int*>(S.base + Lo.row_of_token);
+    S.tok_of_row = reinterpret_cast<long long*>(S.base + Lo.tok_of_row);
+    S.row_mask = reinterpret_cast<unsigned char*>(S.base + Lo.row_mask);
+    S.counter = reinterpret_cast<int*>(S.base + Lo.counter);
+    S.sched_p = reinterpret_cast<int*>(S.base + Lo.sched);
+    S.packed_p = reinterpret_cast<float*>(S.base + Lo.packed);
+    S.T = reinterpret_cast<float*>(S.base + Lo.table_T);
+    if (!build_plans(&S.Lo.dp, S.pp)) return RBR_ERR_BAD_ARG;
+    S.pp[0].store_rows = 1;      // group 0's plan describes every group; the kernel folds them into one launch
+    ProdArgs A{};
+    A.n_docs = d->n_docs; A.L = d->L; A.V = d->V; A.cap = Lo.cap; A.zrow = Lo.cap; A.pitch = S.pp[0].nslots_total;
+    int o = 0;    // product channels follow the bank order of the ORIGINAL problem (bank w, tap j, channel cl)
+    for (int w = 0; w < d->n_widths; ++w) { A.poff[w] = o; o += d->kz[w] * d->ch[w]; }
+    A.cp_real = o;
+    S.A = A;
+    return 0;
+}
+
+}  // namespace
+
+// Stage 1: distinct-token list of the batch, product weight image, work list of the token pseudo-document.
+extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
+                                        const float* const* W, void* ws, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (!ids || !W) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    ProdState S;
+    if (int e = prod_state(d, ws, S)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    // used / row_mask / counter / zero row are re-initialised every call: graph-replay safe
+    if (int e = check_hip(hipMemsetAsync(S.base + S.Lo.used, 0, S.Lo.row_of_token - S.Lo.used, st), "token-list state memset")) return e;
+    const long n_tok = (long)d->n_docs * d->L;
+    hipLaunchKernelGGL(mark_tokens_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, n_tok,
+                       reinterpret_cast<const long long*>(ids), mask, S.used);
+    RBR_CHECK_LAUNCH("textcnn mark_tokens launch");
+    hipLaunchKernelGGL(compact_tokens_kernel, dim3((d->V + 255) / 256), dim3(256), 0, st, d->V, S.Lo.cap, S.used, S.row_of_token,
+                       S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch);
+    RBR_CHECK_LAUNCH("textcnn compact_tokens launch");
+    PtrArray wp{};
+    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
+    const long total = (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC;
+    hipLaunchKernelGGL(pack_prod_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, S.pp[0],
+                       plans[0], S.A, wp, S.packed_p);
+    RBR_CHECK_LAUNCH("textcnn pack_prod launch");
+    // rows beyond the distinct count are masked -> their tiles are skipped
+    return scan_tiles(S.pp[0], S.row_mask, S.sched_p, st);
+}
+
+// Stage 2 (one kernel): T = table[tok_of_row] @ Wprod on the f32 MFMA pipe.
+extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream) {
+    if (!table) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    ProdState S;
+    if (int e = prod_state(d, ws, S)) return e;
+    return run_conv_groups(S.pp, 1, S.tok_of_row, S.row_mask, nullptr, table, S.packed_p, S.T, nullptr, S.sched_p, (hipStream_t)stream);
+}
+
+// Stage 3: per active wave-tile of the real documents, add the kz rows of T per position, max / first argmax.
+extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                     float* pval, int32_t* pidx, void* ws, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    const int ngroups = build_plans(d, plans);
+    if (!ngroups) return RBR_ERR_BAD_ARG;
+    if (!ids || !pval || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    ProdState S;
+    if (int e = prod_state(d, ws, S)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
+    if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
     for (int g = 0; g < ngroups; ++g) {
-        hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[g], A, ids, mask, gate, row_of_token, T,
-                           sched, pval, pidx);
+        hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[g], S.A,
+                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
         RBR_CHECK_LAUNCH("textcnn gather_pool launch");
     }
+    return 0;
+}
+
+namespace rbr {
+
+// returns 1 when the product path ran, 0 when the caller must run the dense conv, < 0 / hip error on failure
+int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const unsigned char* mask, const float* gate,
+                      const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st) {
+    if (ws == nullptr || !prod_applicable(d)) return 0;
+    const int64_t* ids64 = reinterpret_cast<const int64_t*>(ids);
+    if (int e = rbr_textcnn_prod_prepare(d, ids64, mask, W, ws, st)) return e;
+    if (int e = rbr_textcnn_prod_table(d, table, ws, st)) return e;
+    if (int e = rbr_textcnn_prod_pool(d, ids64, mask, gate, pval, pidx, ws, st)) return e;
     return 1;
 }
 

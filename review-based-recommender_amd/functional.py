@@ -66,14 +66,34 @@ class _TextCNN(torch.autograd.Function):
               "rbr_textcnn_pack")
         ws_bytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))      # > 0: the token-product formulation will run
         prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        ev = TIMER.record("textcnn_conv_fwd")
-        check(L_.rbr_textcnn_conv_fwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                      dev_ptr(gate, F32, "gate"), dev_ptr(table_c, F32, "word table"),
-                                      ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"),
-                                      dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
-                                      prod_ws.data_ptr() if prod_ws is not None else None, st), "rbr_textcnn_conv_fwd")
-        if ev is not None:
-            ev.record()
+        if prod_ws is not None:
+            # token-product formulation, stage by stage (each stage is what rbr_textcnn_conv_fwd would run)
+            wsp = prod_ws.data_ptr()
+            ev = TIMER.record("textcnn_prod_prepare")
+            check(L_.rbr_textcnn_prod_prepare(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                              ptr_array(ws, F32, "conv weight"), wsp, st), "rbr_textcnn_prod_prepare")
+            if ev is not None:
+                ev.record()
+            ev = TIMER.record("textcnn_prod_table")
+            check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st),
+                  "rbr_textcnn_prod_table")
+            if ev is not None:
+                ev.record()
+            ev = TIMER.record("textcnn_prod_pool")
+            check(L_.rbr_textcnn_prod_pool(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                           dev_ptr(gate, F32, "gate"), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
+                                           wsp, st), "rbr_textcnn_prod_pool")
+            if ev is not None:
+                ev.record()
+        else:
+            ev = TIMER.record("textcnn_conv_fwd")
+            check(L_.rbr_textcnn_conv_fwd(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                          dev_ptr(gate, F32, "gate"), dev_ptr(table_c, F32, "word table"),
+                                          ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"),
+                                          dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), None, st),
+                  "rbr_textcnn_conv_fwd")
+            if ev is not None:
+                ev.record()
         check(L_.rbr_textcnn_pool_finalize(C.byref(desc), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
                                            ptr_array(bs, F32, "conv bias"), dev_ptr(feat, F32, "feat"),
                                            dev_ptr(argmax, I32, "argmax"), st), "rbr_textcnn_pool_finalize")
@@ -81,6 +101,7 @@ class _TextCNN(torch.autograd.Function):
         ctx.n = n
         ctx.has_gate = gate is not None
         ctx.has_mask = mask8 is not None
+        ctx.prod_ws = prod_ws          # distinct-token list of the batch, reused by the table-gradient GEMM
         ctx.save_for_backward(table_c, ids, packed, feat, argmax, *([mask8] if mask8 is not None else []),
                               *([gate] if gate is not None else []), *ws)
         ctx.mark_non_differentiable(argmax)
@@ -120,6 +141,19 @@ class _TextCNN(torch.autograd.Function):
         if ev is not None:
             ev.record()
         ev = TIMER.record("textcnn_bwd_dtable")
+        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if (ctx.prod_ws is not None and gate is None) else 0
+        if need_table and bws_bytes:
+            # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
+            # table); the gated variant (D-ATT) also needs d(gate) and keeps the scatter kernel
+            bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+            check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                 ptr_array(ws, F32, "conv weight"), dev_ptr(feat, F32, "feat"),
+                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"), st),
+                  "rbr_textcnn_bwd_dtable_prod")
+            if ev is not None:
+                ev.record()
+            return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         check(L_.rbr_textcnn_bwd_dtable(*common, dev_ptr(packed, F32, "packed"), dev_ptr(feat, F32, "feat"),
                                         dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
                                         dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st),
