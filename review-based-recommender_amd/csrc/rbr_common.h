@@ -76,6 +76,8 @@ int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, co
 // Token-product forward (textcnn_prod.hip): returns 1 when it produced pval/pidx, 0 when the dense conv must run.
 int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const unsigned char* mask, const float* gate,
                       const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st);
+// Zero-fills `bytes` (a multiple of 4) at the 4-byte aligned `p` with a kernel.
+int zero_words(void* p, size_t bytes, hipStream_t st);
 // Zeroes the counters of `sched` and builds flags | work list | counter for the documents of `p`.
 int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st);
 

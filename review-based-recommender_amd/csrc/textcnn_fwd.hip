@@ -524,9 +524,22 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
 
 namespace rbr {
 
+__global__ __launch_bounds__(256) void zero_words_kernel(int* __restrict__ p, long n) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) p[k] = 0;
+}
+
+// A kernel, not hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and
+// stays a chain of plain kernel nodes.
+int zero_words(void* p, size_t bytes, hipStream_t st) {
+    const long n = (long)(bytes / sizeof(int));
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st,
+                       static_cast<int*>(p), n);
+    RBR_CHECK_LAUNCH("zero_words launch");
+    return 0;
+}
+
 int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st) {
-    if (int e = check_hip(hipMemsetAsync(sched + 2 * (size_t)p.total_wt, 0, kSchedCounters * sizeof(int), st), "work-list counter memset"))
-        return e;
+    if (int e = zero_words(sched + 2 * (size_t)p.total_wt, kSchedCounters * sizeof(int), st)) return e;
     hipLaunchKernelGGL(tile_scan_kernel, dim3((p.total_wt + 255) / 256), dim3(256), 0, st, p, mask, sched);
     RBR_CHECK_LAUNCH("textcnn tile_scan launch");
     return 0;

@@ -508,7 +508,7 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
     if (int e = prod_state(d, ws, S)) return e;
     hipStream_t st = (hipStream_t)stream;
     // used / row_mask / counter / zero row are re-initialised every call: graph-replay safe
-    if (int e = check_hip(hipMemsetAsync(S.base + S.Lo.used, 0, S.Lo.row_of_token - S.Lo.used, st), "token-list state memset")) return e;
+    if (int e = zero_words(S.base + S.Lo.used, S.Lo.row_of_token - S.Lo.used, st)) return e;
     const long n_tok = (long)d->n_docs * d->L;
     hipLaunchKernelGGL(mark_tokens_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, n_tok,
                        reinterpret_cast<const long long*>(ids), mask, S.used);
