@@ -12,8 +12,8 @@ fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the referenc
 [N>1: RCCL gradient all-reduce] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
 HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
 
-The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed; every timed step first copies
-its batch into the graph's input buffers.  `--no-graph` launches the kernels one by one from Python instead.
+The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed on the batch resident in the
+graph's input buffers.  `--no-graph` launches the kernels one by one from Python instead.
 
 Rank 0 prints ONE JSON line.  `value` = pairs/s over all ranks of the full train step;
 `roofline` prices the longest kernel of the step -- by default the distinct-token GEMM of the token-product
@@ -204,7 +204,7 @@ def main():
         stepper = GraphedTrainStep(model, opt, args, ratings, grad_sync=grad_sync)
 
         def step():
-            stepper(args, ratings)      # batch copied into the graph's input buffers, then one replay
+            stepper()      # the batch is resident in the graph's input buffers (where a loader's H2D copy lands)
     else:
         def step():
             train_step(model, opt, args, ratings, grad_sync=grad_sync)

@@ -89,12 +89,14 @@ int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const ui
                          void* ws, void* stream);
 
 /* The three stages rbr_textcnn_conv_fwd runs for the product formulation, callable separately (same `ws`):
- *   prepare: distinct unmasked tokens of ids -> list / inverse map, product weight image, work list;
+ *   prepare: work list of the documents (tail of pidx), distinct unmasked tokens of ids -> list / inverse map,
+ *            product weight images (forward tile image and row-major Wprod^T for the backward);
  *   table  : ONE kernel, T = table[distinct tokens] @ Wprod on the f32 MFMA pipe;
- *   pool   : per 32-token slab, add the kz rows of T per position (x gate), max / first argmax -> pval / pidx.
+ *   pool   : ONE kernel, per 32-token slab add the kz rows of T per position (x gate), max / first argmax ->
+ *            pval / pidx (same pidx as prepare).
  * They fail with RBR_ERR_UNSUPPORTED when rbr_textcnn_fwd_ws_bytes(d) == 0. */
 int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
-                             void* ws, void* stream);
+                             int32_t* pidx, void* ws, void* stream);
 int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream);
 int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                           float* pval, int32_t* pidx, void* ws, void* stream);
@@ -129,9 +131,9 @@ int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const 
  * `dtable` is written once with plain stores, all other rows are left untouched (the caller zero-fills dtable).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
  * bytes (0 = formulation not applicable: use rbr_textcnn_bwd_dtable; env RBR_DTABLE_MODE=scatter forces that). */
 size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
-int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
-                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                                float* dtable, void* stream);
+int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* feat,
+                                const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws, float* dtable,
+                                void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                     const float* table, const float* packed, const float* feat, const int32_t* argmax,
                     const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,

@@ -66,7 +66,7 @@ SIGNATURES = {
     "rbr_set_conv_mode": (None, [i32]),
     "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, _PP, c_f32p, c_f32p, c_i32p, C.c_void_p,
                                        c_stream]),
-    "rbr_textcnn_prod_prepare": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, C.c_void_p, c_stream]),
+    "rbr_textcnn_prod_prepare": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p, c_stream]),
     "rbr_textcnn_prod_table": (C.c_int, [_DESC, c_f32p, C.c_void_p, c_stream]),
     "rbr_textcnn_prod_pool": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, C.c_void_p, c_stream]),
     "rbr_textcnn_pool_finalize": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, c_stream]),
@@ -76,7 +76,7 @@ SIGNATURES = {
     "rbr_textcnn_bwd_dtable": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p,
                                          c_f32p, c_stream]),
     "rbr_textcnn_bwd_prod_ws_bytes": (C.c_size_t, [_DESC]),
-    "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
+    "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
                                               c_f32p, c_stream]),
     "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,
                                   c_f32p, c_f32p, c_f32p, c_stream]),

@@ -76,8 +76,43 @@ int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, co
 // Token-product forward (textcnn_prod.hip): returns 1 when it produced pval/pidx, 0 when the dense conv must run.
 int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const unsigned char* mask, const float* gate,
                       const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st);
-// Zero-fills `bytes` (a multiple of 4) at the 4-byte aligned `p` with a kernel.
-int zero_words(void* p, size_t bytes, hipStream_t st);
+// Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not
+// hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and stays a chain of
+// plain kernel nodes (memset nodes of these shapes faulted on replay with ROCm 7.2).
+struct ZeroRegions {
+    int* p[3];
+    long n[3];      // words
+};
+int zero_regions(const ZeroRegions& r, hipStream_t st);
+inline int zero_words(void* p, size_t bytes, hipStream_t st) {
+    ZeroRegions r{{static_cast<int*>(p), nullptr, nullptr}, {(long)(bytes / sizeof(int)), 0, 0}};
+    return zero_regions(r, st);
+}
+
+// Work-list scan of 256 wave-tiles (block `blk` of the scan grid): flags[wt], and the active tiles appended to the
+// list in any order.  sched = flags[total_wt] | list[total_wt] | counters; the counters must be zero beforehand.
+__device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigned char* __restrict__ mask,
+                                                int* __restrict__ sched, int blk) {
+    const int wt = blk * 256 + threadIdx.x;
+    int act = 0;
+    if (wt < P.total_wt) {
+        act = 1;
+        if (mask != nullptr) {
+            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
+            const int lo = max(0, l0 - P.P), hi = min(P.L, l0 + kTile + P.KF - 1 - P.P);
+            act = 0;
+            for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
+            act = act ? 1 : 0;
+        }
+        sched[wt] = act;
+    }
+    const unsigned long long b = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(sched + 2 * (long)P.total_wt, __popcll(b));
+    base = __shfl(base, 0);
+    if (act) sched[(long)P.total_wt + base + __popcll(b & ((1ull << lane) - 1))] = wt;
+}
 // Zeroes the counters of `sched` and builds flags | work list | counter for the documents of `p`.
 int scan_tiles(const ConvPlan& p, const unsigned char* mask, int* sched, hipStream_t st);
 

@@ -71,25 +71,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const ConvPlan P, const PtrAr
 // (counter[0] = active tiles, counter[1 + g] = next work item of launch group g).
 __global__ __launch_bounds__(256) void tile_scan_kernel(const ConvPlan P, const unsigned char* __restrict__ mask,
                                                         int* __restrict__ sched) {
-    const int wt = blockIdx.x * 256 + threadIdx.x;
-    int act = 0;
-    if (wt < P.total_wt) {
-        act = 1;
-        if (mask != nullptr) {
-            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
-            const int lo = max(0, l0 - P.P), hi = min(P.L, l0 + kTile + P.KF - 1 - P.P);
-            act = 0;
-            for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
-            act = act ? 1 : 0;
-        }
-        sched[wt] = act;
-    }
-    const unsigned long long b = __ballot(act);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && b) base = atomicAdd(sched + 2 * (long)P.total_wt, __popcll(b));
-    base = __shfl(base, 0);
-    if (act) sched[(long)P.total_wt + base + __popcll(b & ((1ull << lane) - 1))] = wt;
+    tile_scan_block(P, mask, sched, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ conv
@@ -173,7 +155,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     int* s_item = reinterpret_cast<int*>(reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + kWavesPerWG * (kTile + kMaxKF));
     // store_rows launches fold all (identical) channel-tile groups into one grid: item -> (row item, group)
     const int ngroups_in_launch = P.store_rows ? P.tiles_total / P.ntiles : 1;
-    const int n_active = sched[2 * (long)P.total_wt];            // wave-tiles with at least one unmasked token
+    // wave-tiles with at least one unmasked token; store_rows: the slot holds the ROW count of the token list and
+    // the active tiles are simply the first ceil(rows / 32)
+    const int n_active = P.store_rows ? (sched[2 * (long)P.total_wt] + kTile - 1) / kTile : sched[2 * (long)P.total_wt];
     const int* worklist = sched + P.total_wt;
     const int nrow_items = (n_active + kWavesPerWG - 1) / kWavesPerWG;
     const int nitems = nrow_items * ngroups_in_launch;
@@ -199,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const float* wbase = packed + (long)tile_base * TILE_F;
     const int slot_in_list = (item - grp * nrow_items) * kWavesPerWG + wave;
     const bool active = slot_in_list < n_active;      // wave-uniform
-    const int wt = active ? worklist[slot_in_list] : 0;   // global wave-tile
+    const int wt = active ? (P.store_rows ? slot_in_list : worklist[slot_in_list]) : 0;   // global wave-tile
     const int doc = wt / P.wpd;
     const int l0 = (wt % P.wpd) * kTile;
 
@@ -524,17 +508,19 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
 
 namespace rbr {
 
-__global__ __launch_bounds__(256) void zero_words_kernel(int* __restrict__ p, long n) {
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) p[k] = 0;
+__global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions R) {
+    const long total = R.n[0] + R.n[1] + R.n[2];
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
+        if (k < R.n[0]) R.p[0][k] = 0;
+        else if (k < R.n[0] + R.n[1]) R.p[1][k - R.n[0]] = 0;
+        else R.p[2][k - R.n[0] - R.n[1]] = 0;
+    }
 }
 
-// A kernel, not hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and
-// stays a chain of plain kernel nodes.
-int zero_words(void* p, size_t bytes, hipStream_t st) {
-    const long n = (long)(bytes / sizeof(int));
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st,
-                       static_cast<int*>(p), n);
-    RBR_CHECK_LAUNCH("zero_words launch");
+int zero_regions(const ZeroRegions& r, hipStream_t st) {
+    const long n = r.n[0] + r.n[1] + r.n[2];
+    hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st, r);
+    RBR_CHECK_LAUNCH("zero_regions launch");
     return 0;
 }
 

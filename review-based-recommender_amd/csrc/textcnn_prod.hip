@@ -32,61 +32,84 @@ struct ProdArgs {
 };
 
 // ---------------------------------------------------------------------------------- distinct tokens
-__global__ __launch_bounds__(256) void mark_tokens_kernel(long n_tok, const long long* __restrict__ ids,
-                                                          const unsigned char* __restrict__ mask, int* __restrict__ used) {
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_tok; k += (long)gridDim.x * 256)
+// Launch 2 of the forward chain: blocks [0, nb_scan) build the work list of the REAL documents (which 32-token slabs
+// hold an unmasked token), the remaining blocks mark the tokens that occur.  Independent jobs, one launch.
+__global__ __launch_bounds__(256) void mark_scan_kernel(const ConvPlan P, int nb_scan, long n_tok, const long long* __restrict__ ids,
+                                                        const unsigned char* __restrict__ mask, int* __restrict__ sched,
+                                                        int* __restrict__ used) {
+    if ((int)blockIdx.x < nb_scan) {
+        tile_scan_block(P, mask, sched, blockIdx.x);
+        return;
+    }
+    const long nb = gridDim.x - nb_scan;
+    for (long k = (long)(blockIdx.x - nb_scan) * 256 + threadIdx.x; k < n_tok; k += nb * 256)
         if (mask == nullptr || mask[k]) used[ids[k]] = 1;      // benign race: everyone stores 1
 }
 
-// row_of_token[v] = dense row index (any order) or -1; tok_of_row / row_mask describe the pseudo-document
-__global__ __launch_bounds__(256) void compact_tokens_kernel(int V, int cap, const int* __restrict__ used,
-                                                             int* __restrict__ row_of_token, long long* __restrict__ tok_of_row,
-                                                             unsigned char* __restrict__ row_mask, int* __restrict__ counter,
-                                                             float* __restrict__ zero_row, int pitch) {
-    if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
-        for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    const int u = (v < V) ? used[v] : 0;
-    const unsigned long long b = __ballot(u);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
-    base = __shfl(base, 0);
-    if (v < V) {
-        int row = -1;
-        if (u) {
-            row = base + __popcll(b & ((1ull << lane) - 1));
-            if (row < cap) { tok_of_row[row] = v; row_mask[row] = 1; } else row = -1;   // cannot happen: cap >= distinct
-        }
-        row_of_token[v] = row;
-    }
+struct PackJob {        // weight images of the product formulation, both derived from the torch-layout conv weights
+    ConvPlan P;         // plan of the token pseudo-document (one kz = 1 bank of Cp channels): forward image [dc][tile][slot][dd]
+    int n_widths, D, cp_real;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
+};
+
+__device__ __forceinline__ float prod_weight(const PackJob& J, const PtrArray& W, int pc, int d) {
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < J.n_widths && pc >= J.poff[k]) w = k;
+    const int rel = pc - J.poff[w];
+    const int j = rel / J.ch[w], cl = rel - j * J.ch[w];
+    return W.p[w][((long)cl * J.D + d) * J.kz[w] + j];
 }
 
-// ---------------------------------------------------------------------------------- product weights
-// packed layout of the conv kernel for ONE bank of Cp channels with kz = 1:  [dc][tile][slot][dd]
-__global__ __launch_bounds__(256) void pack_prod_kernel(const ConvPlan P, const ConvPlan D0, const ProdArgs A, const PtrArray W,
-                                                        float* __restrict__ packed) {
-    const int DC = P.DC;
-    const long total = (long)P.nchunks * P.tiles_total * kTile * DC;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        long r = idx;
-        const int dd = (int)(r % DC); r /= DC;
-        const int slot = (int)(r % kTile); r /= kTile;
-        const int t = (int)(r % P.tiles_total);
-        const int dc = (int)(r / P.tiles_total);
-        const int pc = t * kTile + slot;          // product channel
-        const int d = dc * DC + dd;
-        float v = 0.f;
-        if (pc < A.cp_real && d < P.D) {
-            int w = 0;
-#pragma unroll
-            for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
-                if (k < D0.n_widths && pc >= A.poff[k]) w = k;
-            const int rel = pc - A.poff[w];
-            const int j = rel / D0.ch[w], cl = rel - j * D0.ch[w];
-            v = W.p[w][((long)cl * P.D + d) * D0.kz[w] + j];
+// Launch 3: blocks [0, nb_compact) turn the marks into the token list (row_of_token[v] = dense row or -1,
+// tok_of_row / row_mask describe the pseudo-document, *counter = rows); the remaining blocks write the product weight
+// image of the forward GEMM and the row-major Wprod^T the backward's sparse product reads.
+__global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int nb_compact, int V, int cap,
+                                                           const int* __restrict__ used, int* __restrict__ row_of_token,
+                                                           long long* __restrict__ tok_of_row, unsigned char* __restrict__ row_mask,
+                                                           int* __restrict__ counter, float* __restrict__ zero_row, int pitch,
+                                                           const PtrArray W, float* __restrict__ packed, float* __restrict__ WT) {
+    if ((int)blockIdx.x < nb_compact) {
+        if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
+            for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
+        const int v = blockIdx.x * 256 + threadIdx.x;
+        const int u = (v < V) ? used[v] : 0;
+        const unsigned long long b = __ballot(u);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
+        base = __shfl(base, 0);
+        if (v < V) {
+            int row = -1;
+            if (u) {
+                row = base + __popcll(b & ((1ull << lane) - 1));
+                if (row < cap) { tok_of_row[row] = v; row_mask[row] = 1; } else row = -1;   // cannot happen: cap >= distinct
+            }
+            row_of_token[v] = row;
         }
-        packed[idx] = v;
+        return;
+    }
+    const long nb = gridDim.x - nb_compact, b0 = blockIdx.x - nb_compact;
+    const ConvPlan& P = J.P;
+    const int DC = P.DC;
+    const long n_img = (long)P.nchunks * P.tiles_total * kTile * DC;
+    const long n_wt = (long)J.cp_real * J.D;
+    for (long idx = b0 * 256 + threadIdx.x; idx < n_img + n_wt; idx += nb * 256) {
+        if (idx < n_img) {
+            long r = idx;
+            const int dd = (int)(r % DC); r /= DC;
+            const int slot = (int)(r % kTile); r /= kTile;
+            const int t = (int)(r % P.tiles_total);
+            const int dc = (int)(r / P.tiles_total);
+            const int pc = t * kTile + slot;          // product channel
+            const int d = dc * DC + dd;
+            packed[idx] = (pc < J.cp_real && d < J.D) ? prod_weight(J, W, pc, d) : 0.f;
+        } else {
+            const long e = idx - n_img;
+            const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
+            WT[e] = prod_weight(J, W, pc, d);         // WT[(w, j, cl)][d] = W_w[cl, d, j]
+        }
     }
 }
 
@@ -217,41 +240,31 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
     if (row >= 0) atomicAdd(G + (long)row * A.KG + A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]), g);
 }
 
-// WT[(w, j, cl)][d] = W_w[cl, d, j]: the rows the sparse product adds up
-__global__ __launch_bounds__(256) void pack_wrows_kernel(const ProdBwdArgs A, int cp_real, const PtrArray W, float* __restrict__ WT) {
-    const long total = (long)cp_real * A.D;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int pc = (int)(idx / A.D), d = (int)(idx - (long)pc * A.D);
-        int w = 0;
-#pragma unroll
-        for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
-            if (k < A.n_widths && pc >= A.poff[k]) w = k;
-        const int rel = pc - A.poff[w];
-        const int j = rel / A.ch[w], cl = rel - j * A.ch[w];
-        WT[idx] = W.p[w][((long)cl * A.D + d) * A.kz[w] + j];
-    }
-}
-
 constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of the table row
 
-// one wave per distinct-token row (grid-stride).  Dynamic LDS: per wave KG (int column, float value) pairs.
-__global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int* __restrict__ counter,
+// One WORKGROUP per distinct-token row (grid-stride): wave w compacts and multiplies the w-th quarter of the row's
+// columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
+// non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
+// Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
+__global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* s_pc = s_dyn + wave * 2 * A.KG;
-    float* s_val = reinterpret_cast<float*>(s_pc + A.KG);
+    int* s_pc = s_dyn + wave * 2 * KGW;
+    float* s_val = reinterpret_cast<float*>(s_pc + KGW);
+    float* s_part = reinterpret_cast<float*>(s_dyn + kWavesPerWG * 2 * KGW);     // [4][D]
     const int n = min(*counter, A.cap);
     const int D = A.D, nq4 = D >> 2;
     const unsigned long long lt = (1ull << lane) - 1;
-    for (int row = blockIdx.x * kWavesPerWG + wave; row < n; row += gridDim.x * kWavesPerWG) {
-        // 1. non-zeros of the row -> (column, value) list, in column-block order
+    const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);      // this wave's columns (KGW % 4 == 0)
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
         const float* grow = G + (long)row * A.KG;
         int cnt = 0;
-        for (int k0 = 0; k0 < A.KG; k0 += 256) {
+        for (int k0 = kbeg; k0 < kend; k0 += 256) {
             const int k = k0 + 4 * lane;
-            const f32x4 v = (k < A.KG) ? *reinterpret_cast<const f32x4*>(grow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = (k < kend) ? *reinterpret_cast<const f32x4*>(grow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int cpt = 0; cpt < 4; ++cpt) {
                 const bool nz = v[cpt] != 0.f;
@@ -265,8 +278,7 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // 2. dtable row = sum val * WT[column, :]   (4 weight rows in flight)
-        const long trow = (long)tok_of_row[row] * D;
+        // 2. partial row = sum val * WT[column, :]   (4 weight rows in flight per wave)
         for (int qblk = 0; qblk < nq4; qblk += 64 * kSpQ4) {
             f32x4 sum[kSpQ4];
             int doff[kSpQ4];
@@ -296,9 +308,18 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             }
 #pragma unroll
             for (int u = 0; u < kSpQ4; ++u)
-                if (doff[u] >= 0) *reinterpret_cast<f32x4*>(dtable + trow + doff[u]) = sum[u];
+                if (doff[u] >= 0) *reinterpret_cast<f32x4*>(s_part + wave * D + doff[u]) = sum[u];
         }
-        __builtin_amdgcn_wave_barrier();      // the list is rewritten for the next row
+        __syncthreads();
+        // 3. the four partial rows, summed in wave order, written once
+        const long trow = (long)tok_of_row[row] * D;
+        for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(s_part + 4 * q4);
+#pragma unroll
+            for (int w = 1; w < kWavesPerWG; ++w) r += *reinterpret_cast<const f32x4*>(s_part + w * D + 4 * q4);
+            *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
+        }
+        __syncthreads();      // lists and partial rows are rewritten for the next row
     }
 }
 
@@ -309,7 +330,7 @@ using namespace rbr;
 namespace {
 
 struct ProdLayout {      // byte offsets inside the workspace
-    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, table_T, total;
+    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, table_T, total;
     int cap, Cp, tiles_p;
     rbr_textcnn_desc dp;
 };
@@ -349,14 +370,19 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     if (!build_plans(&Lo.dp, plans)) return false;
     const ConvPlan& p = plans[0];
     size_t o = 0;
-    // [used | row_mask | counter] are contiguous: ONE memset node re-initialises them every call
+    // [used | row_mask] are contiguous and re-zeroed every call together with the counters of `sched`
     Lo.used = o;         o += align256((size_t)d->V * sizeof(int));
     Lo.row_mask = o;     o += align256((size_t)Lo.cap);
-    Lo.counter = o;      o += 256;
     Lo.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
     Lo.tok_of_row = o;   o += align256((size_t)Lo.cap * sizeof(long long));
+    // flags | list (unused: the token list needs no scan) | counters.  counters[0] doubles as the distinct-token count:
+    // the MFMA kernel in store mode derives its active tiles from it
     Lo.sched = o;        o += align256((2 * (size_t)p.total_wt + kSchedCounters) * sizeof(int));
+    Lo.counter = Lo.sched + 2 * (size_t)p.total_wt * sizeof(int);
     Lo.packed = o;       o += align256((size_t)p.nchunks * p.tiles_total * kTile * p.DC * sizeof(float));
+    long cp_real = 0;
+    for (int w = 0; w < d->n_widths; ++w) cp_real += (long)d->kz[w] * d->ch[w];
+    Lo.wt = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
     Lo.table_T = o;      o += align256(((size_t)Lo.cap + 1) * p.nslots_total * sizeof(float));
     Lo.total = o;
     return true;
@@ -378,8 +404,8 @@ extern "C" size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d) {
 namespace {
 
 struct ProdBwdLayout {
-    size_t WT, G, total;
-    int KG, cp_real;
+    size_t G, total;
+    int KG, KGW, cp_real;
 };
 
 bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLayout& B) {
@@ -388,9 +414,9 @@ bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLay
     for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
     B.cp_real = (int)cp;
     B.KG = (int)((cp + 3) / 4 * 4);
-    if ((size_t)B.KG * 8 * kWavesPerWG > 60 * 1024) return false;   // per-wave non-zero list must fit in LDS
+    B.KGW = ((B.KG / 4 + kWavesPerWG - 1) / kWavesPerWG) * 4;      // columns per wave of the sparse product
+    if ((size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;   // lists + partial rows in LDS
     size_t o = 0;
-    B.WT = o; o += align256((size_t)cp * d->D * sizeof(float));
     B.G = o;  o += align256((size_t)Lo.cap * B.KG * sizeof(float));
     B.total = o;
     return true;
@@ -411,11 +437,11 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
 }
 
 extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
-                                           const float* const* W, const float* feat, const int32_t* argmax,
-                                           const float* d_feat, void* fwd_ws, void* bwd_ws, float* dtable, void* stream) {
+                                           const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
+                                           void* bwd_ws, float* dtable, void* stream) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
-    if (!ids || !W || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
     ProdLayout Lo;
     ProdBwdLayout B;
@@ -425,9 +451,8 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     const int* row_of_token = reinterpret_cast<const int*>(fbase + Lo.row_of_token);
     const long long* tok_of_row = reinterpret_cast<const long long*>(fbase + Lo.tok_of_row);
     const int* counter = reinterpret_cast<const int*>(fbase + Lo.counter);
-    char* bbase = static_cast<char*>(bwd_ws);
-    float* WT = reinterpret_cast<float*>(bbase + B.WT);
-    float* G = reinterpret_cast<float*>(bbase + B.G);
+    const float* WT = reinterpret_cast<const float*>(fbase + Lo.wt);     // Wprod^T, written by the forward's stage 1
+    float* G = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + B.G);
 
     ProdBwdArgs A{};
     A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.KG = B.KG; A.D = d->D; A.cap = Lo.cap;
@@ -437,23 +462,15 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
         A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
         A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
     }
-    PtrArray wp{};
-    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
-    {
-        const long total = (long)cp_real * d->D;
-        hipLaunchKernelGGL(pack_wrows_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, A, cp_real,
-                           wp, WT);
-        RBR_CHECK_LAUNCH("textcnn pack_wrows launch");
-    }
     hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
     RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
     const long n_items = (long)d->n_docs * A.C * A.KF;
     hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
                        reinterpret_cast<const long long*>(ids), mask, row_of_token, feat, argmax, d_feat, G);
     RBR_CHECK_LAUNCH("textcnn build_g launch");
-    const int rows_cap = (Lo.cap + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(rows_cap, 4096)), dim3(256), (size_t)B.KG * 8 * kWavesPerWG, st, A,
-                       counter, G, WT, tok_of_row, dtable);
+    const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
+    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
+                       tok_of_row, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
@@ -467,7 +484,7 @@ struct ProdState {       // everything the three forward stages share, derived f
     int *used, *row_of_token, *counter, *sched_p;
     long long* tok_of_row;
     unsigned char* row_mask;
-    float *packed_p, *T;
+    float *packed_p, *WT, *T;
     char* base;
 };
 
@@ -484,6 +501,7 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
     S.counter = reinterpret_cast<int*>(S.base + Lo.counter);
     S.sched_p = reinterpret_cast<int*>(S.base + Lo.sched);
     S.packed_p = reinterpret_cast<float*>(S.base + Lo.packed);
+    S.WT = reinterpret_cast<float*>(S.base + Lo.wt);
     S.T = reinterpret_cast<float*>(S.base + Lo.table_T);
     if (!build_plans(&S.Lo.dp, S.pp)) return RBR_ERR_BAD_ARG;
     S.pp[0].store_rows = 1;      // group 0's plan describes every group; the kernel folds them into one launch
@@ -498,32 +516,41 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
 
 }  // namespace
 
-// Stage 1: distinct-token list of the batch, product weight image, work list of the token pseudo-document.
+// Stage 1: work list of the real documents (tail of `pidx`), distinct-token list of the batch, product weight
+// images.  Three launches: zero the state | mark + scan | compact + pack.
 extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
-                                        const float* const* W, void* ws, void* stream) {
+                                        const float* const* W, int32_t* pidx, void* ws, void* stream) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
-    if (!ids || !W) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!ids || !W || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     ProdState S;
     if (int e = prod_state(d, ws, S)) return e;
     hipStream_t st = (hipStream_t)stream;
-    // used / row_mask / counter / zero row are re-initialised every call: graph-replay safe
-    if (int e = zero_words(S.base + S.Lo.used, S.Lo.row_of_token - S.Lo.used, st)) return e;
+    int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
+    // token marks, row mask and both work-list counter blocks are re-initialised every call: graph-replay safe
+    ZeroRegions zr{{reinterpret_cast<int*>(S.base + S.Lo.used), S.sched_p + 2 * (size_t)S.pp[0].total_wt,
+                    sched + 2 * (size_t)plans[0].total_wt},
+                   {(long)((S.Lo.row_of_token - S.Lo.used) / sizeof(int)), kSchedCounters, kSchedCounters}};
+    if (int e = zero_regions(zr, st)) return e;
     const long n_tok = (long)d->n_docs * d->L;
-    hipLaunchKernelGGL(mark_tokens_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, n_tok,
-                       reinterpret_cast<const long long*>(ids), mask, S.used);
-    RBR_CHECK_LAUNCH("textcnn mark_tokens launch");
-    hipLaunchKernelGGL(compact_tokens_kernel, dim3((d->V + 255) / 256), dim3(256), 0, st, d->V, S.Lo.cap, S.used, S.row_of_token,
-                       S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch);
-    RBR_CHECK_LAUNCH("textcnn compact_tokens launch");
+    const int nb_scan = (plans[0].total_wt + 255) / 256;
+    const int nb_mark = (int)std::min<long>((n_tok + 255) / 256, 2048);
+    hipLaunchKernelGGL(mark_scan_kernel, dim3(nb_scan + nb_mark), dim3(256), 0, st, plans[0], nb_scan, n_tok,
+                       reinterpret_cast<const long long*>(ids), mask, sched, S.used);
+    RBR_CHECK_LAUNCH("textcnn mark_scan launch");
+    PackJob J{};
+    J.P = S.pp[0]; J.n_widths = d->n_widths; J.D = d->D; J.cp_real = S.A.cp_real;
+    for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = S.A.poff[w]; }
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
-    const long total = (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC;
-    hipLaunchKernelGGL(pack_prod_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, S.pp[0],
-                       plans[0], S.A, wp, S.packed_p);
-    RBR_CHECK_LAUNCH("textcnn pack_prod launch");
-    // rows beyond the distinct count are masked -> their tiles are skipped
-    return scan_tiles(S.pp[0], S.row_mask, S.sched_p, st);
+    const int nb_compact = (d->V + 255) / 256;
+    const long n_pack = (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC + (long)S.A.cp_real * d->D;
+    const int nb_pack = (int)std::min<long>((n_pack + 255) / 256, 2048);
+    hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, S.Lo.cap, S.used,
+                       S.row_of_token, S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch, wp,
+                       S.packed_p, S.WT);
+    RBR_CHECK_LAUNCH("textcnn compact_pack launch");
+    return 0;
 }
 
 // Stage 2 (one kernel): T = table[tok_of_row] @ Wprod on the f32 MFMA pipe.
@@ -534,7 +561,8 @@ extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* ta
     return run_conv_groups(S.pp, 1, S.tok_of_row, S.row_mask, nullptr, table, S.packed_p, S.T, nullptr, S.sched_p, (hipStream_t)stream);
 }
 
-// Stage 3: per active wave-tile of the real documents, add the kz rows of T per position, max / first argmax.
+// Stage 3 (one kernel): per active wave-tile of the real documents (work list in the tail of `pidx`, built by stage 1),
+// add the kz rows of T per position, max / first argmax.
 extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                      float* pval, int32_t* pidx, void* ws, void* stream) {
     ConvPlan plans[kMaxGroups];
@@ -544,8 +572,7 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     ProdState S;
     if (int e = prod_state(d, ws, S)) return e;
     hipStream_t st = (hipStream_t)stream;
-    int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;
-    if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
+    const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
     for (int g = 0; g < ngroups; ++g) {
         hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[g], S.A,
@@ -562,7 +589,7 @@ int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const uns
                       const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st) {
     if (ws == nullptr || !prod_applicable(d)) return 0;
     const int64_t* ids64 = reinterpret_cast<const int64_t*>(ids);
-    if (int e = rbr_textcnn_prod_prepare(d, ids64, mask, W, ws, st)) return e;
+    if (int e = rbr_textcnn_prod_prepare(d, ids64, mask, W, pidx, ws, st)) return e;
     if (int e = rbr_textcnn_prod_table(d, table, ws, st)) return e;
     if (int e = rbr_textcnn_prod_pool(d, ids64, mask, gate, pval, pidx, ws, st)) return e;
     return 1;

@@ -55,23 +55,24 @@ class _TextCNN(torch.autograd.Function):
         n_part = L_.rbr_textcnn_partial_elems(C.byref(desc))
         if n_packed == 0 or n_part == 0:
             check(-1, "rbr_textcnn plan")
-        packed = torch.empty(n_packed, dtype=F32, device=dev)
         pval = torch.empty(n_part, dtype=F32, device=dev)
         pidx = torch.empty(n_part, dtype=I32, device=dev)
         feat = torch.empty(n_docs, Ctot, dtype=F32, device=dev)
         argmax = torch.empty(n_docs, Ctot, dtype=I32, device=dev)
         st = current_stream()
 
-        check(L_.rbr_textcnn_pack(C.byref(desc), ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"), st),
-              "rbr_textcnn_pack")
         ws_bytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))      # > 0: the token-product formulation will run
         prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        packed = None         # MFMA tile image of the conv weights: the dense forward and the scatter backward read it
+        if prod_ws is None:
+            packed = _TextCNN._pack(L_, desc, ws, n_packed, dev, st)
         if prod_ws is not None:
             # token-product formulation, stage by stage (each stage is what rbr_textcnn_conv_fwd would run)
             wsp = prod_ws.data_ptr()
             ev = TIMER.record("textcnn_prod_prepare")
             check(L_.rbr_textcnn_prod_prepare(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                              ptr_array(ws, F32, "conv weight"), wsp, st), "rbr_textcnn_prod_prepare")
+                                              ptr_array(ws, F32, "conv weight"), dev_ptr(pidx, I32, "pidx"), wsp, st),
+                  "rbr_textcnn_prod_prepare")
             if ev is not None:
                 ev.record()
             ev = TIMER.record("textcnn_prod_table")
@@ -106,6 +107,13 @@ class _TextCNN(torch.autograd.Function):
                               *([gate] if gate is not None else []), *ws)
         ctx.mark_non_differentiable(argmax)
         return feat, argmax
+
+    @staticmethod
+    def _pack(L_, desc, ws, n_packed, dev, st):
+        packed = torch.empty(n_packed, dtype=F32, device=dev)
+        check(L_.rbr_textcnn_pack(C.byref(desc), ptr_array(ws, F32, "conv weight"), dev_ptr(packed, F32, "packed"), st),
+              "rbr_textcnn_pack")
+        return packed
 
     @staticmethod
     def backward(ctx, d_feat, _d_argmax):
@@ -147,13 +155,15 @@ class _TextCNN(torch.autograd.Function):
             # table); the gated variant (D-ATT) also needs d(gate) and keeps the scatter kernel
             bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
             check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                 ptr_array(ws, F32, "conv weight"), dev_ptr(feat, F32, "feat"),
+                                                 dev_ptr(feat, F32, "feat"),
                                                  dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
                                                  ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"), st),
                   "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
+        if packed is None:
+            packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
         check(L_.rbr_textcnn_bwd_dtable(*common, dev_ptr(packed, F32, "packed"), dev_ptr(feat, F32, "feat"),
                                         dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
                                         dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st),
@@ -213,9 +223,12 @@ class _PairHead(torch.autograd.Function):
         L_ = _lib.lib()
         names = ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib")
         hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(params, names)])
-        # embedding-style grads are accumulated with atomics -> start from zero; the rest is overwritten
-        grads = [torch.zeros_like(t) if n in ("Eu", "Ei", "ub", "ib") else torch.empty_like(t)
-                 for t, n in zip(params, names)]
+        # embedding-style grads are accumulated with atomics -> start from zero (one fill for the four of them);
+        # the rest is overwritten
+        acc = [t for t, n in zip(params, names) if n in ("Eu", "Ei", "ub", "ib")]
+        flat = torch.zeros(sum(t.numel() for t in acc), dtype=F32, device=dev)
+        zeroed = iter(v.view_as(t) for v, t in zip(flat.split([t.numel() for t in acc]), acc))
+        grads = [next(zeroed) if n in ("Eu", "Ei", "ub", "ib") else torch.empty_like(t) for t, n in zip(params, names)]
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
         d_uf = torch.empty_like(u_feat)
         d_if = torch.empty_like(i_feat)
