@@ -119,6 +119,8 @@ __device__ __forceinline__ void mma_chain(f32x16& acc, const Frag<DC>& a, const 
 }
 
 #ifdef RBR_DIAG
+// tuning build only (tools/dev_conv_diag.py): per-workgroup cycle counts of the item-loop segments
+__device__ unsigned long long g_diag[8 * 1024];
 #define RBR_STAMP(slot)                                                                         \
     do {                                                                                        \
         unsigned long long _t;                                                                  \
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
                 }
             }
         }
+        RBR_STAMP(7);   // epilogue
         continue;
     }
     // max + first argmax over this wave's 32 positions, per channel slot
@@ -366,10 +369,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     RBR_STAMP(7);   // epilogue
   }  // item loop
 #ifdef RBR_DIAG
-    if (tid == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(pval + (long)P.total_wt * P.nslots_total) + 8 * blockIdx.x;
+    if (tid == 0 && blockIdx.x < 1024) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = diag[k];
+        for (int k = 0; k < 8; ++k) g_diag[8 * blockIdx.x + k] = diag[k];
     }
 #endif
 }
@@ -458,6 +460,12 @@ static size_t packed_floats(const ConvPlan& p0) {
 }  // namespace rbr
 
 using namespace rbr;
+
+#ifdef RBR_DIAG
+extern "C" int rbr_diag_fetch(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_diag), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" size_t rbr_textcnn_packed_floats(const rbr_textcnn_desc* d) {
     ConvPlan plans[kMaxGroups];
