@@ -67,7 +67,8 @@ void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // Builds the launch plans for `d`.  Returns the number of groups (0 on error, see rbr_last_error()).
-int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */);
+int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */, int tiles_per_group = 5);
+constexpr int kProdGroupTiles = 8;   // channel tiles per work item of the token-product GEMM (textcnn_prod.hip)
 
 // Launches the fused gather + conv kernel for every group of `plans` (textcnn_fwd.hip).  `sched` must have been
 // filled by scan_tiles() for the same document set.  In store_rows mode `pval` is the output table.

@@ -42,15 +42,15 @@ static bool validate(const rbr_textcnn_desc* d) {
 
 // Channel slots are ordered by ascending kernel width and cut into tiles of 32: a tile then only
 // streams the taps its widest member needs (3/5/7 x 50 channels -> 27 tap-tiles instead of 30).
-int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans) {
+int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans, int tiles_per_group) {
     if (!validate(d)) return 0;
     int C = 0, KF = 0;
     int ch_off[RBR_MAX_WIDTHS];
     for (int w = 0; w < d->n_widths; ++w) { ch_off[w] = C; C += d->ch[w]; KF = std::max(KF, d->kz[w]); }
     const int tiles_total = (C + kTile - 1) / kTile;
-    // <= 5 tiles per launch keeps the kernel at 2 waves/SIMD (6 tiles = 96 accumulator + ~176 other VGPRs goes
-    // past 256); groups are balanced (10 tiles -> 5 + 5, not 8 + 2)
-    constexpr int kPreferredTiles = 5;
+    // <= 5 tiles per launch keeps the pooling kernel at 2 waves/SIMD without asking the compiler for it; the
+    // store-mode kernel is compiled for 2 waves/SIMD and takes 8.  Groups are balanced (10 tiles -> 5 + 5, not 8 + 2)
+    const int kPreferredTiles = std::min(std::max(tiles_per_group, 1), kMaxTiles);
     const int ngroups = (tiles_total + kPreferredTiles - 1) / kPreferredTiles;
     const int per_group = (tiles_total + ngroups - 1) / ngroups;
     if (ngroups > kMaxGroups) { set_error("%d output channels exceed the supported %d", C, kMaxGroups * kPreferredTiles * kTile); return 0; }

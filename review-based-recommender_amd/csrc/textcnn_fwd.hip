@@ -132,12 +132,15 @@ __device__ unsigned long long g_diag[8 * 1024];
 #define RBR_STAMP(slot) do { } while (0)
 #endif
 
-template <int NT, int DC, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const long long* __restrict__ ids,
-                                                       const unsigned char* __restrict__ mask,
-                                                       const float* __restrict__ gate, const float* __restrict__ table,
-                                                       const float* __restrict__ packed, float* __restrict__ pval,
-                                                       int* __restrict__ pidx, const int* __restrict__ sched) {
+// STORE = the token-product GEMM (P.store_rows, one tap): the accumulators are written out as rows of T; the token
+// fragment of a chunk is read from LDS once and kept in registers for all its pieces, and the freed slab receives the
+// NEXT chunk's rows while the current chunk computes (every workgroup holds exactly one item there, so co-resident
+// workgroups run in phase and cannot hide each other's gathers).
+template <int NT, int DC, bool VEC, bool STORE>
+__device__ __forceinline__ void conv_body(const ConvPlan& P, const long long* __restrict__ ids,
+                                          const unsigned char* __restrict__ mask, const float* __restrict__ gate,
+                                          const float* __restrict__ table, const float* __restrict__ packed,
+                                          float* __restrict__ pval, int* __restrict__ pidx, const int* __restrict__ sched) {
     static_assert(DC % 4 == 0 && (DC / 4) % 2 == 1, "row stride must be 4*odd floats (bank-conflict-free b128 reads)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE_F = kTile * DC;             // floats of one channel tile of a piece
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * (kTile + kMaxKF);   // [XR] per wave
     int* s_item = reinterpret_cast<int*>(reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + kWavesPerWG * (kTile + kMaxKF));
     // store_rows launches fold all (identical) channel-tile groups into one grid: item -> (row item, group)
-    const int ngroups_in_launch = P.store_rows ? P.tiles_total / P.ntiles : 1;
+    const int ngroups_in_launch = STORE ? P.tiles_total / P.ntiles : 1;
     // wave-tiles with at least one unmasked token; store_rows: the slot holds the ROW count of the token list and
     // the active tiles are simply the first ceil(rows / 32)
-    const int n_active = P.store_rows ? (sched[2 * (long)P.total_wt] + kTile - 1) / kTile : sched[2 * (long)P.total_wt];
+    const int n_active = STORE ? (sched[2 * (long)P.total_wt] + kTile - 1) / kTile : sched[2 * (long)P.total_wt];
     const int* worklist = sched + P.total_wt;
     const int nrow_items = (n_active + kWavesPerWG - 1) / kWavesPerWG;
     const int nitems = nrow_items * ngroups_in_launch;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     const float* wbase = packed + (long)tile_base * TILE_F;
     const int slot_in_list = (item - grp * nrow_items) * kWavesPerWG + wave;
     const bool active = slot_in_list < n_active;      // wave-uniform
-    const int wt = active ? (P.store_rows ? slot_in_list : worklist[slot_in_list]) : 0;   // global wave-tile
+    const int wt = active ? (STORE ? slot_in_list : worklist[slot_in_list]) : 0;   // global wave-tile
     const int doc = wt / P.wpd;
     const int l0 = (wt % P.wpd) * kTile;
 
@@ -236,54 +239,64 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     }
     RBR_STAMP(1);   // item prologue: first piece request + row offsets
 
-    int pi = 0, dc = 0;                       // piece q = dc * np + pi, tracked incrementally (no divisions)
-    for (int q = 0; q < T; ++q) {
-        if (pi == 0) {
-            // ---- gather this wave's token rows for columns [dc*DC, dc*DC+DC) --------------------------------
-            if (active) {
-                if (VEC) {
-                    constexpr int QPR = DC / 4;
-                    constexpr int NX = ((kTile + kMaxKF - 1) * QPR + 63) / 64;
+    // gather this wave's token rows for columns [dcq*DC, dcq*DC+DC) into its slab
+    auto gather_chunk = [&](int dcq) {
+        if (VEC) {
+            constexpr int QPR = DC / 4;
+            constexpr int NX = ((kTile + (STORE ? 0 : kMaxKF - 1)) * QPR + 63) / 64;
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) {
-                        const int idx = lane + 64 * k;
-                        if (idx < XR * QPR) {
-                            const int row = idx / QPR, qq = idx - row * QPR;
-                            const int d = dc * DC + 4 * qq;
-                            const long ro = s_row[row];
-                            const float* src = (ro >= 0 && d < D) ? table + ro + d : g_zero_row;
-                            dma16(src, Xw + 256 * k);     // granule idx lands at Xw + 4*idx = row*DC + 4*qq
-                        }
-                    }
-                    if (gate != nullptr) {
-                        // gated rows (D-ATT: x * score): scale the slab in place once the wave's own DMA has landed
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        for (int idx = lane; idx < XR * QPR; idx += 64) {
-                            const int row = idx / QPR;
-                            const int p = l0 - P.P + row;
-                            if (p >= 0 && p < L) {
-                                f32x4* cell = reinterpret_cast<f32x4*>(Xw + 4 * idx);
-                                *cell = *cell * gate[(long)doc * L + p];
-                            }
-                        }
-                    }
-                } else {
-                    for (int idx = lane; idx < XR * DC; idx += 64) {
-                        const int row = idx / DC, dd = idx - row * DC;
-                        float v = 0.f;
-                        const int d = dc * DC + dd;
-                        const long ro = s_row[row];
-                        if (ro >= 0 && d < D) {
-                            v = table[ro + d];
-                            if (gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
-                        }
-                        Xw[idx] = v;
+            for (int k = 0; k < NX; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < XR * QPR) {
+                    const int row = idx / QPR, qq = idx - row * QPR;
+                    const int d = dcq * DC + 4 * qq;
+                    const long ro = s_row[row];
+                    const float* src = (ro >= 0 && d < D) ? table + ro + d : g_zero_row;
+                    dma16(src, Xw + 256 * k);     // granule idx lands at Xw + 4*idx = row*DC + 4*qq
+                }
+            }
+            if (!STORE && gate != nullptr) {
+                // gated rows (D-ATT: x * score): scale the slab in place once the wave's own DMA has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int idx = lane; idx < XR * QPR; idx += 64) {
+                    const int row = idx / QPR;
+                    const int p = l0 - P.P + row;
+                    if (p >= 0 && p < L) {
+                        f32x4* cell = reinterpret_cast<f32x4*>(Xw + 4 * idx);
+                        *cell = *cell * gate[(long)doc * L + p];
                     }
                 }
             }
+        } else {
+            for (int idx = lane; idx < XR * DC; idx += 64) {
+                const int row = idx / DC, dd = idx - row * DC;
+                float v = 0.f;
+                const int d = dcq * DC + dd;
+                const long ro = s_row[row];
+                if (ro >= 0 && d < D) {
+                    v = table[ro + d];
+                    if (!STORE && gate != nullptr) v *= gate[(long)doc * L + l0 - P.P + row];
+                }
+                Xw[idx] = v;
+            }
+        }
+    };
+
+    int pi = 0, dc = 0;                       // piece q = dc * np + pi, tracked incrementally (no divisions)
+    Frag<DC> a_keep;                          // STORE: token fragment of the current chunk
+    for (int q = 0; q < T; ++q) {
+        if (pi == 0 && (!STORE || dc == 0)) {
+            if (active) gather_chunk(dc);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA requests have landed ...
             __syncthreads();                                   // ... and so have everyone else's
             RBR_STAMP(2);   // row gather of the chunk (+ its barrier)
+        }
+        if (STORE && pi == 0 && active) {
+            // chunk dc's rows were requested while chunk dc-1 computed and have landed (every piece ends in vmcnt(0));
+            // read them once, then hand the slab to the next chunk's gather
+            a_keep.load(Xw + i * DC + 4 * h, h);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (dc + 1 < P.nchunks) gather_chunk(dc + 1);
         }
         const int st3 = P.piece_st[wrap(pi + 3)];         // consumed three pieces from now
         // piece q+1 goes into the other ring slot (free since the last barrier); its DMA requests are issued from
@@ -297,8 +310,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
         if (active) {
             const int s = st0 & 0xff, t = (st0 >> 8) & 0xff, nt = st0 >> 16;
             const float* wb = Ws + cur * PIECE + i * DC + 4 * h;
-            Frag<DC> a, b;
-            a.load(Xw + (i + s) * DC + 4 * h, h);
+            Frag<DC> a_tap, b;
+            if (!STORE) a_tap.load(Xw + (i + s) * DC + 4 * h, h);
+            const Frag<DC>& a = STORE ? a_keep : a_tap;
             b.load(wb, h);
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------------
-    if (P.store_rows) {
+    if (STORE) {
         // token-product table: out[row, slot] = accumulator (rows of the pseudo-document = distinct tokens)
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
@@ -374,6 +388,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const l
         for (int k = 0; k < 8; ++k) g_diag[8 * blockIdx.x + k] = diag[k];
     }
 #endif
+}
+
+// pooling conv: up to 5 channel tiles per launch group (2 waves/SIMD with the default register split)
+template <int NT, int DC, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const long long* __restrict__ ids,
+                                                       const unsigned char* __restrict__ mask,
+                                                       const float* __restrict__ gate, const float* __restrict__ table,
+                                                       const float* __restrict__ packed, float* __restrict__ pval,
+                                                       int* __restrict__ pidx, const int* __restrict__ sched) {
+    conv_body<NT, DC, VEC, false>(P, ids, mask, gate, table, packed, pval, pidx, sched);
+}
+
+// token-product GEMM (P.store_rows): compiled for exactly 2 waves/SIMD, i.e. the unified 512-entry register file is
+// split 256 / 256 -- 8 accumulator tiles (128 registers) fit without spills
+template <int NT, int DC, bool VEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_store_kernel(const ConvPlan P, const long long* __restrict__ ids, const unsigned char* __restrict__ mask,
+                       const float* __restrict__ table, const float* __restrict__ packed, float* __restrict__ out,
+                       const int* __restrict__ sched) {
+    conv_body<NT, DC, VEC, true>(P, ids, mask, nullptr, table, packed, out, nullptr, sched);
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -426,17 +460,24 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
     const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) +
                         (size_t)kWavesPerWG * (kTile + kMaxKF) * sizeof(long) + 16 + extra_lds;
-    static int occ = 0;   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
-    if (occ == 0) {
+    static int occ[2] = {0, 0};   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
+    const int sm = p.store_rows ? 1 : 0;
+    if (occ[sm] == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_fwd_kernel<NT, DC, VEC>, 256, smem) != hipSuccess || nb <= 0)
-            nb = 2;
-        occ = nb;
+        const hipError_t e = sm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_store_kernel<NT, DC, VEC>, 256, smem)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_fwd_kernel<NT, DC, VEC>, 256, smem);
+        if (e != hipSuccess || nb <= 0) nb = 2;
+        occ[sm] = nb;
     }
     const int nitems = ((p.total_wt + kWavesPerWG - 1) / kWavesPerWG) * (p.store_rows ? p.tiles_total / p.ntiles : 1);
-    const dim3 grid(std::min(nitems, num_cus() * occ)), block(256);
-    hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,
-                       pidx, sched);
+    const dim3 grid(std::min(nitems, num_cus() * occ[sm])), block(256);
+    if (p.store_rows) {
+        if (gate != nullptr) { set_error("store mode takes no gate"); return RBR_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL((conv_store_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, table, packed, pval, sched);
+    } else {
+        hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,
+                           pidx, sched);
+    }
     RBR_CHECK_LAUNCH("textcnn conv_fwd launch");
     return 0;
 }

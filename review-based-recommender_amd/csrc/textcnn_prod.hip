@@ -345,7 +345,7 @@ bool prod_applicable(const rbr_textcnn_desc* d) {
     long Cp = 0;
     for (int w = 0; w < d->n_widths; ++w) Cp += (long)d->kz[w] * d->ch[w];
     if (Cp > 30000) return false;                          // slot ids are 16-bit
-    if ((Cp + kTile - 1) / kTile > (long)kMaxGroups * 5) return false;
+    if ((Cp + kTile - 1) / kTile > (long)kMaxGroups * kProdGroupTiles) return false;
     if (mode && !strcmp(mode, "product")) return true;
     // auto: worth it when the vocabulary bounds the distinct tokens well below the position count
     return (long)d->V * 5 <= n_pos * 2 && n_pos >= 4096;
@@ -358,8 +358,11 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     Lo.cap = (int)std::min<long>(d->V, n_pos);
     long Cp = 0;
     for (int w = 0; w < d->n_widths; ++w) Cp += (long)d->kz[w] * d->ch[w];
-    constexpr int kGroupSlots = 5 * kTile;            // one launch group = 5 tiles (rbr_plan.hip)
-    Cp = ((Cp + kGroupSlots - 1) / kGroupSlots) * kGroupSlots;   // zero-weight padding channels: all groups identical
+    // zero-weight padding channels make all work-item groups identical: 8 tiles each (750 -> 768 = 3 x 8 tiles at cfg2:
+    // 167 row blocks x 3 groups = 501 items for 512 resident workgroups), fewer when the whole bank is smaller
+    const int group_tiles = (int)std::min<long>(kProdGroupTiles, (Cp + kTile - 1) / kTile);
+    const int kGroupSlots = group_tiles * kTile;
+    Cp = ((Cp + kGroupSlots - 1) / kGroupSlots) * kGroupSlots;
     Lo.Cp = (int)Cp;
     Lo.tiles_p = (int)(Cp / kTile);
     memset(&Lo.dp, 0, sizeof(Lo.dp));
@@ -367,7 +370,7 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     Lo.dp.n_widths = 1; Lo.dp.kz[0] = 1; Lo.dp.ch[0] = Lo.Cp;
     Lo.dp.pad_mode = RBR_PAD_SAME; Lo.dp.act = RBR_ACT_RELU; Lo.dp.padding_idx = -1;
     ConvPlan plans[kMaxGroups];
-    if (!build_plans(&Lo.dp, plans)) return false;
+    if (!build_plans(&Lo.dp, plans, kProdGroupTiles)) return false;
     const ConvPlan& p = plans[0];
     size_t o = 0;
     // [used | row_mask] are contiguous and re-zeroed every call together with the counters of `sched`
@@ -503,7 +506,7 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
     S.packed_p = reinterpret_cast<float*>(S.base + Lo.packed);
     S.WT = reinterpret_cast<float*>(S.base + Lo.wt);
     S.T = reinterpret_cast<float*>(S.base + Lo.table_T);
-    if (!build_plans(&S.Lo.dp, S.pp)) return RBR_ERR_BAD_ARG;
+    if (!build_plans(&S.Lo.dp, S.pp, kProdGroupTiles)) return RBR_ERR_BAD_ARG;
     S.pp[0].store_rows = 1;      // group 0's plan describes every group; the kernel folds them into one launch
     ProdArgs A{};
     A.n_docs = d->n_docs; A.L = d->L; A.V = d->V; A.cap = Lo.cap; A.zrow = Lo.cap; A.pitch = S.pp[0].nslots_total;
