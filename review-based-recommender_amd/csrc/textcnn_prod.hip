@@ -28,6 +28,7 @@ struct ProdArgs {
     int zrow;                       // index of the all-zero row of T (= cap)
     int pitch;                      // floats per row of T (32 * product tiles)
     int poff[RBR_MAX_WIDTHS];       // first product channel of bank w: channel (w, j, cl) = poff[w] + j*ch[w] + cl
+    int rank_off[RBR_MAX_WIDTHS];   // first slot of bank w in the pooling workspace (banks ordered by kernel width, stable)
     int cp_real;                    // product channels before padding to whole launch groups
 };
 
@@ -114,9 +115,14 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
 }
 
 // ---------------------------------------------------------------------------------- gather + pool
-// One wave per active 32-position wave-tile (work list of the dense path's tile scan).  Lanes = channel slots
-// (64 per pass); for each position the lane adds its kz product rows.  Writes the same (max, first argmax)
-// partials as the conv kernel's pooling epilogue.
+// One wave per active 32-position slab (work list of the tile scan).  A lane owns FOUR consecutive channels of one
+// bank at every fourth position: lane = (position mod 4, channel quad), so one float4 load instruction moves
+// 4 positions x 16 quads of one (bank, tap) segment of T -- the 200-byte segments of a 50-channel bank are read whole.
+// For each of its positions the lane adds its kz product rows (x gate), keeps the running max / first argmax, and the
+// four position classes meet by shuffle.  Writes the same (max, first argmax) partials as the conv kernel's epilogue.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // segments start at any float
+
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
                                                           const int* __restrict__ row_of_token, const float* __restrict__ T,
@@ -147,45 +153,54 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
         s_gate[wave][r] = gv;
     }
     __builtin_amdgcn_wave_barrier();
-    const int nslots = P.ntiles * kTile;            // slots of this launch group
-    for (int ls0 = 0; ls0 < nslots; ls0 += 64) {
-        const int ls = ls0 + lane;
-        // slot descriptors of ALL groups live in plan order; this kernel is launched with the group-0 plan of a
-        // single-group problem or once per group (tile_base selects the slot range)
-        const int chan = (ls < nslots) ? P.slot_chan[ls] : -1;
-        int kz = 0, off = 0, col = 0, cstride = 0;
-        if (chan >= 0) {
-            const int w = P.slot_w[ls];
-            kz = P.slot_kz[ls];
-            off = P.slot_off[ls];
-            cstride = P.ch[w];
-            col = A.poff[w] + (chan - P.ch_off[w]);
-        }
-        const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;
-        float best = -__builtin_huge_valf();
-        int bidx = 0x7fffffff;
-        for (int q0 = 0; q0 < kTile; q0 += 4) {          // 4 positions x kz rows of independent loads in flight
-            float y[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < P.KF; ++j) {
-                if (j < kz) {
+    const int ps = lane >> 4, ql = lane & 15;
+    const float NEG = -__builtin_huge_valf();
+    for (int w = 0; w < P.n_widths; ++w) {
+        const int kz = P.kz[w], ch = P.ch[w];
+        const int off = (P.pad_mode == RBR_PAD_SAME) ? (P.KF - kz) / 2 : 0;      // frame tap of the bank's tap 0
+        const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;          // pool length of this bank
+        const int nquads = (ch + 3) >> 2;
+        for (int qb = 0; qb < nquads; qb += 16) {
+            const int q = qb + ql;
+            const bool valid = q < nquads;
+            const float* tcol = T + A.poff[w] + 4 * (valid ? q : 0);
+            float best[4] = {NEG, NEG, NEG, NEG};
+            int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+            for (int p0 = 0; p0 < kTile; p0 += 4) {
+                const int pl = p0 + ps;                                   // position inside the slab
+                f32x4 y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = q0 + u + j + off;
-                        const float v = T[(long)s_row[wave][r] * A.pitch + col + j * cstride];
-                        y[u] = fmaf(v, s_gate[wave][r], y[u]);
+                for (int j = 0; j < kMaxKF; ++j) {                        // kz independent float4 loads in flight
+                    if (j < kz) {
+                        const int r = pl + j + off;
+                        const f32x4u v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
+                        const float gv = s_gate[wave][r];
+                        y.x = fmaf(v.x, gv, y.x); y.y = fmaf(v.y, gv, y.y); y.z = fmaf(v.z, gv, y.z); y.w = fmaf(v.w, gv, y.w);
                     }
+                }
+                const int pos = l0 + pl;
+                if (pos < Lv) {                                           // ascending positions per lane: '>' keeps the first max
+                    if (y.x > best[0]) { best[0] = y.x; bidx[0] = pos; }
+                    if (y.y > best[1]) { best[1] = y.y; bidx[1] = pos; }
+                    if (y.z > best[2]) { best[2] = y.z; bidx[2] = pos; }
+                    if (y.w > best[3]) { best[3] = y.w; bidx[3] = pos; }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int pos = l0 + q0 + u;
-                if (chan >= 0 && pos < Lv && y[u] > best) { best = y[u]; bidx = pos; }
+            for (int c = 0; c < 4; ++c) {                                 // meet the four position classes
+#pragma unroll
+                for (int o = 16; o < 64; o <<= 1) {
+                    const float ob = __shfl_xor(best[c], o);
+                    const int oi = __shfl_xor(bidx[c], o);
+                    if (ob > best[c] || (ob == best[c] && oi < bidx[c])) { best[c] = ob; bidx[c] = oi; }
+                }
             }
-        }
-        if (chan >= 0) {
-            const long o = (long)wt * P.nslots_total + (long)P.tile_base * kTile + ls;
-            pval[o] = best;
-            pidx[o] = bidx;
+            if (valid && ps == 0) {
+                const long o = (long)wt * P.nslots_total + A.rank_off[w] + 4 * q;      // kz-sorted slot of the channel
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * q + c < ch) { pval[o + c] = best[c]; pidx[o + c] = bidx[c]; }
+            }
         }
     }
 }
@@ -203,8 +218,6 @@ struct ProdBwdArgs {
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
 };
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G) {
     const long n = (long)min(*counter, cap) * KG4;
@@ -386,7 +399,7 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     long cp_real = 0;
     for (int w = 0; w < d->n_widths; ++w) cp_real += (long)d->kz[w] * d->ch[w];
     Lo.wt = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
-    Lo.table_T = o;      o += align256(((size_t)Lo.cap + 1) * p.nslots_total * sizeof(float));
+    Lo.table_T = o;      o += align256((((size_t)Lo.cap + 1) * p.nslots_total + 4) * sizeof(float));   // + one float4 of slack: quads read whole
     Lo.total = o;
     return true;
 }
@@ -513,6 +526,12 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
     int o = 0;    // product channels follow the bank order of the ORIGINAL problem (bank w, tap j, channel cl)
     for (int w = 0; w < d->n_widths; ++w) { A.poff[w] = o; o += d->kz[w] * d->ch[w]; }
     A.cp_real = o;
+    for (int w = 0; w < d->n_widths; ++w) {      // as build_plans orders the channel slots
+        int r = 0;
+        for (int v = 0; v < d->n_widths; ++v)
+            if (d->kz[v] < d->kz[w] || (d->kz[v] == d->kz[w] && v < w)) r += d->ch[v];
+        A.rank_off[w] = r;
+    }
     S.A = A;
     return 0;
 }
@@ -577,11 +596,9 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     hipStream_t st = (hipStream_t)stream;
     const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
-    for (int g = 0; g < ngroups; ++g) {
-        hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[g], S.A,
-                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
-        RBR_CHECK_LAUNCH("textcnn gather_pool launch");
-    }
+    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
+                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
+    RBR_CHECK_LAUNCH("textcnn gather_pool launch");
     return 0;
 }
 
