@@ -132,6 +132,119 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
     if (tid == 0) ws_b[(long)chunk * C + c] = bsum;
 }
 
+// float4 variant of dw_partial (D % 4 == 0, D <= 1024): thread = (slot, float4 column).  The 256 / (D/4) slots of a
+// workgroup split into `jslots` taps x `dpar` documents in flight, so a 300-wide row is read by 75 lanes with one
+// dwordx4 each and three window rows are read at once (the scalar kernel needs 300 + 44 lanes in two passes per row).
+// Partial sums of the `dpar` document classes meet in LDS; same slabs, same dw_reduce.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// kDwMaxM = taps per thread (compile-time bound: the register arrays below are sized by it)
+template <int kDwMaxM>
+__global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const long long* __restrict__ ids,
+                                                          const unsigned char* __restrict__ mask,
+                                                          const float* __restrict__ gate, const float* __restrict__ table,
+                                                          const float* __restrict__ feat, const int* __restrict__ argmax,
+                                                          const float* __restrict__ d_feat, float* __restrict__ ws_w,
+                                                          float* __restrict__ ws_b) {
+    __shared__ long s_row[kDocsPerBatch * kMaxKF];
+    __shared__ float s_sc[kDocsPerBatch * kMaxKF];
+    __shared__ float s_g[kDocsPerBatch];
+    __shared__ __attribute__((aligned(16))) float s_red[512];      // [kz][D], used when dpar > 1, i.e. kz * D/4 <= 128
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int w = bank_of(A, c);
+    const int kz = A.kz[w];
+    const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
+    const int doc_begin = chunk * A.DPC;
+    const int doc_end = min(A.n_docs, doc_begin + A.DPC);
+    const int L = A.L, D = A.D, C = A.C;
+    const int nq4 = D >> 2;
+    const int nslots = 256 / nq4;
+    const int jslots = min(nslots, kz);
+    const int dpar = nslots / jslots;
+    const int q4 = tid % nq4, slot = tid / nq4;
+    const bool live = slot < jslots * dpar;
+    const int jsub = slot % jslots, dsub = slot / jslots;
+    const int M = (kz - jsub + jslots - 1) / jslots;          // taps of this thread: jsub, jsub + jslots, ...
+
+    f32x4 acc[kDwMaxM];
+#pragma unroll
+    for (int m = 0; m < kDwMaxM; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int b0 = doc_begin; b0 < doc_end; b0 += kDocsPerBatch) {
+        const int nb = min(kDocsPerBatch, doc_end - b0);
+        __syncthreads();   // previous batch fully consumed
+        for (int e = tid; e < nb * kz; e += 256) {
+            const int dl = e / kz, j = e - dl * kz;
+            const long o = (long)(b0 + dl) * C + c;
+            const float g = act_grad(A.act, feat[o], d_feat[o]);
+            const int p = argmax[o] + j - padl;
+            long row = 0;      // (row 0, scale 0) = no contribution
+            float sc = 0.f;
+            if (g != 0.f && p >= 0 && p < L) {
+                const long tok = (long)(b0 + dl) * L + p;
+                if (mask == nullptr || mask[tok]) {
+                    row = ids[tok] * (long)D;
+                    sc = (gate != nullptr) ? g * gate[tok] : g;
+                }
+            }
+            s_row[e] = row;
+            s_sc[e] = sc;
+            if (j == 0) s_g[dl] = g;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int dl = 0; dl < nb; ++dl) bsum += s_g[dl];   // fixed order
+        if (live) {
+            // branch-free: rows without a contribution were resolved to (row 0, scale 0); 4 documents x M taps of
+            // independent float4 loads are in flight together
+            for (int dl = dsub; dl < nb; dl += 4 * dpar) {
+                f32x4 x[4][kDwMaxM];
+                float sc[4][kDwMaxM];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int du = dl + u * dpar;
+                    const bool ok = du < nb;
+                    const int dq = ok ? du : dl;
+#pragma unroll
+                    for (int m = 0; m < kDwMaxM; ++m) {
+                        if (m < M) {
+                            const int e = dq * kz + jsub + m * jslots;
+                            x[u][m] = *reinterpret_cast<const f32x4*>(table + s_row[e] + 4 * q4);
+                            sc[u][m] = ok ? s_sc[e] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int m = 0; m < kDwMaxM; ++m)
+                        if (m < M) acc[m] += sc[u][m] * x[u][m];
+            }
+        }
+    }
+    // document classes meet in LDS (fixed order), class 0 writes the slab
+    for (int r = 1; r < dpar; ++r) {
+        __syncthreads();
+        if (live && dsub == r) {
+#pragma unroll
+            for (int m = 0; m < kDwMaxM; ++m)
+                if (m < M) *reinterpret_cast<f32x4*>(s_red + ((jsub + m * jslots) * nq4 + q4) * 4) = acc[m];
+        }
+        __syncthreads();
+        if (live && dsub == 0) {
+#pragma unroll
+            for (int m = 0; m < kDwMaxM; ++m)
+                if (m < M) acc[m] += *reinterpret_cast<const f32x4*>(s_red + ((jsub + m * jslots) * nq4 + q4) * 4);
+        }
+    }
+    if (live && dsub == 0) {
+#pragma unroll
+        for (int m = 0; m < kDwMaxM; ++m)
+            if (m < M)
+                *reinterpret_cast<f32x4*>(ws_w + (((long)chunk * C + c) * A.KF + jsub + m * jslots) * D + 4 * q4) = acc[m];
+    }
+    if (tid == 0) ws_b[(long)chunk * C + c] = bsum;
+}
+
 // Document-centric dW for SHORT documents (NARRE reviews: L = 50, 150 channels x 3 taps = 450 windows rows drawn
 // from <= 50 distinct token rows per review).  dw_partial reads every (doc, channel, tap) row from L2/Infinity Cache
 // (2.76 GB at cfg3); here a workgroup owns a 32-float slice of the embedding dim, stages each document's rows for
@@ -261,7 +374,6 @@ constexpr int kWinMax = 512;   // token positions per workgroup window (upper bo
 constexpr int kHash = 1024;    // open-addressing table: token id -> first row of the window with that id
 constexpr int kMaxDI = 8;      // embedding dim handled per pass = 64 lanes * kMaxDI (scalar path)
 constexpr int kMaxQ4 = 2;      // float4 columns per lane and pass (vector path): 512 floats per pass
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const int kWin, const int nwin,
                                                         const long long* __restrict__ ids,
@@ -545,8 +657,24 @@ extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids,
                            gate, table, feat, argmax, d_feat, ws_w, ws_b);
         RBR_CHECK_LAUNCH("textcnn dw_doc launch");
     } else {
-        hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
-                           d_feat, ws_w, ws_b);
+        // float4 rows when the layout allows it (16-byte aligned rows, one row <= 256 float4 lanes)
+        const bool vec4 = (A.D % 4 == 0) && (A.D / 4 <= 256) && ((((uintptr_t)table) & 15) == 0) && ((((uintptr_t)ws_w) & 15) == 0);
+        int taps_per_thread = 1;      // widest bank: ceil(kz / min(slots, kz))
+        if (vec4)
+            for (int w = 0; w < d->n_widths; ++w) {
+                const int nslots = 256 / (A.D / 4), js = std::min(nslots, d->kz[w]);
+                taps_per_thread = std::max(taps_per_thread, (d->kz[w] + js - 1) / js);
+            }
+        if (vec4 && taps_per_thread <= 1) {
+            hipLaunchKernelGGL(dw_partial4_kernel<1>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
+                               argmax, d_feat, ws_w, ws_b);
+        } else if (vec4 && taps_per_thread <= 3) {
+            hipLaunchKernelGGL(dw_partial4_kernel<3>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
+                               argmax, d_feat, ws_w, ws_b);
+        } else {      // odd widths, or rows so long that one slot would own > 3 taps: the scalar-column kernel
+            hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
+                               d_feat, ws_w, ws_b);
+        }
         RBR_CHECK_LAUNCH("textcnn dw_partial launch");
     }
     MutPtrArray dWp{}, dbp{};
