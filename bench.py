@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -190,7 +192,7 @@ def main():
     model = build_model(cfg, device)          # identical parameters on every rank (same seed)
     model.train()
     use_graph = not a.no_graph
-    opt = make_optimizer(model, capturable=use_graph)
+    opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
         grad_sync = GradAllReduce(model)
@@ -259,7 +261,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                       "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)"},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
             "kernel_timing": ("HIP events around the C-ABI launches, eager pass over the same steps after the timed region"

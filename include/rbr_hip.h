@@ -124,16 +124,17 @@ int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint
 int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                            const float* table, const float* packed, const float* feat, const int32_t* argmax,
                            const float* d_feat, float* dtable, float* dgate, void* stream);
-/* Table gradient through the token-product formulation (same maths as rbr_textcnn_bwd_dtable with gate == NULL):
+/* Table (and gate) gradient through the token-product formulation (same maths as rbr_textcnn_bwd_dtable; with a gate,
+ * dgate[doc,p] is ACCUMULATED from the forward's product table T, which must still be intact in `fwd_ws`):
  * G[token][tap, channel] = sum of g over the argmax windows touching that token, for the DISTINCT tokens the
  * forward listed in `fwd_ws` (the workspace rbr_textcnn_conv_fwd was given for the SAME ids/mask, still intact),
  * then dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product (G is ~2 % dense); each listed row of
  * `dtable` is written once with plain stores, all other rows are left untouched (the caller zero-fills dtable).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
  * bytes (0 = formulation not applicable: use rbr_textcnn_bwd_dtable; env RBR_DTABLE_MODE=scatter forces that). */
 size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
-int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* feat,
-                                const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws, float* dtable,
-                                void* stream);
+int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                float* dtable, float* dgate, void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                     const float* table, const float* packed, const float* feat, const int32_t* argmax,
                     const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,
@@ -238,6 +239,19 @@ int rbr_hier_pool_fwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int
 int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
                       const int32_t* argmax, const float* pooled, const float* d_pooled, int32_t relu, int32_t pad_idx,
                       float* dtable, void* stream);
+
+/* ---- clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step()  (trainer/train_deepconn_pp.py:166-167;
+ *      optimizer of :135: lr only, betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), two launches over all
+ *      tensors.  params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers (fp32, contiguous,
+ *      numel[k] elements each).  `step`: device float holding the number of steps taken so far; it is advanced by one
+ *      and the bias corrections use the new value.  max_norm <= 0 skips the clipping.  The gradients are left clipped
+ *      (as clip_grad_norm_ leaves them), *gnorm_out (device, may be NULL) receives the norm before clipping.
+ *      ws: rbr_clip_adam_ws_floats() floats.                                                             ---- */
+#define RBR_OPT_MAX_TENSORS 64
+size_t rbr_clip_adam_ws_floats(void);
+int rbr_clip_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1, float beta2,
+                       float eps, float* step, float* gnorm_out, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,10 +76,13 @@ SIGNATURES = {
     "rbr_textcnn_bwd_dtable": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p,
                                          c_f32p, c_stream]),
     "rbr_textcnn_bwd_prod_ws_bytes": (C.c_size_t, [_DESC]),
-    "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
-                                              c_f32p, c_stream]),
+    "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
+                                              c_f32p, c_f32p, c_stream]),
     "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,
                                   c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_clip_adam_ws_floats": (C.c_size_t, []),
+    "rbr_clip_adam_step": (C.c_int, [i32, _PP, _PP, _PP, _PP, C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_pair_head_fwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
                                     c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_pair_head_bwd_ws_floats": (C.c_size_t, [i32, i32]),
@@ -160,7 +163,7 @@ def dev_ptr(t: Optional[torch.Tensor], dtype: torch.dtype, name: str) -> Optiona
 
 
 def ptr_array(tensors: Sequence[torch.Tensor], dtype: torch.dtype, name: str):
-    arr = (C.c_void_p * RBR_MAX_WIDTHS)()
+    arr = (C.c_void_p * max(RBR_MAX_WIDTHS, len(tensors)))()
     for i, t in enumerate(tensors):
         arr[i] = dev_ptr(t, dtype, f"{name}[{i}]")
     return arr

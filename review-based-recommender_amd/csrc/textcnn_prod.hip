@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
 // ~6.5 rows of f32 atomics per token in the window scatter.
 struct ProdBwdArgs {
     int n_docs, L, C, KF, KG, D, cap, padding_idx, pad_mode, act;
+    int t_pitch;                    // floats per row of the forward's product table T (gated convs: d(gate) reads it)
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
 };
@@ -224,11 +225,14 @@ __global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict_
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// one thread per (doc, channel, tap)
+// one thread per (doc, channel, tap).  Gated convs (D-ATT: x = gate[doc,p] * table[id]): the token's share is g * gate, and
+// d(gate[doc,p]) += g * <W[c,:,j], table[id]> = g * T[token][(w,j,c)], read from the forward's product table.
 __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const long long* __restrict__ ids,
-                                                      const unsigned char* __restrict__ mask, const int* __restrict__ row_of_token,
+                                                      const unsigned char* __restrict__ mask, const float* __restrict__ gate,
+                                                      const int* __restrict__ row_of_token, const float* __restrict__ T,
                                                       const float* __restrict__ feat, const int* __restrict__ argmax,
-                                                      const float* __restrict__ d_feat, float* __restrict__ G) {
+                                                      const float* __restrict__ d_feat, float* __restrict__ G,
+                                                      float* __restrict__ dgate) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const long o = e / A.KF;
     const int j = (int)(e - o * A.KF);
@@ -248,9 +252,12 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
     const long tok = (long)doc * A.L + p;
     if (mask != nullptr && !mask[tok]) return;          // masked token: x was zeroed, no gradient
     const long long t = ids[tok];
-    if (t == A.padding_idx) return;                     // nn.Embedding(padding_idx): that row gets no gradient
     const int row = row_of_token[t];
-    if (row >= 0) atomicAdd(G + (long)row * A.KG + A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]), g);
+    if (row < 0) return;
+    const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
+    if (dgate != nullptr) atomicAdd(dgate + tok, g * T[(long)row * A.t_pitch + col]);
+    if (t == A.padding_idx || G == nullptr) return;     // nn.Embedding(padding_idx): that row gets no gradient
+    atomicAdd(G + (long)row * A.KG + col, (gate != nullptr) ? g * gate[tok] : g);
 }
 
 constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of the table row
@@ -452,12 +459,14 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
-extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
+extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                            const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
-                                           void* bwd_ws, float* dtable, void* stream) {
+                                           void* bwd_ws, float* dtable, float* dgate, void* stream) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
-    if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (dgate != nullptr && gate == nullptr) dgate = nullptr;
+    if (dtable == nullptr && dgate == nullptr) return 0;
+    if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
     ProdLayout Lo;
     ProdBwdLayout B;
@@ -468,22 +477,32 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     const long long* tok_of_row = reinterpret_cast<const long long*>(fbase + Lo.tok_of_row);
     const int* counter = reinterpret_cast<const int*>(fbase + Lo.counter);
     const float* WT = reinterpret_cast<const float*>(fbase + Lo.wt);     // Wprod^T, written by the forward's stage 1
+    const float* T = reinterpret_cast<const float*>(fbase + Lo.table_T);  // product table, still intact
     float* G = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + B.G);
 
     ProdBwdArgs A{};
     A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.KG = B.KG; A.D = d->D; A.cap = Lo.cap;
     A.padding_idx = d->padding_idx; A.pad_mode = d->pad_mode; A.act = d->act; A.n_widths = d->n_widths;
+    {
+        ConvPlan pp[kMaxGroups];
+        if (!build_plans(&Lo.dp, pp, kProdGroupTiles)) return RBR_ERR_BAD_ARG;
+        A.t_pitch = pp[0].nslots_total;
+    }
     int cp_real = 0;
     for (int w = 0; w < d->n_widths; ++w) {
         A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
         A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
     }
-    hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
-    RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+    if (dtable != nullptr) {
+        hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
+        RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+    }
     const long n_items = (long)d->n_docs * A.C * A.KF;
     hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
-                       reinterpret_cast<const long long*>(ids), mask, row_of_token, feat, argmax, d_feat, G);
+                       reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat,
+                       dtable != nullptr ? G : nullptr, dgate);
     RBR_CHECK_LAUNCH("textcnn build_g launch");
+    if (dtable == nullptr) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
                        tok_of_row, dtable);

@@ -149,16 +149,16 @@ class _TextCNN(torch.autograd.Function):
         if ev is not None:
             ev.record()
         ev = TIMER.record("textcnn_bwd_dtable")
-        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if (ctx.prod_ws is not None and gate is None) else 0
-        if need_table and bws_bytes:
+        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if ctx.prod_ws is not None else 0
+        if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
-            # table); the gated variant (D-ATT) also needs d(gate) and keeps the scatter kernel
+            # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
             bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
             check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                 dev_ptr(feat, F32, "feat"),
+                                                 dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
                                                  dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"), st),
-                  "rbr_textcnn_bwd_dtable_prod")
+                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"),
+                                                 dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)

@@ -20,19 +20,112 @@ MAX_GRAD_NORM = 5.0  # default_deepconn_pp.json:27
 
 
 def make_optimizer(model: nn.Module, lr: float = LR, fused: bool | None = None,
-                   capturable: bool = False) -> torch.optim.Optimizer:
+                   capturable: bool = False, hip_clip_adam: bool = False) -> torch.optim.Optimizer:
     """torch.optim.Adam(model.parameters(), lr=args.lr)  (train_deepconn_pp.py:135).
 
     `fused=None` picks torch's single-kernel ("fused") Adam implementation when every parameter lives on
     a HIP device and the default multi-kernel one otherwise; both compute the same update.
     `capturable=True` keeps the step counter on the device so the update can be recorded into a hipGraph
-    (GraphedTrainStep)."""
+    (GraphedTrainStep).  `hip_clip_adam=True` returns HipClipAdam instead: same update, with the trainer's
+    clip_grad_norm_ folded into the optimizer pass (train_step() then calls its clip_and_step)."""
     params = list(model.parameters())
+    if hip_clip_adam:      # clip + Adam as two HIP launches (HipClipAdam below); always graph-capturable
+        return HipClipAdam(params, lr=lr)
     if fused is None:
         fused = len(params) > 0 and all(p.is_cuda for p in params)
     if fused:
         return torch.optim.Adam(params, lr=lr, fused=True, capturable=capturable)
     return torch.optim.Adam(params, lr=lr, capturable=capturable)
+
+
+class HipClipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr)  +  the clip_grad_norm_ in front of its step  (train_deepconn_pp.py:135,166-167)
+    as two HIP launches over all parameter tensors (csrc/clip_adam.hip): torch's sequence is ~10 kernels and three
+    full passes over the gradients, dominated by the 60 MB word table.
+
+    Same update rule and state names as torch.optim.Adam (amsgrad / weight_decay / maximize unsupported, as the
+    reference trainers never set them); `state_dict()` interchanges with it.  The step counter lives on the device,
+    so `clip_and_step` can be recorded into a hipGraph.  Parameters must be contiguous fp32 HIP tensors."""
+
+    MAX_TENSORS = 64      # RBR_OPT_MAX_TENSORS
+
+    def __init__(self, params, lr: float = LR, betas=(0.9, 0.999), eps: float = 1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._ws = None
+        self._gnorm = None
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def clip_and_step(self, max_grad_norm: float | None = None) -> torch.Tensor:
+        """Clips the gradients of ALL parameter groups to a total 2-norm of `max_grad_norm` (None: no clipping),
+        applies the Adam update, leaves the clipped gradients in .grad and returns the norm before clipping."""
+        import ctypes as C
+        from . import _lib
+        L_ = _lib.lib()
+        todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not todo:
+            raise RuntimeError("HipClipAdam.clip_and_step: no gradients")
+        dev = todo[0][1].device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = torch.empty(L_.rbr_clip_adam_ws_floats(), dtype=torch.float32, device=dev)
+            self._gnorm = torch.zeros((), dtype=torch.float32, device=dev)
+        st = _lib.current_stream()
+        # one launch pair per parameter group and per 64 tensors; the common case (17 tensors, one group) is one pair.
+        # With several pairs the norm must still be global: a first sweep with lr = 0 would be wasteful, so more than
+        # one pair is only allowed without clipping.
+        batches = []
+        for g in self.param_groups:
+            ps = [p for gg, p in todo if gg is g]
+            for k in range(0, len(ps), self.MAX_TENSORS):
+                batches.append((g, ps[k:k + self.MAX_TENSORS]))
+        if len(batches) > 1 and max_grad_norm is not None:
+            raise RuntimeError(f"HipClipAdam clips one group of <= {self.MAX_TENSORS} tensors; got {len(batches)} batches")
+        for g, ps in batches:
+            states = [self._state_of(p) for p in ps]
+            step = states[0]["step"]
+            for s_ in states[1:]:          # the tensors of a batch step together: one shared device counter
+                if s_["step"] is not step:
+                    s_["step"] = step
+            grads = [p.grad for p in ps]
+            for p, gr in zip(ps, grads):
+                if not (p.is_contiguous() and gr.is_contiguous()):
+                    raise RuntimeError("HipClipAdam needs contiguous parameters and gradients")
+            numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
+            b1, b2 = g["betas"]
+            _lib.check(L_.rbr_clip_adam_step(len(ps), _lib.ptr_array(ps, torch.float32, "param"),
+                                             _lib.ptr_array(grads, torch.float32, "grad"),
+                                             _lib.ptr_array([s_["exp_avg"] for s_ in states], torch.float32, "exp_avg"),
+                                             _lib.ptr_array([s_["exp_avg_sq"] for s_ in states], torch.float32, "exp_avg_sq"),
+                                             numel, float(max_grad_norm) if max_grad_norm is not None else 0.0,
+                                             float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                             _lib.dev_ptr(step, torch.float32, "step"),
+                                             _lib.dev_ptr(self._gnorm, torch.float32, "gnorm"),
+                                             _lib.dev_ptr(self._ws, torch.float32, "ws"), st), "rbr_clip_adam_step")
+        return self._gnorm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """Plain Adam step (no clipping), for callers that clip separately."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.clip_and_step(None)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():      # torch.optim.Adam checkpoints hold a CPU float / int step
+            if "step" in st and (not torch.is_tensor(st["step"]) or not st["step"].is_cuda):
+                dev = st["exp_avg"].device
+                st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=dev)
 
 
 def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, ratings: torch.Tensor,
@@ -47,9 +140,18 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     loss.backward()
     if grad_sync is not None:
         grad_sync(model)
+    gnorm = clip_and_step(model, optimizer, max_grad_norm)
+    return loss.detach(), gnorm, pred.detach()
+
+
+def clip_and_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_grad_norm: float) -> torch.Tensor:
+    """clip_grad_norm_(model.parameters(), max_grad_norm); optimizer.step()  (train_deepconn_pp.py:166-167).
+    Returns the total gradient norm before clipping."""
+    if isinstance(optimizer, HipClipAdam):
+        return optimizer.clip_and_step(max_grad_norm)
     gnorm = nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
     optimizer.step()
-    return loss.detach(), gnorm, pred.detach()
+    return gnorm
 
 
 class GraphedTrainStep:
@@ -100,8 +202,7 @@ class GraphedTrainStep:
             grad_sync(model)
             self.g_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool()):
-                self.gnorm = nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
-                optimizer.step()
+                self.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
             for p, v in zip(model.parameters(), saved_params):
                 p.copy_(v)

@@ -1,0 +1,69 @@
+"""HipClipAdam (csrc/clip_adam.hip) against torch's clip_grad_norm_ + Adam on the same parameters and gradients."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(5003, 37), (64, 300, 3), (1,), (7,), (130,), (4096,), (33, 5)]
+    return [torch.randn(s, generator=g).to(dev).requires_grad_(True) for s in shapes]
+
+
+@pytest.mark.parametrize("max_norm", [5.0, 1e6, None])
+def test_clip_adam_matches_torch(max_norm):
+    from review_based_recommender_amd.train_step import HipClipAdam
+    dev = torch.device("cuda", 0)
+    pa, pb = _params(dev, 0), _params(dev, 0)
+    oa = torch.optim.Adam(pa, lr=2e-3)
+    ob = HipClipAdam(pb, lr=2e-3)
+    gen = torch.Generator().manual_seed(1)
+    for step in range(5):
+        # gradients: dense noise, a mostly-zero "embedding" gradient, and one view at an odd offset of a flat buffer
+        flat = torch.randn(7 + 130 + 3, generator=gen).to(dev)
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(a.shape, generator=gen).to(dev) * (10.0 if step == 2 else 0.1)
+            if k == 0:
+                gr[torch.rand(a.shape[0], generator=gen).to(dev) < 0.7] = 0
+            if k == 3:
+                gr = flat[3:10].view_as(a)          # 4-byte aligned only
+            a.grad, b.grad = gr.clone(), gr.clone() if k != 3 else flat.clone()[3:10].view_as(b)
+        if max_norm is not None:
+            ref_norm = torch.nn.utils.clip_grad_norm_(pa, max_norm)
+        else:
+            ref_norm = torch.linalg.vector_norm(torch.stack([p.grad.norm() for p in pa]))
+        oa.step()
+        got_norm = ob.clip_and_step(max_norm)
+        torch.cuda.synchronize()
+        assert abs(float(got_norm) - float(ref_norm)) <= 2e-6 * float(ref_norm)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a.grad, b.grad, rtol=2e-6, atol=1e-9)          # clipped gradients are left behind
+            # rounding-level gradient differences can flip +-lr on near-zero gradients: compare with a small absolute slack
+            assert float((a - b).abs().max()) <= 2e-6 + 1e-3 * 2e-3
+        assert float(ob.state[pb[0]]["step"]) == step + 1
+
+
+def test_state_dict_interchanges_with_torch_adam():
+    from review_based_recommender_amd.train_step import HipClipAdam
+    dev = torch.device("cuda", 0)
+    pa, pb = _params(dev, 3), _params(dev, 3)
+    oa = torch.optim.Adam(pa, lr=2e-3)
+    for p in pa:
+        p.grad = torch.ones_like(p)
+    oa.step()
+    ob = HipClipAdam(pb, lr=2e-3)
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))      # load_state_dict keeps same-device tensors by reference
+    for a, b in zip(pa, pb):
+        b.data.copy_(a.data)
+        a.grad = torch.full_like(a, 0.5)
+        b.grad = torch.full_like(b, 0.5)
+    oa.step()
+    ob.clip_and_step(None)
+    torch.cuda.synchronize()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    sd = ob.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
