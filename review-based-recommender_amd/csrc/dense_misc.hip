@@ -25,6 +25,8 @@ struct Epi {
     int relu;
 };
 
+// The next K chunk's global loads are issued into registers before the current chunk's MFMAs, so their latency hides
+// behind the LDS reads and the matrix pipe (these GEMMs have only ~64 workgroups: nothing else would hide it).
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long sam, long sak,
                                                    const float* __restrict__ B, long sbn, long sbk, float* __restrict__ C,
                                                    long ldc, const Epi ep) {
@@ -37,23 +39,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += GK) {
-        __syncthreads();
+    // element e = tid + 256 q of a 64 x GK chunk: lanes run along the contiguous dimension of the operand
+    int arow[8], akk[8], brow[8], bkk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * q;
+        arow[q] = (sak == 1) ? e / GK : e % 64; akk[q] = (sak == 1) ? e % GK : e / 64;
+        brow[q] = (sbk == 1) ? e / GK : e % 64; bkk[q] = (sbk == 1) ? e % GK : e / 64;
+    }
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q;
-            {   // A: lanes along the contiguous dimension
-                const int row = (sak == 1) ? e / GK : e % 64, kk = (sak == 1) ? e % GK : e / 64;
-                const int m = m0 + row, k = k0 + kk;
-                As[row * GS + kk] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-            }
-            {
-                const int row = (sbk == 1) ? e / GK : e % 64, kk = (sbk == 1) ? e % GK : e / 64;
-                const int n = n0 + row, k = k0 + kk;
-                Bs[row * GS + kk] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
-            }
+            const int m = m0 + arow[q], ka = k0 + akk[q];
+            ra[q] = (m < M && ka < K) ? A[m * sam + ka * sak] : 0.f;
+            const int n = n0 + brow[q], kb = k0 + bkk[q];
+            rb[q] = (n < N && kb < K) ? B[n * sbn + kb * sbk] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads();       // previous chunk's LDS reads are done
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            As[arow[q] * GS + akk[q]] = ra[q];
+            Bs[brow[q] * GS + bkk[q]] = rb[q];
         }
         __syncthreads();
+        if (k0 + GK < K) fetch(k0 + GK);
         const float* pa = As + (wm * 32 + i) * GS + 4 * h;
         const float* pb = Bs + (wn * 32 + i) * GS + 4 * h;
 #pragma unroll
@@ -104,13 +117,27 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long n, const float* __res
     }
 }
 
-// db[n] = sum_m g[m, n]   (fixed order)
+// db[n] = sum_m g[m, n]   (fixed order).  64 columns per workgroup, the rows split over its four waves (8 loads in
+// flight per thread), partial sums met in LDS in wave order.
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ g, float* __restrict__ db) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float s_part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += g[(long)m * N + n];
-    db[n] = s;
+    if (n < N) {
+        int m = wave;
+        for (; m + 28 < M; m += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = g[(long)(m + 4 * u) * N + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; m < M; m += 4) s += g[(long)m * N + n];
+    }
+    s_part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) db[n] = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------ embedding
@@ -216,7 +243,7 @@ extern "C" int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x
     // dW[OUT, IN] = g^T[OUT, N] . x[N, IN]:  A(m=o, k=n) = g[n*OUT + o], B(n=i, k=n) = x[n*IN + i]
     if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st)) return e;
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((OUT + 255) / 256), dim3(256), 0, st, N, OUT, g, db);
+        hipLaunchKernelGGL(colsum_kernel, dim3((OUT + 63) / 64), dim3(256), 0, st, N, OUT, g, db);
         RBR_CHECK_LAUNCH("linear colsum launch");
     }
     // d_x[N, IN] = g[N, OUT] . W[OUT, IN]:  A(m=n, k=o) = g[n*OUT + o], B(n=i, k=o) = W[o*IN + i]
