@@ -211,7 +211,8 @@ int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids
                              const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                              float* db0, float* dtable, float* ws, void* stream);
 
-/* ---- nn.Linear (+ReLU, + dropout multiplier) on the f32 MFMA pipe: y = (relu?)(x @ W^T + b) * drop
+/* ---- nn.Linear (+ReLU / Tanh, + dropout multiplier) on the f32 MFMA pipe: y = act(x @ W^T + b) * drop
+ *      (`relu`: 0 none, 1 ReLU, 2 Tanh -- SimpleSiamese's latent_transform_layer, simple_siamese.py:24-26)
  *      replaces D-ATT's shared fc (dual_att/dual_att.py:31-35,51,57) and HierPooling's projection
  *      (deepconn/layers.py:76-79,96).  x [N,IN], W [OUT,IN] (torch layout), b [OUT] or NULL,
  *      drop [N,OUT] multiplier or NULL, y [N,OUT].
@@ -239,6 +240,28 @@ int rbr_hier_pool_fwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int
 int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int64_t* ids, const uint8_t* mask,
                       const int32_t* argmax, const float* pooled, const float* d_pooled, int32_t relu, int32_t pad_idx,
                       float* dtable, void* stream);
+
+/* ---- SimpleSiamese encoder (models/simple_siamese/simple_siamese.py:57-74).
+ *      review_bag: WordEmbedding -> VariationalDropout -> MaskedAvgPooling1d (layers.py:24-50,53-68,90-110) in one pass:
+ *        out[r, :] = drop[r, :] * sum_l mask[r,l] * table[ids[r,l], :] / (sum_l mask[r,l] + 1e-8)
+ *        ids [n_rev, T] int64, mask [n_rev, T] or NULL, drop [n_rev, D] multiplier or NULL, out [n_rev, D],
+ *        inv_len [n_rev] (kept for the backward).  Backward: dtable ACCUMULATED, row padding_idx excluded.
+ *      additive_attn: NodeDropout + AddictiveAttention (layers.py:7-22,171-197) for B users / items with R reviews each:
+ *        x = node_drop[b,r] * rev[b,r,:];  t = tanh(x Wp^T + bp);  s = softmax_r(masked_fill(<t, wi>, ~mask, -1e8));
+ *        out[b,:] = sum_r s[r] x[r,:].   rev [B,R,H], mask [B,R] or NULL, node_drop [B,R] or NULL, Wp [K,H], bp [K],
+ *        wi [K]; scores [B,R] and t_out [B,R,K] are kept for the backward, which overwrites d_rev, d_Wp, d_bp, d_wi.
+ *        R <= 64; ws: rbr_additive_attn_bwd_ws_floats(B,R,H,K) floats.                                     ---- */
+int rbr_review_bag_fwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* table,
+                       const float* drop, float* out, float* inv_len, void* stream);
+int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* drop,
+                       const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable, void* stream);
+int rbr_additive_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t K, const float* rev, const uint8_t* mask,
+                          const float* node_drop, const float* Wp, const float* bp, const float* wi, float* out, float* scores,
+                          float* t_out, void* stream);
+size_t rbr_additive_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t K);
+int rbr_additive_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t K, const float* rev, const uint8_t* mask,
+                          const float* node_drop, const float* Wp, const float* wi, const float* scores, const float* t_in,
+                          const float* d_out, float* d_rev, float* d_Wp, float* d_bp, float* d_wi, float* ws, void* stream);
 
 /* ---- clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step()  (trainer/train_deepconn_pp.py:166-167;
  *      optimizer of :135: lr only, betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), two launches over all

@@ -208,6 +208,57 @@ def datt_forward(p: Params, u_docs, i_docs, dropout_p: float = 0.0, training: bo
 
 
 # --------------------------------------------------------------------------- train step
+# --------------------------------------------------------------------------- SimpleSiamese
+def masked_avg_pool(x_nlc: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """models/simple_siamese/layers.py:90-110 -- sum of the unmasked rows / (count + 1e-8).  [n, D]."""
+    fm_ = mask.unsqueeze(-1).float()
+    return (x_nlc * fm_).sum(dim=1) / (fm_.sum(dim=1) + 1e-8)
+
+
+def additive_attention(x, mask, proj_w, proj_b, inner_w):
+    """models/simple_siamese/layers.py:171-197 -- logits = inner(tanh(proj(x))); masked softmax over the reviews
+    (masked_fill -1e8: a row with no valid review becomes uniform); weighted sum.  Returns ([B,H], [B,R,1])."""
+    logits = F.linear(torch.tanh(F.linear(x, proj_w, proj_b)), inner_w)            # [B,R,1]
+    scores = F.softmax(torch.masked_fill(logits, ~mask.unsqueeze(2), -1e8), dim=1)
+    return torch.sum(scores * x, dim=1), scores
+
+
+def siamese_forward(p: Params, u_revs, i_revs, u_word_masks, i_word_masks, u_rev_masks, i_rev_masks, u_ids, i_ids,
+                    dropout_p: float = 0.0, word_dropout_p: float = 0.0, review_dropout_p: float = 0.0,
+                    training: bool = False):
+    """models/simple_siamese/simple_siamese.py:38-87 -- bag-of-embeddings reviews (variational word dropout, masked
+    average), optional Linear+Tanh, review (node) dropout, additive attention over reviews shared by both towers,
+    LastFeat, FM (with or without user / item biases).  Returns (pred [B], u_scores, i_scores)."""
+    table = p["word_embedding.embedding.weight"]
+    B = u_revs.shape[0]
+    lt = "latent_transform_layer.0.weight" in p
+
+    def tower(revs, wmask, rmask):
+        _, R, T = revs.shape
+        e = word_embedding(table, revs).view(B * R, T, -1)
+        if training and word_dropout_p > 0:                                     # layers.py:24-50: one mask per (review, dim)
+            e = e * F.dropout(torch.ones(B * R, e.shape[-1]), word_dropout_p, True).unsqueeze(1)
+        r = masked_avg_pool(e, wmask.view(B * R, T)).view(B, R, -1)
+        if lt:
+            r = torch.tanh(F.linear(r, p["latent_transform_layer.0.weight"], p["latent_transform_layer.0.bias"]))
+        if training and review_dropout_p > 0:                                   # layers.py:7-22: one mask per review
+            r = r * F.dropout(torch.ones(B, R), review_dropout_p, True).unsqueeze(2)
+        return additive_attention(r, rmask, p["review_att_layer.proj_layer.0.weight"],
+                                  p["review_att_layer.proj_layer.0.bias"], p["review_att_layer.inner_product.weight"])
+
+    uf, us = tower(u_revs, u_word_masks, u_rev_masks)
+    itf, is_ = tower(i_revs, i_word_masks, i_rev_masks)
+    ul = last_feat(uf, u_ids, p["user_last_feat_layer.W"], p["user_last_feat_layer.b"], p["user_last_feat_layer.ebd.weight"])
+    il = last_feat(itf, i_ids, p["item_last_feat_layer.W"], p["item_last_feat_layer.b"], p["item_last_feat_layer.ebd.weight"])
+    if "fm.user_bias.weight" in p:
+        pred = fm(ul, il, u_ids, i_ids, p["fm.h"], p["fm.g_bias"], p["fm.user_bias.weight"], p["fm.item_bias.weight"],
+                  dropout_p, training)
+    else:                                                                       # FMWithoutUIBias, layers.py:263-297
+        z = F.dropout(F.relu(ul * il), dropout_p, training)
+        pred = z @ p["fm.h"] + p["fm.g_bias"]
+    return pred.view(-1), us, is_
+
+
 def train_steps(params: Params, forward_fn, ratings, n_steps: int = 1, lr: float = 2e-3, max_grad_norm: float = 5.0):
     """trainer/train_deepconn_pp.py:161-168 -- zero_grad, forward, MSELoss(mean), backward,
     clip_grad_norm_(max_grad_norm), Adam(lr).  `forward_fn(p) -> pred`.

@@ -22,7 +22,7 @@ constexpr int GK = 32, GS = 36;
 struct Epi {
     const float* bias;   // [N] or null
     const float* mul;    // [M,N] multiplier (dropout) or null
-    int relu;
+    int relu;            // activation: 0 none, 1 ReLU, 2 Tanh
 };
 
 // The next K chunk's global loads are issued into registers before the current chunk's MFMAs, so their latency hides
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < M) {
             float v = acc[r] + bv;
-            if (ep.relu) v = fmaxf(v, 0.f);
+            if (ep.relu == 1) v = fmaxf(v, 0.f);
+            else if (ep.relu == 2) v = tanhf(v);
             if (ep.mul) v *= ep.mul[(long)m * N + n];
             C[(long)m * ldc + n] = v;
         }
@@ -108,10 +109,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long n, const float* __res
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
         float v = dy[k];
         if (mul) v *= mul[k];
-        if (relu) {
+        if (relu == 1) {
             // y = relu(z) * mul: z > 0  <=>  y != 0 unless mul == 0 (then v is already 0)
             const bool pos = mul ? (y[k] != 0.f) : (y[k] > 0.f);
             if (!pos) v = 0.f;
+        } else if (relu == 2) {
+            // y = tanh(z) * mul: tanh(z) = y / mul where mul != 0 (mul == 0: v is already 0)
+            const float t = mul ? (mul[k] != 0.f ? y[k] / mul[k] : 0.f) : y[k];
+            v *= 1.f - t * t;
         }
         out[k] = v;
     }

@@ -1,0 +1,288 @@
+// review_bag.hip -- the SimpleSiamese encoder (models/simple_siamese/simple_siamese.py:57-74):
+//   * bag of embeddings per review: WordEmbedding -> VariationalDropout (one mask per (review, dim)) -> MaskedAvgPooling1d
+//     (layers.py:24-50, 53-68, 90-110): out[r, :] = drop[r, :] * sum_l mask[r,l] * table[ids[r,l], :] / (sum_l mask[r,l] + 1e-8)
+//     -- a pure HBM-bound row gather, no contraction;
+//   * AddictiveAttention over the reviews of a user / item (layers.py:171-197), with NodeDropout (layers.py:7-22) folded in:
+//     x = node_drop[b,r] * rev[b,r,:];  t = tanh(x Wp^T + bp);  logit = <t, wi>;  s = softmax_r(masked_fill(logit, -1e8));
+//     out[b,:] = sum_r s[r] x[r,:].
+// Nothing of shape [reviews, tokens, D] is ever written to HBM (the reference materialises it twice per tower).
+#include "rbr_common.h"
+
+#include <algorithm>
+
+namespace rbr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------ bag forward
+// one wave per review; lanes own float4 columns of the embedding (scalar columns when D % 4 != 0)
+__global__ __launch_bounds__(256) void bag_fwd_kernel(int n_rev, int T, int D, const long long* __restrict__ ids,
+                                                      const unsigned char* __restrict__ mask, const float* __restrict__ table,
+                                                      const float* __restrict__ drop, float* __restrict__ out,
+                                                      float* __restrict__ inv_len) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerWG + wave;
+    if (r >= n_rev) return;
+    const long long* rid = ids + (long)r * T;
+    const unsigned char* rm = mask ? mask + (long)r * T : nullptr;
+    int cnt = 0;
+    for (int l = lane; l < T; l += 64) cnt += (rm == nullptr || rm[l]) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    const float inv = 1.f / ((float)cnt + 1e-8f);
+    if (lane == 0) inv_len[r] = inv;
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)table) & 15) == 0);
+    if (vec) {
+        const int nq4 = D >> 2;
+        for (int q0 = 0; q0 < nq4; q0 += 64) {
+            const int q4 = q0 + lane;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (q4 < nq4) {
+                for (int l0 = 0; l0 < T; l0 += 4) {          // 4 independent row reads in flight
+                    f32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int l = l0 + u;
+                        const bool ok = l < T && (rm == nullptr || rm[l]);
+                        v[u] = ok ? *reinterpret_cast<const f32x4*>(table + rid[l] * (long)D + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    acc += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                f32x4 o = acc * inv;
+                if (drop != nullptr) o = o * *reinterpret_cast<const f32x4*>(drop + (long)r * D + 4 * q4);
+                *reinterpret_cast<f32x4*>(out + (long)r * D + 4 * q4) = o;
+            }
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+            for (int l = 0; l < T; ++l)
+                if (rm == nullptr || rm[l]) acc += table[rid[l] * (long)D + d];
+            float o = acc * inv;
+            if (drop != nullptr) o *= drop[(long)r * D + d];
+            out[(long)r * D + d] = o;
+        }
+    }
+}
+
+// dtable[ids[r,l], :] += mask * drop[r,:] * d_out[r,:] * inv_len[r]   (rows of padding_idx get nothing)
+__global__ __launch_bounds__(256) void bag_bwd_kernel(int n_rev, int T, int D, const long long* __restrict__ ids,
+                                                      const unsigned char* __restrict__ mask, const float* __restrict__ drop,
+                                                      const float* __restrict__ inv_len, const float* __restrict__ d_out,
+                                                      int padding_idx, float* __restrict__ dtable) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * kWavesPerWG + wave;
+    if (r >= n_rev) return;
+    const long long* rid = ids + (long)r * T;
+    const unsigned char* rm = mask ? mask + (long)r * T : nullptr;
+    const float inv = inv_len[r];
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float g = 0.f;
+        if (d < D) {
+            g = d_out[(long)r * D + d] * inv;
+            if (drop != nullptr) g *= drop[(long)r * D + d];
+        }
+        for (int l = 0; l < T; ++l) {
+            if (rm != nullptr && !rm[l]) continue;          // wave-uniform
+            const long long t = rid[l];
+            if (t == padding_idx) continue;
+            if (d < D) atomicAdd(dtable + t * (long)D + d, g);     // 256 contiguous bytes per wave instruction
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ additive attention
+constexpr int kAttMaxR = 64;      // reviews per user / item
+
+// one workgroup per (user | item) row b.  LDS: x [R,H] (node dropout applied), t [R,K], logits / scores [R]
+__global__ __launch_bounds__(256) void addatt_fwd_kernel(int B, int R, int H, int K, const float* __restrict__ rev,
+                                                         const unsigned char* __restrict__ mask, const float* __restrict__ node_drop,
+                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                         const float* __restrict__ wi, float* __restrict__ out,
+                                                         float* __restrict__ scores, float* __restrict__ t_out) {
+    extern __shared__ float sm[];
+    float* x = sm;                   // [R][H]
+    float* t = x + R * H;            // [R][K]
+    float* lg = t + R * K;           // [R]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < R * H; e += 256) {
+        const int r = e / H;
+        float v = rev[(long)b * R * H + e];
+        if (node_drop != nullptr) v *= node_drop[(long)b * R + r];
+        x[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < R * K; e += 256) {
+        const int r = e / K, k = e - r * K;
+        float acc = bp[k];
+        const float* wrow = Wp + (long)k * H;
+        for (int h = 0; h < H; ++h) acc = fmaf(x[r * H + h], wrow[h], acc);
+        const float tv = tanhf(acc);
+        t[e] = tv;
+        t_out[(long)b * R * K + e] = tv;
+    }
+    __syncthreads();
+    if (tid < R) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(t[tid * K + k], wi[k], acc);
+        lg[tid] = (mask == nullptr || mask[(long)b * R + tid]) ? acc : -1e8f;       // masked_fill(~mask, -1e8)
+    }
+    __syncthreads();
+    if (tid == 0) {      // R <= 64: a serial softmax in the reference's order of operations (max, exp, sum, divide)
+        float mx = lg[0];
+        for (int r = 1; r < R; ++r) mx = fmaxf(mx, lg[r]);
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) { lg[r] = expf(lg[r] - mx); s += lg[r]; }
+        const float is = 1.f / s;
+        for (int r = 0; r < R; ++r) { lg[r] *= is; scores[(long)b * R + r] = lg[r]; }
+    }
+    __syncthreads();
+    for (int h = tid; h < H; h += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(lg[r], x[r * H + h], acc);
+        out[(long)b * H + h] = acc;
+    }
+}
+
+// d_rev [B,R,H], d_pre [B,R,K] (pre-activation gradient, consumed by the dWp GEMM), d_bp / d_wi accumulated by atomics
+__global__ __launch_bounds__(256) void addatt_bwd_kernel(int B, int R, int H, int K, const float* __restrict__ rev,
+                                                         const unsigned char* __restrict__ mask, const float* __restrict__ node_drop,
+                                                         const float* __restrict__ Wp, const float* __restrict__ wi,
+                                                         const float* __restrict__ scores, const float* __restrict__ t_in,
+                                                         const float* __restrict__ d_out, float* __restrict__ d_rev,
+                                                         float* __restrict__ d_pre, float* __restrict__ x_eff,
+                                                         float* __restrict__ d_bp, float* __restrict__ d_wi) {
+    extern __shared__ float sm[];
+    float* x = sm;                   // [R][H]
+    float* dp = x + R * H;           // [R][K]
+    float* dl = dp + R * K;          // [R] d_logit
+    float* dsr = dl + R;             // [R] d_score
+    float* dy = dsr + R;             // [H]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < R * H; e += 256) {
+        const int r = e / H;
+        float v = rev[(long)b * R * H + e];
+        if (node_drop != nullptr) v *= node_drop[(long)b * R + r];
+        x[e] = v;
+        x_eff[(long)b * R * H + e] = v;          // operand of the dWp GEMM
+    }
+    for (int h = tid; h < H; h += 256) dy[h] = d_out[(long)b * H + h];
+    __syncthreads();
+    if (tid < R) {
+        float acc = 0.f;
+        for (int h = 0; h < H; ++h) acc = fmaf(dy[h], x[tid * H + h], acc);
+        dsr[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < R) {
+        float dot = 0.f;
+        for (int r = 0; r < R; ++r) dot = fmaf(scores[(long)b * R + r], dsr[r], dot);
+        const float s = scores[(long)b * R + tid];
+        // masked_fill blocks the gradient of masked logits (also when every review is masked and s is uniform)
+        dl[tid] = (mask == nullptr || mask[(long)b * R + tid]) ? s * (dsr[tid] - dot) : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < R * K; e += 256) {
+        const int r = e / K, k = e - r * K;
+        const float tv = t_in[(long)b * R * K + e];
+        const float g = dl[r] * wi[k] * (1.f - tv * tv);
+        dp[e] = g;
+        d_pre[(long)b * R * K + e] = g;
+    }
+    for (int k = tid; k < K; k += 256) {
+        float gw = 0.f;
+        for (int r = 0; r < R; ++r) gw = fmaf(dl[r], t_in[((long)b * R + r) * K + k], gw);
+        atomicAdd(d_wi + k, gw);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        float gb = 0.f;
+        for (int r = 0; r < R; ++r) gb += dp[r * K + k];
+        atomicAdd(d_bp + k, gb);
+    }
+    for (int e = tid; e < R * H; e += 256) {
+        const int r = e / H, h = e - r * H;
+        float acc = scores[(long)b * R + r] * dy[h];
+        for (int k = 0; k < K; ++k) acc = fmaf(dp[r * K + k], Wp[(long)k * H + h], acc);
+        if (node_drop != nullptr) acc *= node_drop[(long)b * R + r];
+        d_rev[(long)b * R * H + e] = acc;
+    }
+}
+
+// dWp[k, h] = sum_n d_pre[n, k] * x[n, h]    (n = (b, r) rows; one thread per (k, h), fixed order over n)
+__global__ __launch_bounds__(256) void addatt_dw_kernel(int N, int H, int K, const float* __restrict__ d_pre,
+                                                        const float* __restrict__ x, float* __restrict__ d_Wp) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * H) return;
+    const int k = e / H, h = e - k * H;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(d_pre[(long)n * K + k], x[(long)n * H + h], acc);
+    d_Wp[e] = acc;
+}
+
+}  // namespace rbr
+
+using namespace rbr;
+
+extern "C" int rbr_review_bag_fwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* table,
+                                  const float* drop, float* out, float* inv_len, void* stream) {
+    if (n_rev <= 0 || T <= 0 || D <= 0) { set_error("bad shape n_rev=%d T=%d D=%d", n_rev, T, D); return RBR_ERR_BAD_ARG; }
+    if (!ids || !table || !out || !inv_len) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(bag_fwd_kernel, dim3((n_rev + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, (hipStream_t)stream, n_rev, T, D,
+                       reinterpret_cast<const long long*>(ids), mask, table, drop, out, inv_len);
+    RBR_CHECK_LAUNCH("review_bag fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* drop,
+                                  const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable, void* stream) {
+    if (n_rev <= 0 || T <= 0 || D <= 0) { set_error("bad shape n_rev=%d T=%d D=%d", n_rev, T, D); return RBR_ERR_BAD_ARG; }
+    if (!ids || !inv_len || !d_out || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(bag_bwd_kernel, dim3((n_rev + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, (hipStream_t)stream, n_rev, T, D,
+                       reinterpret_cast<const long long*>(ids), mask, drop, inv_len, d_out, padding_idx, dtable);
+    RBR_CHECK_LAUNCH("review_bag bwd launch");
+    return 0;
+}
+
+static bool addatt_ok(int B, int R, int H, int K) {
+    if (B <= 0 || R <= 0 || R > kAttMaxR || H <= 0 || K <= 0) { set_error("bad shape B=%d R=%d (<= %d) H=%d K=%d", B, R, kAttMaxR, H, K); return false; }
+    if ((size_t)(R * H + R * K + 2 * R + H) * sizeof(float) > 64 * 1024) { set_error("R*H + R*K exceeds the LDS budget"); return false; }
+    return true;
+}
+
+extern "C" int rbr_additive_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t K, const float* rev, const uint8_t* mask,
+                                     const float* node_drop, const float* Wp, const float* bp, const float* wi, float* out,
+                                     float* scores, float* t_out, void* stream) {
+    if (!addatt_ok(B, R, H, K)) return RBR_ERR_BAD_ARG;
+    if (!rev || !Wp || !bp || !wi || !out || !scores || !t_out) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const size_t lds = (size_t)(R * H + R * K + R) * sizeof(float);
+    hipLaunchKernelGGL(addatt_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, B, R, H, K, rev, mask, node_drop, Wp, bp, wi,
+                       out, scores, t_out);
+    RBR_CHECK_LAUNCH("additive_attn fwd launch");
+    return 0;
+}
+
+extern "C" size_t rbr_additive_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t K) {
+    return (size_t)B * R * K + (size_t)B * R * H;          // d_pre | x (node dropout applied)
+}
+
+extern "C" int rbr_additive_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t K, const float* rev, const uint8_t* mask,
+                                     const float* node_drop, const float* Wp, const float* wi, const float* scores,
+                                     const float* t_in, const float* d_out, float* d_rev, float* d_Wp, float* d_bp, float* d_wi,
+                                     float* ws, void* stream) {
+    if (!addatt_ok(B, R, H, K)) return RBR_ERR_BAD_ARG;
+    if (!rev || !Wp || !wi || !scores || !t_in || !d_out || !d_rev || !d_Wp || !d_bp || !d_wi || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    float* d_pre = ws;
+    float* x_eff = ws + (size_t)B * R * K;
+    ZeroRegions zr{{reinterpret_cast<int*>(d_bp), reinterpret_cast<int*>(d_wi), nullptr}, {K, K, 0}};
+    if (int e = zero_regions(zr, st)) return e;
+    const size_t lds = (size_t)(R * H + R * K + 2 * R + H) * sizeof(float);
+    hipLaunchKernelGGL(addatt_bwd_kernel, dim3(B), dim3(256), lds, st, B, R, H, K, rev, mask, node_drop, Wp, wi, scores, t_in, d_out,
+                       d_rev, d_pre, x_eff, d_bp, d_wi);
+    RBR_CHECK_LAUNCH("additive_attn bwd launch");
+    hipLaunchKernelGGL(addatt_dw_kernel, dim3((K * H + 255) / 256), dim3(256), 0, st, B * R, H, K, d_pre, x_eff, d_Wp);
+    RBR_CHECK_LAUNCH("additive_attn dW launch");
+    return 0;
+}

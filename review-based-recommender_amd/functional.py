@@ -349,9 +349,129 @@ class _Linear(torch.autograd.Function):
         return d_x, dW, db, None, None
 
 
-def linear(x, W, b=None, *, relu=False, drop=None):
-    """y = (relu)(x @ W^T + b) * drop  with torch's nn.Linear weight layout [OUT, IN]."""
-    return _Linear.apply(x, W, b, relu, drop)
+def linear(x, W, b=None, *, relu=False, drop=None, tanh=False):
+    """y = act(x @ W^T + b) * drop  with torch's nn.Linear weight layout [OUT, IN]; act = ReLU, Tanh or none."""
+    return _Linear.apply(x, W, b, 2 if tanh else int(bool(relu)), drop)
+
+
+# --------------------------------------------------------------------------- SimpleSiamese encoder (SURVEY.md 8 f-4)
+class _ReviewBag(torch.autograd.Function):
+    """out[n_rev, D] = drop * masked mean of table[ids]  -- rbr_review_bag_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, table, ids, mask, drop, padding_idx):
+        dev_ptr(table.contiguous(), F32, "word table")
+        if ids.dim() != 2:
+            raise RuntimeError("ids must be [n_reviews, review_len]")
+        n_rev, T = ids.shape
+        D = table.shape[1]
+        L_ = _lib.lib()
+        table_c, ids = table.contiguous(), ids.contiguous()
+        mask8 = _mask_u8(mask)
+        if mask8 is not None and mask8.shape != ids.shape:
+            raise AssertionError("input_masks must be [n_reviews, review_len]")
+        drop = drop.contiguous() if drop is not None else None
+        out = torch.empty(n_rev, D, dtype=F32, device=table.device)
+        inv_len = torch.empty(n_rev, dtype=F32, device=table.device)
+        check(L_.rbr_review_bag_fwd(n_rev, T, D, dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                    dev_ptr(table_c, F32, "word table"), dev_ptr(drop, F32, "drop"), dev_ptr(out, F32, "out"),
+                                    dev_ptr(inv_len, F32, "inv_len"), current_stream()), "rbr_review_bag_fwd")
+        ctx.dims = (n_rev, T, D, -1 if padding_idx is None else int(padding_idx), tuple(table.shape))
+        ctx.has_mask, ctx.has_drop = mask8 is not None, drop is not None
+        ctx.save_for_backward(ids, inv_len, *([mask8] if mask8 is not None else []), *([drop] if drop is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n_rev, T, D, pad, shape = ctx.dims
+        saved = list(ctx.saved_tensors)
+        ids, inv_len = saved[:2]
+        k = 2
+        mask8 = drop = None
+        if ctx.has_mask:
+            mask8 = saved[k]; k += 1
+        if ctx.has_drop:
+            drop = saved[k]
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        dtable = torch.zeros(shape, dtype=F32, device=d_out.device)
+        d_out = d_out.contiguous()
+        check(_lib.lib().rbr_review_bag_bwd(n_rev, T, D, dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                            dev_ptr(drop, F32, "drop"), dev_ptr(inv_len, F32, "inv_len"),
+                                            dev_ptr(d_out, F32, "d_out"), pad, dev_ptr(dtable, F32, "dtable"),
+                                            current_stream()), "rbr_review_bag_bwd")
+        return dtable, None, None, None, None
+
+
+def review_bag(table, ids, mask, *, drop=None, padding_idx=0):
+    """WordEmbedding -> VariationalDropout (multiplier `drop` [n_rev, D]) -> MaskedAvgPooling1d.  [n_rev, D]."""
+    return _ReviewBag.apply(table, ids, mask, drop, padding_idx)
+
+
+class _AdditiveAttn(torch.autograd.Function):
+    """out[B,H], scores[B,R] = AddictiveAttention(node_drop * rev[B,R,H], mask[B,R])  -- rbr_additive_attn_*."""
+
+    @staticmethod
+    def forward(ctx, rev, mask, node_drop, Wp, bp, wi):
+        if rev.dim() != 3:
+            raise RuntimeError("inputs must be [bz, seq_len, hdim]")
+        B, R, H = rev.shape
+        K = Wp.shape[0]
+        L_ = _lib.lib()
+        rev, Wp, bp, wi = rev.contiguous(), Wp.contiguous(), bp.contiguous(), wi.contiguous().view(-1)
+        mask8 = _mask_u8(mask)
+        if mask8 is not None and mask8.dim() != 2:
+            raise AssertionError("input_masks.dim() == 2")          # simple_siamese/layers.py:189
+        node_drop = node_drop.contiguous() if node_drop is not None else None
+        dev = rev.device
+        out = torch.empty(B, H, dtype=F32, device=dev)
+        scores = torch.empty(B, R, dtype=F32, device=dev)
+        t = torch.empty(B, R, K, dtype=F32, device=dev)
+        check(L_.rbr_additive_attn_fwd(B, R, H, K, dev_ptr(rev, F32, "inputs"), dev_ptr(mask8, U8, "mask"),
+                                       dev_ptr(node_drop, F32, "node_drop"), dev_ptr(Wp, F32, "proj weight"),
+                                       dev_ptr(bp, F32, "proj bias"), dev_ptr(wi, F32, "inner_product weight"),
+                                       dev_ptr(out, F32, "out"), dev_ptr(scores, F32, "scores"), dev_ptr(t, F32, "t"),
+                                       current_stream()), "rbr_additive_attn_fwd")
+        ctx.dims = (B, R, H, K)
+        ctx.has_mask, ctx.has_nd = mask8 is not None, node_drop is not None
+        ctx.wi_shape = None
+        ctx.save_for_backward(rev, Wp, wi, scores, t, *([mask8] if mask8 is not None else []),
+                              *([node_drop] if node_drop is not None else []))
+        ctx.mark_non_differentiable(scores)
+        return out, scores
+
+    @staticmethod
+    def backward(ctx, d_out, _d_scores):
+        B, R, H, K = ctx.dims
+        saved = list(ctx.saved_tensors)
+        rev, Wp, wi, scores, t = saved[:5]
+        k = 5
+        mask8 = node_drop = None
+        if ctx.has_mask:
+            mask8 = saved[k]; k += 1
+        if ctx.has_nd:
+            node_drop = saved[k]
+        L_ = _lib.lib()
+        dev = rev.device
+        d_out = d_out.contiguous()
+        d_rev = torch.empty_like(rev)
+        d_Wp = torch.empty_like(Wp)
+        d_bp = torch.empty(K, dtype=F32, device=dev)
+        d_wi = torch.empty(K, dtype=F32, device=dev)
+        ws = torch.empty(L_.rbr_additive_attn_bwd_ws_floats(B, R, H, K), dtype=F32, device=dev)
+        check(L_.rbr_additive_attn_bwd(B, R, H, K, dev_ptr(rev, F32, "inputs"), dev_ptr(mask8, U8, "mask"),
+                                       dev_ptr(node_drop, F32, "node_drop"), dev_ptr(Wp, F32, "proj weight"),
+                                       dev_ptr(wi, F32, "inner_product weight"), dev_ptr(scores, F32, "scores"),
+                                       dev_ptr(t, F32, "t"), dev_ptr(d_out, F32, "d_out"), dev_ptr(d_rev, F32, "d_inputs"),
+                                       dev_ptr(d_Wp, F32, "d_Wp"), dev_ptr(d_bp, F32, "d_bp"), dev_ptr(d_wi, F32, "d_wi"),
+                                       dev_ptr(ws, F32, "ws"), current_stream()), "rbr_additive_attn_bwd")
+        return d_rev, None, None, d_Wp, d_bp, d_wi.view(1, K)
+
+
+def additive_attention(rev, mask, Wp, bp, wi, *, node_drop=None):
+    """AddictiveAttention over the reviews (+ NodeDropout multiplier [B,R]).  Returns (out [B,H], scores [B,R,1])."""
+    out, scores = _AdditiveAttn.apply(rev, mask, node_drop, Wp, bp, wi)
+    return out, scores.unsqueeze(2)
 
 
 # --------------------------------------------------------------------------- standalone embedding

@@ -1,0 +1,134 @@
+"""Layer mirrors of models/simple_siamese/layers.py (class names, constructor arguments, parameter names and
+initialisation), running on the HIP kernels of csrc/review_bag.hip, csrc/pair_head.hip and csrc/dense_misc.hip."""
+import torch
+import torch.nn as nn
+
+from ... import functional as RF
+from ..deepconn.layers import WordEmbedding as _WordEmbedding
+
+
+class NodeDropout(torch.nn.Dropout):
+    """layers.py:7-22 -- one keep/drop decision per (batch row, node): [bz, seq_len, dim] * mask[bz, seq_len, 1]."""
+
+    def multiplier(self, bz, seq_len, device):
+        return RF.dropout_multiplier((bz, seq_len), self.p, self.training, device)
+
+    def forward(self, input_tensor):
+        m = self.multiplier(input_tensor.shape[0], input_tensor.shape[1], input_tensor.device)
+        return input_tensor if m is None else m.unsqueeze(2) * input_tensor
+
+
+class VariationalDropout(torch.nn.Dropout):
+    """layers.py:24-50 -- one mask per (batch row, embedding dim), shared by every time step."""
+
+    def multiplier(self, bz, dim, device):
+        return RF.dropout_multiplier((bz, dim), self.p, self.training, device)
+
+    def forward(self, input_tensor):
+        m = self.multiplier(input_tensor.shape[0], input_tensor.shape[-1], input_tensor.device)
+        return input_tensor if m is None else m.unsqueeze(1) * input_tensor
+
+
+class WordEmbedding(_WordEmbedding):
+    """layers.py:53-68 (adds the `sparse` flag; sparse gradients are not produced here: the HIP backward is dense)."""
+
+    def __init__(self, vocab_size, embedding_dim, pretrained_embeddings=None, padding_idx=0, freeze_embeddings=False,
+                 sparse=False):
+        super().__init__(vocab_size, embedding_dim, pretrained_embeddings=pretrained_embeddings, padding_idx=padding_idx,
+                         freeze_embeddings=freeze_embeddings)
+        if sparse:
+            raise ValueError("sparse embedding gradients are not supported by the HIP path")
+
+
+class MaskedAvgPooling1d(nn.Module):
+    """layers.py:90-110 -- inputs [bz, hdim, seq_len], masks [bz, seq_len] -> [bz, hdim, 1] = masked sum / (count + 1e-8).
+    Standalone form on materialised rows; the model fuses the lookup and this pooling (RF.review_bag)."""
+
+    def forward(self, inputs, input_masks):
+        assert input_masks.dim() == 2
+        bz, hdim, seq_len = inputs.shape
+        # a [bz*seq_len, hdim] table indexed by position is exactly the bag kernel's input
+        table = inputs.transpose(1, 2).reshape(bz * seq_len, hdim)
+        ids = torch.arange(bz * seq_len, device=inputs.device, dtype=torch.int64).view(bz, seq_len)
+        return RF.review_bag(table, ids, input_masks, padding_idx=None).unsqueeze(2)
+
+
+class AddictiveAttention(nn.Module):
+    """layers.py:171-197 -- tanh projection, inner product, masked softmax over the sequence, weighted sum."""
+
+    def __init__(self, hidden_dim, latent_dim):
+        super().__init__()
+        self.proj_layer = nn.Sequential(nn.Linear(hidden_dim, latent_dim), nn.Tanh())
+        self.inner_product = nn.Linear(latent_dim, 1, bias=False)
+
+    def forward(self, inputs, input_masks, node_drop=None):
+        """inputs [bz, seq_len, hdim], input_masks [bz, seq_len] -> (outputs [bz, hdim], att_scores [bz, seq_len, 1])."""
+        assert input_masks.dim() == 2
+        lin = self.proj_layer[0]
+        return RF.additive_attention(inputs, input_masks, lin.weight, lin.bias, self.inner_product.weight, node_drop=node_drop)
+
+
+class LastFeat(nn.Module):
+    """layers.py:234-261 -- W [feat, latent], b [latent] (init 0), ebd [vocab, latent]; out = feat @ W + b + ebd[id]."""
+
+    def __init__(self, vocab_size, feat_size, latent_dim, padding_idx):
+        super().__init__()
+        self.W = nn.Parameter(torch.Tensor(feat_size, latent_dim))
+        self.b = nn.Parameter(torch.Tensor(latent_dim))
+        self.ebd = nn.Embedding(vocab_size, latent_dim, padding_idx=padding_idx)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.W, -0.1, 0.1)
+        nn.init.constant_(self.b, 0.)
+        nn.init.uniform_(self.ebd.weight, -0.1, 0.1)
+
+
+class FMWithoutUIBias(nn.Module):
+    """layers.py:263-297 -- h [latent,1], g_bias [1] (init 4.0); pred = dropout(relu(u*i)) @ h + g_bias."""
+
+    def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.user_padding_idx, self.item_padding_idx = user_padding_idx, item_padding_idx
+        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
+        self.g_bias = nn.Parameter(torch.Tensor(1))
+        # the head kernel always adds bias rows: frozen zero tables, outside the state_dict
+        self.register_buffer("_zero_user_bias", torch.zeros(user_size, 1), persistent=False)
+        self.register_buffer("_zero_item_bias", torch.zeros(item_size, 1), persistent=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.h, -0.1, 0.1)
+        nn.init.constant_(self.g_bias, 4.0)
+
+
+class FM(nn.Module):
+    """layers.py:299-343 -- FMWithoutUIBias + user_bias [U,1] / item_bias [I,1] embeddings."""
+
+    def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.user_padding_idx, self.item_padding_idx = user_padding_idx, item_padding_idx
+        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
+        self.user_bias = nn.Embedding(user_size, 1, padding_idx=user_padding_idx)
+        self.item_bias = nn.Embedding(item_size, 1, padding_idx=item_padding_idx)
+        self.g_bias = nn.Parameter(torch.Tensor(1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.uniform_(self.h, -0.1, 0.1)
+        nn.init.uniform_(self.user_bias.weight, -0.1, 0.1)
+        nn.init.uniform_(self.item_bias.weight, -0.1, 0.1)
+        nn.init.constant_(self.g_bias, 4.0)
+
+
+def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm, u_text_feat, i_text_feat, u_ids, i_ids):
+    """LastFeat(user) + LastFeat(item) + FM / FMWithoutUIBias in one HIP kernel pair."""
+    drop = RF.dropout_multiplier((u_text_feat.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
+    ub = fm.user_bias.weight if isinstance(fm, FM) else fm._zero_user_bias
+    ib = fm.item_bias.weight if isinstance(fm, FM) else fm._zero_item_bias
+    return RF.pair_head(u_text_feat, i_text_feat, u_ids, i_ids,
+                        user_feat.W, user_feat.b, user_feat.ebd.weight,
+                        item_feat.W, item_feat.b, item_feat.ebd.weight,
+                        fm.h, fm.g_bias, ub, ib, drop=drop, pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)

@@ -188,6 +188,28 @@ def gen_datt(name, edge=False, seed=0):
     return out
 
 
+# ----------------------------------------------------------------------------- SimpleSiamese
+def gen_siamese(name, edge=False, seed=0):
+    from models.simple_siamese.simple_siamese import SimpleSiamese
+    c = synth.SIAMESE_CFGS[name]
+    # dropout rates 0: the fixtures pin the deterministic math (dropout draws cannot match across generators)
+    model = _quiet(SimpleSiamese, c["D"], c["K"], c["V"], c["U"], c["I"], None, False, 0.0, 0.0, 0.0, c["UB"], c["LT"])
+    model.load_state_dict(synth.siamese_params(c, seed))
+    b = synth.siamese_batch(c, seed + 1, edge_cases=edge)
+    args = tuple(b[k] for k in ("u_revs", "i_revs", "u_word_masks", "i_word_masks", "u_rev_masks", "i_rev_masks", "u_ids", "i_ids"))
+    out = {}
+    scores = []
+    hook = model.review_att_layer.register_forward_hook(lambda _m, _i, o: scores.append(_np(o[1])) and None)
+    model.eval()
+    with torch.no_grad():
+        out["pred_eval"] = _np(model(*args)[0])
+    hook.remove()
+    out["u_rev_scores"] = scores[0].reshape(c["B"], c["R"])
+    out["i_rev_scores"] = scores[1].reshape(c["B"], c["R"])
+    run_train_steps(model, lambda: model(*args)[0], b["ratings"], out, big=(name == "toys"))
+    return out
+
+
 def main():
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
@@ -204,6 +226,9 @@ def main():
         ("datt_tiny", lambda: gen_datt("tiny", edge=True)),
         ("datt_small", lambda: gen_datt("small", edge=True)),
         ("datt_cfg4", lambda: gen_datt("cfg4")),
+        ("siamese_tiny", lambda: gen_siamese("tiny", edge=True)),
+        ("siamese_small", lambda: gen_siamese("small", edge=True)),
+        ("siamese_toys", lambda: gen_siamese("toys")),
     ]
     for name, fn in jobs:
         if only and name not in only:

@@ -39,6 +39,14 @@ NARRE_CFGS = {
     "cfg3": dict(B=256, R=10, T=50, D=300, kz=[3], H=150, A=32, K=32, V=50002, U=1001, I=1001),
 }
 
+# SimpleSiamese (models/simple_siamese): bag-of-embeddings reviews + additive attention over reviews.
+# LT: latent_transform (Linear D->K + Tanh per review), UB: use_ui_bias (FM vs FMWithoutUIBias)
+SIAMESE_CFGS = {
+    "tiny": dict(B=3, R=4, T=8, D=8, K=4, V=20, U=5, I=5, LT=False, UB=True),
+    "small": dict(B=5, R=6, T=21, D=20, K=8, V=100, U=20, I=20, LT=True, UB=False),
+    "toys": dict(B=64, R=11, T=50, D=108, K=32, V=50002, U=1001, I=1001, LT=False, UB=True),   # defalut_simple_train.json
+}
+
 DATT_CFGS = {
     "tiny": dict(B=2, L=16, E=6, win=5, l_out=8, g_out=4, h1=10, h2=5, V=20),
     "small": dict(B=4, L=40, E=20, win=5, l_out=24, g_out=12, h1=32, h2=8, V=100),
@@ -132,6 +140,32 @@ def narre_params(cfg, seed=0):
     _lastfeat(rng, sd, "user_feat", c["U"], c["H"], c["K"])
     _lastfeat(rng, sd, "item_feat", c["I"], c["H"], c["K"])
     _fm(rng, sd, c["U"], c["I"], c["K"])
+    return sd
+
+
+def siamese_params(cfg, seed=0):
+    """state_dict of models/simple_siamese/simple_siamese.py:8-36 (reset_parameters bounds of its layers.py)."""
+    rng = np.random.default_rng(seed)
+    c = cfg
+    D, K = c["D"], c["K"]
+    H = K if c["LT"] else D                  # review feature width after the optional latent transform
+    sd = OrderedDict()
+    sd["word_embedding.embedding.weight"] = _word_table(rng, c["V"], D)
+    if c["LT"]:
+        b = 1.0 / math.sqrt(D)
+        sd["latent_transform_layer.0.weight"] = _uniform(rng, (K, D), b)
+        sd["latent_transform_layer.0.bias"] = _uniform(rng, (K,), b)
+    _lastfeat(rng, sd, "user_last_feat_layer", c["U"], H, K)
+    _lastfeat(rng, sd, "item_last_feat_layer", c["I"], H, K)
+    b = 1.0 / math.sqrt(H)
+    sd["review_att_layer.proj_layer.0.weight"] = _uniform(rng, (K, H), b)
+    sd["review_att_layer.proj_layer.0.bias"] = _uniform(rng, (K,), b)
+    sd["review_att_layer.inner_product.weight"] = _uniform(rng, (1, K), 1.0 / math.sqrt(K))
+    sd["fm.h"] = _uniform(rng, (K, 1), 0.1)
+    if c["UB"]:
+        sd["fm.user_bias.weight"] = _uniform(rng, (c["U"], 1), 0.1)
+        sd["fm.item_bias.weight"] = _uniform(rng, (c["I"], 1), 0.1)
+    sd["fm.g_bias"] = torch.full((1,), 0.1)
     return sd
 
 
@@ -264,3 +298,31 @@ def datt_batch(cfg, seed=1, edge_cases=False):
         u[0] = 0
     ratings = rng.integers(1, 6, size=c["B"]).astype(np.float32)
     return dict(u_docs=_t(u, torch.int64), i_docs=_t(i, torch.int64), ratings=_t(ratings))
+
+
+def siamese_batch(cfg, seed=1, edge_cases=False):
+    """u_revs/i_revs [B,R,T] int64, word masks [B,R,T] bool, review masks [B,R] bool, ids [B], ratings."""
+    rng = np.random.default_rng(seed)
+    c = cfg
+    B, R, T, V = c["B"], c["R"], c["T"], c["V"]
+
+    def side():
+        txt = _docs(rng, B * R, T, V).reshape(B, R, T)
+        nrev = rng.integers(1, R + 1, size=B)
+        dead = np.arange(R)[None, :] >= nrev[:, None]     # trailing reviews: all pad
+        txt[dead] = 0
+        return txt
+
+    u_revs, i_revs = side(), side()
+    u_ids = rng.integers(1, c["U"], size=B).astype(np.int64)
+    i_ids = rng.integers(1, c["I"], size=B).astype(np.int64)
+    ratings = rng.integers(1, 6, size=B).astype(np.float32)
+    if edge_cases:
+        u_revs[0] = 0               # a user with no review at all: uniform attention over empty bags
+        u_ids[0] = 0
+    return dict(
+        u_revs=_t(u_revs, torch.int64), i_revs=_t(i_revs, torch.int64),
+        u_word_masks=_t(u_revs != 0, torch.bool), i_word_masks=_t(i_revs != 0, torch.bool),
+        u_rev_masks=_t((u_revs != 0).any(-1), torch.bool), i_rev_masks=_t((i_revs != 0).any(-1), torch.bool),
+        u_ids=_t(u_ids, torch.int64), i_ids=_t(i_ids, torch.int64), ratings=_t(ratings),
+    )

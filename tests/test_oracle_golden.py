@@ -137,3 +137,24 @@ def test_datt_oracle_matches_reference(golden_dir, name, cfgname):
         _close(O.datt_forward(p, b["u_docs"], b["i_docs"]), g["pred_eval"], FWD_TOL, what="pred_eval")
     hist = O.train_steps(p, lambda q: O.datt_forward(q, b["u_docs"], b["i_docs"]), b["ratings"], n_steps=3)
     _check_steps(g, hist, False)
+
+
+SIAMESE_ARGS = ("u_revs", "i_revs", "u_word_masks", "i_word_masks", "u_rev_masks", "i_rev_masks", "u_ids", "i_ids")
+
+
+@pytest.mark.parametrize("name,cfgname,edge", [("siamese_tiny", "tiny", True), ("siamese_small", "small", True),
+                                               ("siamese_toys", "toys", False)])
+def test_siamese_oracle_matches_reference(golden_dir, name, cfgname, edge):
+    """SimpleSiamese: with / without latent transform and user / item biases."""
+    g = _load(golden_dir, name)
+    cfg = synth.SIAMESE_CFGS[cfgname]
+    p = synth.siamese_params(cfg, 0)
+    b = synth.siamese_batch(cfg, 1, edge_cases=edge)
+    args = tuple(b[k] for k in SIAMESE_ARGS)
+    with torch.no_grad():
+        pred, us, is_ = O.siamese_forward(p, *args)
+    _close(pred, g["pred_eval"], FWD_TOL, what="pred_eval")
+    _close(us.view(cfg["B"], cfg["R"]), g["u_rev_scores"], FWD_TOL, what="u_rev_scores")
+    _close(is_.view(cfg["B"], cfg["R"]), g["i_rev_scores"], FWD_TOL, what="i_rev_scores")
+    hist = O.train_steps(p, lambda q: O.siamese_forward(q, *args)[0], b["ratings"], n_steps=3)
+    _check_steps(g, hist, cfgname == "toys")

@@ -1,0 +1,133 @@
+"""SimpleSiamese on the HIP path vs golden vectors captured from the reference and vs the CPU oracle
+(through the C ABI: rbr_review_bag_*, rbr_additive_attn_*, rbr_linear_* with tanh, rbr_pair_head_*)."""
+import pytest
+import torch
+
+import synth
+from helpers import check_grads, check_params_after, golden, max_err, quiet
+
+pytestmark = pytest.mark.gpu
+FWD_TOL = 1e-4
+DEV = "cuda:0"
+ARGS = ("u_revs", "i_revs", "u_word_masks", "i_word_masks", "u_rev_masks", "i_rev_masks", "u_ids", "i_ids")
+
+
+def _model(cfg, dropout=0.0, word_dropout=0.0, review_dropout=0.0):
+    from review_based_recommender_amd.models.simple_siamese.simple_siamese import SimpleSiamese
+    c = cfg
+    m = quiet(SimpleSiamese, c["D"], c["K"], c["V"], c["U"], c["I"], None, False, dropout, word_dropout, review_dropout,
+              c["UB"], c["LT"])
+    m.load_state_dict(synth.siamese_params(cfg, 0))
+    return m.to(DEV)
+
+
+def _batch(b):
+    return tuple(b[k].to(DEV) for k in ARGS), b["ratings"].to(DEV)
+
+
+@pytest.mark.parametrize("name,cfgname,edge", [("siamese_tiny", "tiny", True), ("siamese_small", "small", True),
+                                               ("siamese_toys", "toys", False)])
+def test_siamese_matches_reference(golden_dir, name, cfgname, edge):
+    from review_based_recommender_amd.train_step import make_optimizer, train_step
+    g = golden(golden_dir, name)
+    cfg = synth.SIAMESE_CFGS[cfgname]
+    model = _model(cfg)
+    args, ratings = _batch(synth.siamese_batch(cfg, 1, edge_cases=edge))
+    model.eval()
+    with torch.no_grad():
+        pred, a, b = model(*args)
+    assert pred.shape == (cfg["B"],) and a is None and b is None        # the reference returns (logits, None, None)
+    assert max_err(pred.cpu().numpy(), g["pred_eval"]) <= FWD_TOL
+
+    model.train()
+    loss = torch.nn.functional.mse_loss(model(*args)[0], ratings)
+    loss.backward()
+    check_grads({k: p.grad for k, p in model.named_parameters()}, g)
+    model.zero_grad()
+    opt = make_optimizer(model)
+    for step in range(3):
+        loss, gnorm, pred = train_step(model, opt, args, ratings)
+        if step == 0:
+            assert abs(float(loss) - float(g["loss"])) <= 1e-4
+            assert abs(float(gnorm) - float(g["gnorm"])) <= 2e-4 * float(g["gnorm"])
+        if step in (0, 2):
+            check_params_after(model, g, f"after{step + 1}")
+
+
+def test_attention_scores_and_state_dict(golden_dir):
+    g = golden(golden_dir, "siamese_small")
+    cfg = synth.SIAMESE_CFGS["small"]
+    model = _model(cfg).eval()
+    assert list(model.state_dict().keys()) == list(synth.siamese_params(cfg, 0).keys())
+    b = synth.siamese_batch(cfg, 1, edge_cases=True)
+    seen = []
+    h = model.review_att_layer.register_forward_hook(lambda _m, _i, o: seen.append(o[1]))
+    with torch.no_grad():
+        model(*_batch(b)[0])
+    h.remove()
+    assert seen[0].shape == (cfg["B"], cfg["R"], 1)
+    assert max_err(seen[0].view(cfg["B"], cfg["R"]).cpu().numpy(), g["u_rev_scores"]) <= 1e-5
+    assert max_err(seen[1].view(cfg["B"], cfg["R"]).cpu().numpy(), g["i_rev_scores"]) <= 1e-5
+
+
+def test_standalone_layers_match_oracle():
+    """MaskedAvgPooling1d and AddictiveAttention on materialised inputs, forward and input gradients, odd widths."""
+    from oracle import ref_cpu as O
+    from review_based_recommender_amd.models.simple_siamese.layers import AddictiveAttention, MaskedAvgPooling1d
+    gen = torch.Generator().manual_seed(0)
+    bz, hdim, T = 7, 13, 9                                   # hdim % 4 != 0: the scalar-column path of the bag kernel
+    x = torch.randn(bz, hdim, T, generator=gen)
+    m = torch.rand(bz, T, generator=gen) > 0.4
+    m[2] = False                                             # an empty bag: 0 / 1e-8 = 0
+    xg = x.clone().to(DEV).requires_grad_(True)
+    out = MaskedAvgPooling1d()(xg, m.to(DEV))
+    xr = x.clone().requires_grad_(True)
+    ref = O.masked_avg_pool(xr.transpose(1, 2), m).unsqueeze(2)
+    assert out.shape == ref.shape and max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-6
+    w = torch.randn(ref.shape, generator=gen)
+    out.backward(w.to(DEV)); ref.backward(w)
+    assert max_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 1e-6
+
+    att = quiet(AddictiveAttention, hdim, 6)
+    xa = torch.randn(bz, T, hdim, generator=gen)
+    mask = torch.rand(bz, T, generator=gen) > 0.3
+    mask[1] = False                                          # no valid review: uniform scores, no logit gradient
+    ref_x = xa.clone().requires_grad_(True)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    ro, rs = O.additive_attention(ref_x, mask, p["proj_layer.0.weight"], p["proj_layer.0.bias"], p["inner_product.weight"])
+    att = att.to(DEV)
+    gx = xa.clone().to(DEV).requires_grad_(True)
+    go, gs = att(gx, mask.to(DEV))
+    assert max_err(go.detach().cpu().numpy(), ro.detach().numpy()) <= 1e-5
+    assert max_err(gs.detach().cpu().numpy(), rs.detach().numpy()) <= 1e-6
+    w = torch.randn(ro.shape, generator=gen)
+    go.backward(w.to(DEV)); ro.backward(w)
+    assert max_err(gx.grad.cpu().numpy(), ref_x.grad.numpy()) <= 1e-5
+    for k, v in att.named_parameters():
+        assert max_err(v.grad.cpu().numpy(), p[k].grad.numpy()) <= 1e-5, k
+
+
+def test_dropout_masks_have_the_reference_structure():
+    """VariationalDropout: one mask per (review, dim) for all tokens; NodeDropout: one per review; rates as F.dropout."""
+    from review_based_recommender_amd.models.simple_siamese.layers import NodeDropout, VariationalDropout
+    torch.manual_seed(0)
+    x = torch.ones(64, 11, 108, device=DEV)
+    v = VariationalDropout(p=0.2).train()(x)
+    assert torch.equal(v[:, 0], v[:, 5])                                   # same mask at every time step
+    vals = torch.unique(v)
+    assert set(round(float(t), 4) for t in vals) <= {0.0, 1.25}
+    assert abs(float((v[:, 0] == 0).float().mean()) - 0.2) < 0.03
+    n = NodeDropout(p=0.5).train()(x)
+    assert torch.equal(n[:, :, 0], n[:, :, 77])                            # whole reviews dropped together
+    assert abs(float((n[:, :, 0] == 0).float().mean()) - 0.5) < 0.08
+    assert torch.equal(VariationalDropout(p=0.2).eval()(x), x)
+
+
+def test_siamese_refuses_cpu_tensors():
+    cfg = synth.SIAMESE_CFGS["tiny"]
+    from review_based_recommender_amd.models.simple_siamese.simple_siamese import SimpleSiamese
+    c = cfg
+    m = quiet(SimpleSiamese, c["D"], c["K"], c["V"], c["U"], c["I"], None, False, 0.0, 0.0, 0.0, True, False)
+    b = synth.siamese_batch(cfg, 1)
+    with pytest.raises(RuntimeError):
+        m(*[b[k] for k in ARGS])
