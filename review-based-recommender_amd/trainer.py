@@ -1,5 +1,6 @@
 """Trainer-equivalent entry point: the behaviour of the reference's
-trainer/train_{deepconn_pp,narre,dual_att}.py on top of the HIP modules.
+trainer/train_{deepconn_pp,narre,dual_att}.py on top of the HIP modules (plus `--model simple_siamese` on the review
+split: plain Adam, none of train_simple_siamese.py's SparseAdam / scheduler / review sampling).
 
     python -m review_based_recommender_amd.trainer --model deepconn --config cfg.json
     python -m torch.distributed.run --nproc-per-node 8 -m review_based_recommender_amd.trainer --model deepconn --config cfg.json
@@ -54,7 +55,7 @@ DEFAULTS = dict(log_dir="logs", dataset="dataset", log=True, log_idx=500, verbos
 
 
 class ReviewExperiment:
-    KINDS = ("deepconn", "narre", "dual_att")
+    KINDS = ("deepconn", "narre", "dual_att", "simple_siamese")
 
     def __init__(self, kind: str, args: Args, reference_quirks: bool = False, uid: str | None = None):
         if kind not in self.KINDS:
@@ -79,8 +80,9 @@ class ReviewExperiment:
         self.patience = 0
         self.grad_sync = None
 
-        cls = D.ReviewDataset if kind == "narre" else D.DocDataset
-        kw = {} if kind == "narre" else {"with_ids": kind == "deepconn"}
+        review_split = kind in ("narre", "simple_siamese")
+        cls = D.ReviewDataset if review_split else D.DocDataset
+        kw = {} if review_split else {"with_ids": kind == "deepconn"}
         self.train_set = cls(args.data_dir, "train", **kw)
         self.valid_set = cls(args.data_dir, "valid", **kw)
         self._make_dir()
@@ -155,6 +157,16 @@ class ReviewExperiment:
                                    hidden_dim=hd, embedding_dim=a.embedding_dim, att_dim=a.att_dim, latent_dim=a.latent_dim,
                                    max_doc_num=ds.rv_num, max_doc_len=ds.rv_len, dropout=a.dropout, word_padding_idx=0,
                                    user_padding_idx=0, item_padding_idx=0, pretrained_embeddings=None, arch=a.arch)
+            elif self.kind == "simple_siamese":
+                # trainer/train_simple_siamese.py:161-167 (keys of models/simple_siamese/defalut_simple_train.json)
+                from .models.simple_siamese.simple_siamese import SimpleSiamese
+                self.model = SimpleSiamese(embedding_dim=a.embedding_dim, latent_dim=a.latent_dim, vocab_size=ds.vocab_size,
+                                           user_size=ds.user_num, item_size=ds.item_num, pretrained_embeddings=None,
+                                           freeze_embeddings=getattr(a, "freeze_embeddings", False), dropout=a.dropout,
+                                           word_dropout=getattr(a, "word_dropout", 0.2),
+                                           review_dropout=getattr(a, "review_dropout", 0.0),
+                                           use_ui_bias=getattr(a, "use_ui_bias", True),
+                                           latent_transform=getattr(a, "latent_transform", False))
             else:
                 from .models.dual_att.dual_att import DualAtt
                 self.model = DualAtt(vocab_size=ds.vocab_size, doc_len=ds.doc_len, l_window_size=a.l_window_size,
@@ -175,6 +187,11 @@ class ReviewExperiment:
 
     def _to_device(self, batch):
         batch = [t.to(self.device, non_blocking=True) for t in batch]
+        if self.kind == "simple_siamese":
+            # review-split batch (u_revs, i_revs, word masks x2, ids x2, review ids x2, ratings) -> the model's arguments:
+            # review masks mark the reviews that hold any token (simple_siamese/utils.py:94-106)
+            u_revs, i_revs, u_wm, i_wm, u_ids, i_ids = batch[:6]
+            return (u_revs, i_revs, u_wm, i_wm, u_wm.any(-1), i_wm.any(-1), u_ids, i_ids), batch[-1]
         return tuple(batch[:-1]), batch[-1]
 
     # ------------------------------------------------------------------ loops (train_deepconn_pp.py:143-232)

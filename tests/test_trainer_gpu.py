@@ -25,11 +25,11 @@ def _cfg(tmp_path, kind, data_dir, **extra):
     return str(path)
 
 
-@pytest.mark.parametrize("kind", ["deepconn", "narre", "dual_att"])
+@pytest.mark.parametrize("kind", ["deepconn", "narre", "dual_att", "simple_siamese"])
 def test_trainer_runs_logs_and_checkpoints(tmp_path, kind):
     from review_based_recommender_amd.trainer import ReviewExperiment, parse_args
     data_dir = str(tmp_path / "data")
-    (make_dataset.write_review_split if kind == "narre" else make_dataset.write_doc_split)(data_dir)
+    (make_dataset.write_review_split if kind in ("narre", "simple_siamese") else make_dataset.write_doc_split)(data_dir)
     exp = ReviewExperiment(kind, parse_args(_cfg(tmp_path, kind, data_dir)), uid="t0")
     exp.train()
     log = open(os.path.join(exp.out_dir, "log.txt")).read().splitlines()
