@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -195,7 +197,7 @@ def main():
     opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
-        grad_sync = GradAllReduce(model)
+        grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None)
 
     def barrier():
         if world > 1:
@@ -262,7 +264,8 @@ def main():
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
-                       "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)"},
+                       "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)",
+                       "grad_allreduce": None if world == 1 else f"RCCL, {a.comm_dtype} wire format, before the clip"},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
             "kernel_timing": ("HIP events around the C-ABI launches, eager pass over the same steps after the timed region"
@@ -294,7 +297,7 @@ def main():
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             conv_ms = sum(ksum[k][1] for k in ("textcnn_prod_prepare", "textcnn_prod_table", "textcnn_prod_pool"))
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_fwd_kernel<5,60> in store mode: T = table[distinct tokens] @ Wprod "
+                "bound": "mfma", "kernel": "conv_store_kernel<8,60>: T = table[distinct tokens] @ Wprod "
                                            "(v_mfma_f32_32x32x2_f32, rows gathered by LDS-DMA)",
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic("r01_prod_table_pmc.json"),

@@ -176,11 +176,21 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const long long* __
   unsigned long long t_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
+  // the first item of a workgroup is its own index (no round trip to the counter); later items are pulled.  When the
+  // grid covers all items (the token-product GEMM: 501 items, 512 resident workgroups) nothing is ever pulled.
+  bool first_item = true;
   for (;;) {
-    __syncthreads();   // every wave is done with the LDS ring (and with *s_item) of the previous item
-    if (tid == 0) *s_item = atomicAdd(item_counter, 1);
-    __syncthreads();
-    const int item = *s_item;
+    int item;
+    if (first_item) {
+        item = blockIdx.x;
+        first_item = false;
+    } else {
+        if ((int)gridDim.x >= nitems) break;
+        __syncthreads();   // every wave is done with the LDS ring (and with *s_item) of the previous item
+        if (tid == 0) *s_item = (int)gridDim.x + atomicAdd(item_counter, 1);
+        __syncthreads();
+        item = *s_item;
+    }
     if (item >= nitems) break;
     RBR_STAMP(0);   // item pull
     const int grp = item / nrow_items;                 // 0 unless store_rows
@@ -340,18 +350,43 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const long long* __
 
     // ---- epilogue -----------------------------------------------------------------------------------------
     if (STORE) {
-        // token-product table: out[row, slot] = accumulator (rows of the pseudo-document = distinct tokens)
+        // token-product table: out[row, slot] = accumulator (rows of the pseudo-document = distinct tokens).  Each
+        // 32 x 32 tile goes through the wave's own (now idle) slab so that a store instruction writes 8 rows x 128
+        // contiguous bytes as float4 -- 4 instructions per tile instead of 16 half-coalesced dword stores.
+        constexpr int TS = 36;                         // slab row stride: 16-byte aligned rows, DC >= 20 floats -> 32*36 <= 32*DC? see static_assert
+        static_assert(32 * TS <= kTile * DC || DC < TS, "transpose staging must fit the wave's slab");
+        if (DC >= TS) {
+            const int trow = lane >> 3, tcq = lane & 7;
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-            if (active && tt < P.ntiles) {
+            for (int tt = 0; tt < NT; ++tt) {
+                if (active && tt < P.ntiles) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = l0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < L) pval[(long)row * P.nslots_total + (long)(tile_base + tt) * kTile + i] = acc[tt][r];
+                    for (int r = 0; r < 16; ++r) Xw[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + i] = acc[tt][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int rr = trow + 8 * pass;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(Xw + rr * TS + 4 * tcq);
+                        const int row = l0 + rr;
+                        if (row < L) *reinterpret_cast<f32x4*>(pval + (long)row * P.nslots_total + (long)(tile_base + tt) * kTile + 4 * tcq) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                if (active && tt < P.ntiles) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = l0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < L) pval[(long)row * P.nslots_total + (long)(tile_base + tt) * kTile + i] = acc[tt][r];
+                    }
                 }
             }
         }
         RBR_STAMP(7);   // epilogue
+        __syncthreads();   // the slab is rewritten by the next item's gather
         continue;
     }
     // max + first argmax over this wave's 32 positions, per channel slot
