@@ -245,7 +245,8 @@ int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int
  *      review_bag: WordEmbedding -> VariationalDropout -> MaskedAvgPooling1d (layers.py:24-50,53-68,90-110) in one pass:
  *        out[r, :] = drop[r, :] * sum_l mask[r,l] * table[ids[r,l], :] / (sum_l mask[r,l] + 1e-8)
  *        ids [n_rev, T] int64, mask [n_rev, T] or NULL, drop [n_rev, D] multiplier or NULL, out [n_rev, D],
- *        inv_len [n_rev] (kept for the backward).  Backward: dtable ACCUMULATED, row padding_idx excluded.
+ *        inv_len [n_rev] (kept for the backward).  Backward: dtable [V, D] ACCUMULATED, row padding_idx excluded;
+ *        the occurrences are sorted by token first (ws: rbr_review_bag_bwd_ws_bytes(n_rev, T) bytes).
  *      additive_attn: NodeDropout + AddictiveAttention (layers.py:7-22,171-197) for B users / items with R reviews each:
  *        x = node_drop[b,r] * rev[b,r,:];  t = tanh(x Wp^T + bp);  s = softmax_r(masked_fill(<t, wi>, ~mask, -1e8));
  *        out[b,:] = sum_r s[r] x[r,:].   rev [B,R,H], mask [B,R] or NULL, node_drop [B,R] or NULL, Wp [K,H], bp [K],
@@ -253,8 +254,9 @@ int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k, const int
  *        R <= 64; ws: rbr_additive_attn_bwd_ws_floats(B,R,H,K) floats.                                     ---- */
 int rbr_review_bag_fwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* table,
                        const float* drop, float* out, float* inv_len, void* stream);
-int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* drop,
-                       const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable, void* stream);
+size_t rbr_review_bag_bwd_ws_bytes(int32_t n_rev, int32_t T);
+int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V, const int64_t* ids, const uint8_t* mask, const float* drop,
+                       const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable, void* ws, void* stream);
 int rbr_additive_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t K, const float* rev, const uint8_t* mask,
                           const float* node_drop, const float* Wp, const float* bp, const float* wi, float* out, float* scores,
                           float* t_out, void* stream);

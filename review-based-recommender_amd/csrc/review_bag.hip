@@ -8,6 +8,8 @@
 // Nothing of shape [reviews, tokens, D] is ever written to HBM (the reference materialises it twice per tower).
 #include "rbr_common.h"
 
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 
 namespace rbr {
@@ -65,30 +67,68 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(int n_rev, int T, int D, c
     }
 }
 
-// dtable[ids[r,l], :] += mask * drop[r,:] * d_out[r,:] * inv_len[r]   (rows of padding_idx get nothing)
-__global__ __launch_bounds__(256) void bag_bwd_kernel(int n_rev, int T, int D, const long long* __restrict__ ids,
-                                                      const unsigned char* __restrict__ mask, const float* __restrict__ drop,
-                                                      const float* __restrict__ inv_len, const float* __restrict__ d_out,
-                                                      int padding_idx, float* __restrict__ dtable) {
+// ------------------------------------------------------------------------------------ bag backward
+// dtable[ids[r,l], :] += mask * drop[r,:] * d_out[r,:] * inv_len[r]   (rows of padding_idx get nothing).
+// One atomic row per occurrence would hammer the rows of frequent words (a Zipf-hot token sits in nearly every review).
+// Instead the occurrences are SORTED by token (rocPRIM radix sort of (token, position) pairs), each wave walks a chunk
+// of the sorted list, sums the runs of equal tokens in registers and adds one row per run: rows added ~ distinct tokens
+// + chunks, not positions.
+constexpr int kBagChunk = 64;       // sorted occurrences per wave (one per lane)
+
+__global__ __launch_bounds__(256) void bag_keys_kernel(long n_pos, const long long* __restrict__ ids,
+                                                       const unsigned char* __restrict__ mask, int padding_idx, int sentinel,
+                                                       int* __restrict__ keys, int* __restrict__ vals) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_pos; k += (long)gridDim.x * 256) {
+        const long long t = ids[k];
+        const bool ok = (mask == nullptr || mask[k]) && t != padding_idx;
+        keys[k] = ok ? (int)t : sentinel;       // masked / padding occurrences sort to the end and are skipped
+        vals[k] = (int)k;
+    }
+}
+
+__global__ __launch_bounds__(256) void bag_bwd_sorted_kernel(long n_pos, int T, int D, int sentinel, const int* __restrict__ keys,
+                                                             const int* __restrict__ vals, const float* __restrict__ drop,
+                                                             const float* __restrict__ inv_len, const float* __restrict__ d_out,
+                                                             float* __restrict__ dtable) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * kWavesPerWG + wave;
-    if (r >= n_rev) return;
-    const long long* rid = ids + (long)r * T;
-    const unsigned char* rm = mask ? mask + (long)r * T : nullptr;
-    const float inv = inv_len[r];
-    for (int d0 = 0; d0 < D; d0 += 64) {
+    const long e0 = ((long)blockIdx.x * kWavesPerWG + wave) * kBagChunk;
+    if (e0 >= n_pos) return;
+    const int n = (int)min((long)kBagChunk, n_pos - e0);
+    // lane j holds occurrence e0 + j: token, review, 1 / len -- read once, broadcast with readlane below
+    const int my_key = (lane < n) ? keys[e0 + lane] : sentinel;
+    const int my_rev = (lane < n) ? vals[e0 + lane] / T : 0;
+    const float my_inv = (lane < n && my_key != sentinel) ? inv_len[my_rev] : 0.f;
+    for (int d0 = 0; d0 < D; d0 += 64) {          // lanes = embedding columns
         const int d = d0 + lane;
-        float g = 0.f;
-        if (d < D) {
-            g = d_out[(long)r * D + d] * inv;
-            if (drop != nullptr) g *= drop[(long)r * D + d];
+        const bool on = d < D;
+        float acc = 0.f;
+        int cur = __builtin_amdgcn_readfirstlane(my_key);
+        for (int j0 = 0; j0 < n; j0 += 4) {        // 4 independent gradient rows in flight
+            int t[4];
+            float g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u, n - 1);
+                t[u] = (j0 + u < n) ? __builtin_amdgcn_readlane(my_key, j) : sentinel;
+                const int r = __builtin_amdgcn_readlane(my_rev, j);
+                const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), j));
+                g[u] = 0.f;
+                if (on && t[u] != sentinel) {
+                    g[u] = d_out[(long)r * D + d] * inv;
+                    if (drop != nullptr) g[u] *= drop[(long)r * D + d];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t[u] != cur) {                  // wave-uniform
+                    if (cur != sentinel && on) atomicAdd(dtable + (long)cur * D + d, acc);
+                    acc = 0.f;
+                    cur = t[u];
+                }
+                acc += g[u];
+            }
         }
-        for (int l = 0; l < T; ++l) {
-            if (rm != nullptr && !rm[l]) continue;          // wave-uniform
-            const long long t = rid[l];
-            if (t == padding_idx) continue;
-            if (d < D) atomicAdd(dtable + t * (long)D + d, g);     // 256 contiguous bytes per wave instruction
-        }
+        if (cur != sentinel && on) atomicAdd(dtable + (long)cur * D + d, acc);
     }
 }
 
@@ -210,15 +250,24 @@ __global__ __launch_bounds__(256) void addatt_bwd_kernel(int B, int R, int H, in
     }
 }
 
-// dWp[k, h] = sum_n d_pre[n, k] * x[n, h]    (n = (b, r) rows; one thread per (k, h), fixed order over n)
+// dWp[k, h] += sum over a chunk of 64 rows n = (b, r) of d_pre[n, k] * x[n, h]   (dWp zeroed beforehand; one workgroup per
+// chunk stages its rows in LDS, every thread owns a few (k, h) outputs and adds them with one atomic each)
+constexpr int kDwRows = 64;
 __global__ __launch_bounds__(256) void addatt_dw_kernel(int N, int H, int K, const float* __restrict__ d_pre,
                                                         const float* __restrict__ x, float* __restrict__ d_Wp) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= K * H) return;
-    const int k = e / H, h = e - k * H;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) acc = fmaf(d_pre[(long)n * K + k], x[(long)n * H + h], acc);
-    d_Wp[e] = acc;
+    extern __shared__ float sm[];
+    float* sp = sm;                    // [rows][K]
+    float* sx = sm + kDwRows * K;      // [rows][H]
+    const int n0 = blockIdx.x * kDwRows, rows = min(kDwRows, N - n0);
+    for (int e = threadIdx.x; e < rows * K; e += 256) sp[e] = d_pre[(long)n0 * K + e];
+    for (int e = threadIdx.x; e < rows * H; e += 256) sx[e] = x[(long)n0 * H + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * H; e += 256) {
+        const int k = e / H, h = e - k * H;
+        float acc = 0.f;
+        for (int n = 0; n < rows; ++n) acc = fmaf(sp[n * K + k], sx[n * H + h], acc);
+        atomicAdd(d_Wp + e, acc);
+    }
 }
 
 }  // namespace rbr
@@ -235,19 +284,59 @@ extern "C" int rbr_review_bag_fwd(int32_t n_rev, int32_t T, int32_t D, const int
     return 0;
 }
 
-extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, const int64_t* ids, const uint8_t* mask, const float* drop,
-                                  const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable, void* stream) {
-    if (n_rev <= 0 || T <= 0 || D <= 0) { set_error("bad shape n_rev=%d T=%d D=%d", n_rev, T, D); return RBR_ERR_BAD_ARG; }
-    if (!ids || !inv_len || !d_out || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(bag_bwd_kernel, dim3((n_rev + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, (hipStream_t)stream, n_rev, T, D,
-                       reinterpret_cast<const long long*>(ids), mask, drop, inv_len, d_out, padding_idx, dtable);
+// workspace of the backward: keys | vals (in) | keys | vals (sorted) | rocPRIM temporary storage
+static size_t bag_sort_temp_bytes(long n_pos) {
+    size_t bytes = 0;
+    int* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)n_pos, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+extern "C" size_t rbr_review_bag_bwd_ws_bytes(int32_t n_rev, int32_t T) {
+    if (n_rev <= 0 || T <= 0) return 0;
+    const long n_pos = (long)n_rev * T;
+    const size_t arr = (((size_t)n_pos * sizeof(int)) + 255) & ~(size_t)255;
+    return 4 * arr + bag_sort_temp_bytes(n_pos) + 256;
+}
+
+extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V, const int64_t* ids, const uint8_t* mask,
+                                  const float* drop, const float* inv_len, const float* d_out, int32_t padding_idx, float* dtable,
+                                  void* ws, void* stream) {
+    if (n_rev <= 0 || T <= 0 || D <= 0 || V <= 0) { set_error("bad shape n_rev=%d T=%d D=%d V=%d", n_rev, T, D, V); return RBR_ERR_BAD_ARG; }
+    if (!ids || !inv_len || !d_out || !dtable || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const long n_pos = (long)n_rev * T;
+    if (n_pos >= (1L << 31)) { set_error("too many token positions"); return RBR_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t arr = (((size_t)n_pos * sizeof(int)) + 255) & ~(size_t)255;
+    char* base = static_cast<char*>(ws);
+    int* keys_in = reinterpret_cast<int*>(base);
+    int* vals_in = reinterpret_cast<int*>(base + arr);
+    int* keys = reinterpret_cast<int*>(base + 2 * arr);
+    int* vals = reinterpret_cast<int*>(base + 3 * arr);
+    void* temp = base + 4 * arr;
+    size_t temp_bytes = bag_sort_temp_bytes(n_pos);
+    const int sentinel = V;              // sorts behind every real token
+    hipLaunchKernelGGL(bag_keys_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos,
+                       reinterpret_cast<const long long*>(ids), mask, padding_idx, sentinel, keys_in, vals_in);
+    RBR_CHECK_LAUNCH("review_bag keys launch");
+    int bits = 1;
+    while ((1L << bits) <= V) ++bits;    // keys are in [0, V]
+    if (int e = check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys, vals_in, vals, (size_t)n_pos, 0, bits, st),
+                          "review_bag radix sort"))
+        return e;
+    const long n_waves = (n_pos + kBagChunk - 1) / kBagChunk;
+    hipLaunchKernelGGL(bag_bwd_sorted_kernel, dim3((unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG)), dim3(256), 0, st, n_pos, T,
+                       D, sentinel, keys, vals, drop, inv_len, d_out, dtable);
     RBR_CHECK_LAUNCH("review_bag bwd launch");
     return 0;
 }
 
 static bool addatt_ok(int B, int R, int H, int K) {
     if (B <= 0 || R <= 0 || R > kAttMaxR || H <= 0 || K <= 0) { set_error("bad shape B=%d R=%d (<= %d) H=%d K=%d", B, R, kAttMaxR, H, K); return false; }
-    if ((size_t)(R * H + R * K + 2 * R + H) * sizeof(float) > 64 * 1024) { set_error("R*H + R*K exceeds the LDS budget"); return false; }
+    if ((size_t)(R * H + R * K + 2 * R + H) * sizeof(float) > 64 * 1024 || (size_t)kDwRows * (K + H) * sizeof(float) > 64 * 1024) {
+        set_error("R*H + R*K (or 64*(K+H)) exceeds the LDS budget");
+        return false;
+    }
     return true;
 }
 
@@ -276,13 +365,14 @@ extern "C" int rbr_additive_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t K,
     hipStream_t st = (hipStream_t)stream;
     float* d_pre = ws;
     float* x_eff = ws + (size_t)B * R * K;
-    ZeroRegions zr{{reinterpret_cast<int*>(d_bp), reinterpret_cast<int*>(d_wi), nullptr}, {K, K, 0}};
+    ZeroRegions zr{{reinterpret_cast<int*>(d_bp), reinterpret_cast<int*>(d_wi), reinterpret_cast<int*>(d_Wp)}, {K, K, (long)K * H}};
     if (int e = zero_regions(zr, st)) return e;
     const size_t lds = (size_t)(R * H + R * K + 2 * R + H) * sizeof(float);
     hipLaunchKernelGGL(addatt_bwd_kernel, dim3(B), dim3(256), lds, st, B, R, H, K, rev, mask, node_drop, Wp, wi, scores, t_in, d_out,
                        d_rev, d_pre, x_eff, d_bp, d_wi);
     RBR_CHECK_LAUNCH("additive_attn bwd launch");
-    hipLaunchKernelGGL(addatt_dw_kernel, dim3((K * H + 255) / 256), dim3(256), 0, st, B * R, H, K, d_pre, x_eff, d_Wp);
+    hipLaunchKernelGGL(addatt_dw_kernel, dim3((B * R + kDwRows - 1) / kDwRows), dim3(256), (size_t)kDwRows * (K + H) * sizeof(float), st,
+                       B * R, H, K, d_pre, x_eff, d_Wp);
     RBR_CHECK_LAUNCH("additive_attn dW launch");
     return 0;
 }

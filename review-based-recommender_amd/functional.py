@@ -396,10 +396,12 @@ class _ReviewBag(torch.autograd.Function):
             return None, None, None, None, None
         dtable = torch.zeros(shape, dtype=F32, device=d_out.device)
         d_out = d_out.contiguous()
-        check(_lib.lib().rbr_review_bag_bwd(n_rev, T, D, dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                            dev_ptr(drop, F32, "drop"), dev_ptr(inv_len, F32, "inv_len"),
-                                            dev_ptr(d_out, F32, "d_out"), pad, dev_ptr(dtable, F32, "dtable"),
-                                            current_stream()), "rbr_review_bag_bwd")
+        L_ = _lib.lib()
+        ws = torch.empty(L_.rbr_review_bag_bwd_ws_bytes(n_rev, T), dtype=torch.uint8, device=d_out.device)
+        check(L_.rbr_review_bag_bwd(n_rev, T, D, shape[0], dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                    dev_ptr(drop, F32, "drop"), dev_ptr(inv_len, F32, "inv_len"),
+                                    dev_ptr(d_out, F32, "d_out"), pad, dev_ptr(dtable, F32, "dtable"), ws.data_ptr(),
+                                    current_stream()), "rbr_review_bag_bwd")
         return dtable, None, None, None, None
 
 

@@ -1,5 +1,6 @@
-"""Secondary measurements (not the driver's bench line): NARRE cfg3 and D-ATT cfg4 forward / train step on one GPU,
-plus the CPU oracle's forward on the same batch.  python tools/bench_models.py [narre|datt] [--cpu]"""
+"""Secondary measurements (not the driver's bench line): NARRE cfg3, D-ATT cfg4 and SimpleSiamese (defalut_simple_train.json
+shape, batch 256) forward / train step on one GPU, plus the CPU oracle's forward on the same batch.
+python tools/bench_models.py [narre|datt|siamese|all] [--cpu] [--no-graph]"""
 import contextlib, io, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -19,7 +20,7 @@ def run(name, model, args, ratings, B, flops_fwd):
     model.train()
     graph_ms = None
     if "--no-graph" not in sys.argv:      # the step replayed as a hipGraph (how bench.py times DeepCoNN)
-        gopt = make_optimizer(model, capturable=True)
+        gopt = make_optimizer(model, hip_clip_adam=True)
         stepper = GraphedTrainStep(model, gopt, args, ratings)
         for _ in range(5):
             stepper()
@@ -88,3 +89,20 @@ if which in ("datt", "all"):
         p = synth.datt_params(c, 0, table_scale=0.3)
         with torch.no_grad():
             O.datt_forward(p, b["u_docs"], b["i_docs"]); t0 = time.perf_counter(); O.datt_forward(p, b["u_docs"], b["i_docs"]); print("cpu fwd pairs/s", c["B"] / (time.perf_counter() - t0), "threads", torch.get_num_threads())
+
+if which in ("siamese", "all"):
+    from review_based_recommender_amd.models.simple_siamese.simple_siamese import SimpleSiamese
+    c = dict(synth.SIAMESE_CFGS["toys"], B=256)
+    m = quiet(SimpleSiamese, c["D"], c["K"], c["V"], c["U"], c["I"], None, False, 0.5, 0.2, 0.0, c["UB"], c["LT"])
+    m.load_state_dict(synth.siamese_params(c, 0)); m.to(dev)
+    b = synth.siamese_batch(c, 1)
+    keys = ("u_revs", "i_revs", "u_word_masks", "i_word_masks", "u_rev_masks", "i_rev_masks", "u_ids", "i_ids")
+    args = tuple(b[k].to(dev) for k in keys)
+    # algorithmic work: 2 towers x R x T row adds of D floats per pair (a gather, not a contraction)
+    run("SimpleSiamese (B=256, 11x50 tok/side, D=108, fp32)", m, args, b["ratings"].to(dev), c["B"], 2.0 * c["R"] * c["T"] * c["D"] * c["B"])
+    if "--cpu" in sys.argv:
+        from oracle import ref_cpu as O
+        p = synth.siamese_params(c, 0)
+        a = tuple(b[k] for k in keys)
+        with torch.no_grad():
+            O.siamese_forward(p, *a); t0 = time.perf_counter(); O.siamese_forward(p, *a); print("cpu fwd pairs/s", c["B"] / (time.perf_counter() - t0), "threads", torch.get_num_threads())
