@@ -17,16 +17,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
                                                        float* __restrict__ out, float* __restrict__ att,
                                                        float* __restrict__ hid) {
     extern __shared__ float sm[];
-    float* s_hid = sm;            // [R*A]
-    float* s_e = sm + R * A;      // [R] exp(logit), then att
+    float* s_hid = sm;                  // [R*A]
+    float* s_e = s_hid + R * A;         // [R] exp(logit), then att
+    float* s_f = s_e + R;               // [R*H] this sample's review features
+    float* s_eb = s_f + R * H;          // [R*A] counterpart-id embedding rows
+    float* s_wr = s_eb + R * A;         // [H*A] W_rv
+    float* s_wi = s_wr + H * A;         // [A*A] W_id
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* fb = feat + (long)b * R * H;
+    for (int e = tid; e < R * H; e += 256) s_f[e] = fb[e];
+    for (int e = tid; e < R * A; e += 256) s_eb[e] = p.ebd[oid[(long)b * R + e / A] * A + (e % A)];
+    for (int e = tid; e < H * A; e += 256) s_wr[e] = p.W_rv[e];
+    for (int e = tid; e < A * A; e += 256) s_wi[e] = p.W_id[e];
+    __syncthreads();
     for (int idx = tid; idx < R * A; idx += 256) {
         const int r = idx / A, a = idx - r * A;
-        const long id = oid[(long)b * R + r];
         float acc = p.b1[a];
-        for (int a2 = 0; a2 < A; ++a2) acc = fmaf(p.ebd[id * A + a2], p.W_id[(long)a2 * A + a], acc);
-        for (int hh = 0; hh < H; ++hh) acc = fmaf(fb[(long)r * H + hh], p.W_rv[(long)hh * A + a], acc);
+        for (int a2 = 0; a2 < A; ++a2) acc = fmaf(s_eb[r * A + a2], s_wi[a2 * A + a], acc);
+        for (int hh = 0; hh < H; ++hh) acc = fmaf(s_f[r * H + hh], s_wr[hh * A + a], acc);
         const float hv = fmaxf(acc, 0.f);
         hid[((long)b * R + r) * A + a] = hv;
         s_hid[idx] = hv;
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
     __syncthreads();
     for (int hh = tid; hh < H; hh += 256) {
         float s = 0.f;
-        for (int r = 0; r < R; ++r) s = fmaf(s_e[r], fb[(long)r * H + hh], s);
+        for (int r = 0; r < R; ++r) s = fmaf(s_e[r], s_f[r * H + hh], s);
         out[(long)b * H + hh] = s;
     }
 }
@@ -108,46 +116,68 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
     }
 }
 
-// reductions over the N = B*R rows, fixed partition and order (bitwise reproducible).
-// block row:  [0,H) dW_rv | [H,H+A) dW_id | H+A db1 | H+A+1 dh | H+A+2 db2
-__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(int N, int H, int A, const float* __restrict__ feat,
-                                                              const long long* __restrict__ oid, const float* __restrict__ ebd,
-                                                              const float* __restrict__ hid, const float* __restrict__ ws_dpre,
-                                                              const float* __restrict__ ws_dl, const rbr_attn_grads g) {
-    __shared__ float red[8][32];
-    const int row = blockIdx.x;
-    const int kk = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    for (int a0 = 0; a0 < A; a0 += 32) {
-        const int a = a0 + kk;
-        float s = 0.f;
-        if (a < A) {
-            if (row < H) {
-                for (int n = grp; n < N; n += 8) s = fmaf(feat[(long)n * H + row], ws_dpre[(long)n * A + a], s);
-            } else if (row < H + A) {
-                const int a2 = row - H;
-                for (int n = grp; n < N; n += 8) s = fmaf(ebd[oid[n] * A + a2], ws_dpre[(long)n * A + a], s);
-            } else if (row == H + A) {
-                for (int n = grp; n < N; n += 8) s += ws_dpre[(long)n * A + a];
-            } else if (row == H + A + 1) {
-                for (int n = grp; n < N; n += 8) s = fmaf(ws_dl[n], hid[(long)n * A + a], s);
-            } else if (a == 0) {
-                for (int n = grp; n < N; n += 8) s += ws_dl[n];
-            }
-        }
-        __syncthreads();
-        red[grp][kk] = s;
-        __syncthreads();
-        if (grp == 0 && a < A) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t += red[q][kk];
-            if (row < H) g.dW_rv[(long)row * A + a] = t;
-            else if (row < H + A) g.dW_id[(long)(row - H) * A + a] = t;
-            else if (row == H + A) g.db1[a] = t;
-            else if (row == H + A + 1) g.dh[a] = t;
-            else if (a == 0) g.db2[0] = t;
-        }
+// reductions over the N = B*R rows in two stages, fixed partition and order (bitwise reproducible):
+//   stage 1: one workgroup per chunk of 64 rows stages d_pre / feat / embedding rows / hid / d_logit in LDS and writes the
+//            chunk's partial of every output;   stage 2: one thread per output sums the chunks in order.
+// output index: [0, H*A) dW_rv | [H*A, H*A + A*A) dW_id | + A db1 | + A dh | + 1 db2
+constexpr int kRedRows = 64;
+
+__device__ __forceinline__ int attn_n_out(int H, int A) { return H * A + A * A + 2 * A + 1; }
+
+__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(int N, int H, int A, const float* __restrict__ feat,
+                                                               const long long* __restrict__ oid, const float* __restrict__ ebd,
+                                                               const float* __restrict__ hid, const float* __restrict__ ws_dpre,
+                                                               const float* __restrict__ ws_dl, float* __restrict__ part) {
+    extern __shared__ float sm[];
+    float* s_dp = sm;                       // [rows][A]
+    float* s_f = s_dp + kRedRows * A;       // [rows][H]
+    float* s_eb = s_f + kRedRows * H;       // [rows][A]
+    float* s_hd = s_eb + kRedRows * A;      // [rows][A]
+    float* s_dl = s_hd + kRedRows * A;      // [rows]
+    const int n0 = blockIdx.x * kRedRows, rows = min(kRedRows, N - n0), tid = threadIdx.x;
+    for (int e = tid; e < rows * A; e += 256) {
+        s_dp[e] = ws_dpre[(long)n0 * A + e];
+        s_hd[e] = hid[(long)n0 * A + e];
+        s_eb[e] = ebd[oid[n0 + e / A] * A + (e % A)];
     }
+    for (int e = tid; e < rows * H; e += 256) s_f[e] = feat[(long)n0 * H + e];
+    for (int e = tid; e < rows; e += 256) s_dl[e] = ws_dl[n0 + e];
+    __syncthreads();
+    const int n_out = attn_n_out(H, A);
+    float* my = part + (long)blockIdx.x * n_out;
+    for (int o = tid; o < n_out; o += 256) {
+        float acc = 0.f;
+        if (o < H * A) {
+            const int hh = o / A, a = o - hh * A;
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_f[n * H + hh], s_dp[n * A + a], acc);
+        } else if (o < H * A + A * A) {
+            const int q = o - H * A, a2 = q / A, a = q - a2 * A;
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_eb[n * A + a2], s_dp[n * A + a], acc);
+        } else if (o < H * A + A * A + A) {
+            const int a = o - H * A - A * A;
+            for (int n = 0; n < rows; ++n) acc += s_dp[n * A + a];
+        } else if (o < H * A + A * A + 2 * A) {
+            const int a = o - H * A - A * A - A;
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_dl[n], s_hd[n * A + a], acc);
+        } else {
+            for (int n = 0; n < rows; ++n) acc += s_dl[n];
+        }
+        my[o] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_final_kernel(int n_chunks, int H, int A, const float* __restrict__ part,
+                                                             const rbr_attn_grads g) {
+    const int n_out = attn_n_out(H, A);
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    float t = 0.f;
+    for (int c = 0; c < n_chunks; ++c) t += part[(long)c * n_out + o];
+    if (o < H * A) g.dW_rv[o] = t;
+    else if (o < H * A + A * A) g.dW_id[o - H * A] = t;
+    else if (o < H * A + A * A + A) g.db1[o - H * A - A * A] = t;
+    else if (o < H * A + A * A + 2 * A) g.dh[o - H * A - A * A - A] = t;
+    else g.db2[0] = t;
 }
 
 }  // namespace rbr
@@ -156,7 +186,11 @@ using namespace rbr;
 
 static bool attn_args_ok(int B, int R, int H, int A) {
     if (B <= 0 || R <= 0 || H <= 0 || A <= 0) { set_error("bad attention shape B=%d R=%d H=%d A=%d", B, R, H, A); return false; }
-    if ((size_t)(R * A + 2 * R) * sizeof(float) > 60 * 1024) { set_error("R*A=%d too large for the LDS tile", R * A); return false; }
+    if ((size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float) > 64 * 1024 ||
+        (size_t)kRedRows * (3 * A + H + 1) * sizeof(float) > 64 * 1024) {
+        set_error("R=%d H=%d A=%d too large for the LDS tiles", R, H, A);
+        return false;
+    }
     return true;
 }
 
@@ -164,15 +198,15 @@ extern "C" int rbr_review_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t A, c
                                    const rbr_attn_params* p, float* out, float* att, float* hid, void* stream) {
     if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
     if (!feat || !other_id || !p || !out || !att || !hid) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), (size_t)(R * A + R) * sizeof(float), (hipStream_t)stream, B, R,
-                       H, A, feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), (size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float),
+                       (hipStream_t)stream, B, R, H, A, feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid);
     RBR_CHECK_LAUNCH("review_attn_fwd launch");
     return 0;
 }
 
 extern "C" size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t A) {
-    (void)H;
-    return (size_t)B * R * A + (size_t)B * R;
+    const size_t chunks = ((size_t)B * R + kRedRows - 1) / kRedRows;
+    return (size_t)B * R * A + (size_t)B * R + chunks * ((size_t)H * A + (size_t)A * A + 2 * A + 1);
 }
 
 extern "C" int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
@@ -188,8 +222,12 @@ extern "C" int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, c
     hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B), dim3(256), (size_t)(R * A + 2 * R) * sizeof(float), st, B, R, H, A,
                        feat, oid, *p, att, hid, d_out, d_att, pad_idx, g->debd, d_feat, ws_dpre, ws_dl);
     RBR_CHECK_LAUNCH("review_attn_bwd sample launch");
-    hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3(H + A + 3), dim3(256), 0, st, B * R, H, A, feat, oid, p->ebd, hid, ws_dpre,
-                       ws_dl, *g);
-    RBR_CHECK_LAUNCH("review_attn_bwd reduce launch");
+    float* part = ws_dl + (size_t)B * R;
+    const int N = B * R, chunks = (N + kRedRows - 1) / kRedRows, n_out = H * A + A * A + 2 * A + 1;
+    hipLaunchKernelGGL(attn_bwd_partial_kernel, dim3(chunks), dim3(256), (size_t)kRedRows * (3 * A + H + 1) * sizeof(float), st, N, H,
+                       A, feat, oid, p->ebd, hid, ws_dpre, ws_dl, part);
+    RBR_CHECK_LAUNCH("review_attn_bwd partial launch");
+    hipLaunchKernelGGL(attn_bwd_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, chunks, H, A, part, *g);
+    RBR_CHECK_LAUNCH("review_attn_bwd final launch");
     return 0;
 }
