@@ -167,7 +167,7 @@ class GraphedTrainStep:
     The optimizer must have been built with make_optimizer(..., capturable=True)."""
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, batch, ratings: torch.Tensor,
-                 max_grad_norm: float = MAX_GRAD_NORM, grad_sync=None, warmup: int = 3):
+                 max_grad_norm: float = MAX_GRAD_NORM, grad_sync=None, warmup: int = 3, capture_error_mode: str | None = None):
         if not ratings.is_cuda:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         self.model, self.optimizer, self.grad_sync, self.max_grad_norm = model, optimizer, grad_sync, max_grad_norm
@@ -186,13 +186,16 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
+        # with a process group alive, RCCL's watchdog thread polls events while we record: only this thread's calls
+        # may be policed by the capture ("thread_local"), as torch recommends for captures next to NCCL work
+        mode = capture_error_mode or ("thread_local" if grad_sync is not None else "global")
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
         self.g_update = None
         if grad_sync is None:
-            with torch.cuda.graph(self.g_fwd_bwd):
+            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
                 self.loss, self.gnorm, self.pred = train_step(model, optimizer, self.batch, self.ratings, max_grad_norm)
         else:
-            with torch.cuda.graph(self.g_fwd_bwd):
+            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
                 optimizer.zero_grad()
                 out = model(*self.batch)
                 pred = out[0] if isinstance(out, tuple) else out
@@ -201,7 +204,7 @@ class GraphedTrainStep:
                 self.loss, self.pred = loss.detach(), pred.detach()
             grad_sync(model)
             self.g_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool()):
+            with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool(), capture_error_mode=mode):
                 self.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
             for p, v in zip(model.parameters(), saved_params):
