@@ -129,7 +129,8 @@ int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const 
  * G[token][tap, channel] = sum of g over the argmax windows touching that token, for the DISTINCT tokens the
  * forward listed in `fwd_ws` (the workspace rbr_textcnn_conv_fwd was given for the SAME ids/mask, still intact),
  * then dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product (G is ~2 % dense); each listed row of
- * `dtable` is written once with plain stores, all other rows are left untouched (the caller zero-fills dtable).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
+ * `dtable` is written once with plain stores and every other row is set to zero: the whole [V, D] gradient is
+ * OVERWRITTEN (no pre-fill needed).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
  * bytes (0 = formulation not applicable: use rbr_textcnn_bwd_dtable; env RBR_DTABLE_MODE=scatter forces that). */
 size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,

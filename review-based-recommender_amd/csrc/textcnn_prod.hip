@@ -166,24 +166,30 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
             const float* tcol = T + A.poff[w] + 4 * (valid ? q : 0);
             float best[4] = {NEG, NEG, NEG, NEG};
             int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-            for (int p0 = 0; p0 < kTile; p0 += 4) {
-                const int pl = p0 + ps;                                   // position inside the slab
-                f32x4 y = {0.f, 0.f, 0.f, 0.f};
+            for (int p0 = 0; p0 < kTile; p0 += 8) {                       // two positions per lane and round:
+                f32x4 y[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // 2 * kz independent float4 loads in flight
 #pragma unroll
-                for (int j = 0; j < kMaxKF; ++j) {                        // kz independent float4 loads in flight
+                for (int j = 0; j < kMaxKF; ++j) {
                     if (j < kz) {
-                        const int r = pl + j + off;
-                        const f32x4u v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
-                        const float gv = s_gate[wave][r];
-                        y.x = fmaf(v.x, gv, y.x); y.y = fmaf(v.y, gv, y.y); y.z = fmaf(v.z, gv, y.z); y.w = fmaf(v.w, gv, y.w);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = p0 + 4 * u + ps + j + off;
+                            const f32x4u v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
+                            const float gv = s_gate[wave][r];
+                            y[u].x = fmaf(v.x, gv, y[u].x); y[u].y = fmaf(v.y, gv, y[u].y);
+                            y[u].z = fmaf(v.z, gv, y[u].z); y[u].w = fmaf(v.w, gv, y[u].w);
+                        }
                     }
                 }
-                const int pos = l0 + pl;
-                if (pos < Lv) {                                           // ascending positions per lane: '>' keeps the first max
-                    if (y.x > best[0]) { best[0] = y.x; bidx[0] = pos; }
-                    if (y.y > best[1]) { best[1] = y.y; bidx[1] = pos; }
-                    if (y.z > best[2]) { best[2] = y.z; bidx[2] = pos; }
-                    if (y.w > best[3]) { best[3] = y.w; bidx[3] = pos; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int pos = l0 + p0 + 4 * u + ps;
+                    if (pos < Lv) {                                       // ascending positions per lane: '>' keeps the first max
+                        if (y[u].x > best[0]) { best[0] = y[u].x; bidx[0] = pos; }
+                        if (y[u].y > best[1]) { best[1] = y[u].y; bidx[1] = pos; }
+                        if (y[u].z > best[2]) { best[2] = y[u].z; bidx[2] = pos; }
+                        if (y[u].w > best[3]) { best[3] = y[u].w; bidx[3] = pos; }
+                    }
                 }
             }
 #pragma unroll
@@ -268,7 +274,8 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
-                                                        const long long* __restrict__ tok_of_row, float* __restrict__ dtable) {
+                                                        const long long* __restrict__ tok_of_row,
+                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* s_pc = s_dyn + wave * 2 * KGW;
@@ -340,6 +347,15 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
         }
         __syncthreads();      // lists and partial rows are rewritten for the next row
+    }
+    // rows of tokens the batch does not contain: zero (the caller need not pre-fill dtable); one wave per row
+    if (row_of_token != nullptr) {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        for (int v = blockIdx.x * kWavesPerWG + wv; v < V; v += gridDim.x * kWavesPerWG) {
+            if (row_of_token[v] >= 0) continue;                 // wave-uniform
+            float* dst = dtable + (long)v * D;
+            for (int q4 = ln; q4 < nq4; q4 += 64) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 }
 
@@ -505,7 +521,7 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     if (dtable == nullptr) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                       tok_of_row, dtable);
+                       tok_of_row, row_of_token, d->V, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }

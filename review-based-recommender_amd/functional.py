@@ -135,7 +135,9 @@ class _TextCNN(torch.autograd.Function):
         d_feat = d_feat.contiguous()
         dWs = [torch.empty_like(w) for w in ws]
         dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
-        dtable = torch.zeros_like(table) if need_table else None
+        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if ctx.prod_ws is not None else 0
+        # the token-product backward overwrites the whole table gradient; the window scatter accumulates into zeros
+        dtable = (torch.empty_like(table) if bws_bytes else torch.zeros_like(table)) if need_table else None
         dgate = torch.zeros_like(gate) if need_gate else None
         wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
         wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
@@ -149,7 +151,6 @@ class _TextCNN(torch.autograd.Function):
         if ev is not None:
             ev.record()
         ev = TIMER.record("textcnn_bwd_dtable")
-        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if ctx.prod_ws is not None else 0
         if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
             # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
