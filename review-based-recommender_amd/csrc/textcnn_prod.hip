@@ -1,21 +1,25 @@
-// textcnn_prod.hip -- token-product formulation of the TextCNN forward.
+// textcnn_prod.hip -- token-product formulation of the TextCNN forward and of its table / gate gradient.
 //
 // The conv input is an embedding LOOKUP: x[doc, p, :] = table[ids[doc, p]].  So for every tap j and channel c
 //     out[doc, l, c] = bias[c] + sum_j  T[ ids[doc, l + j - pad] ][j, c],      T[t][j, c] = <table[t, :], W[c, :, j]>
 // and T needs one row per DISTINCT token of the batch, not one per position.  Review text is Zipfian: the cfg2
-// batch has 262 k positions but only ~28 k distinct tokens, so the contraction shrinks from 118 GFLOP (dense conv,
-// what the reference executes: models/deepconn/layers.py:46-60) to ~13 GFLOP, followed by a gather-add over
-// kz rows of T per position that is L2/HBM-bound row traffic.  Same fp32 arithmetic, different summation order
+// batch has 262 k positions but only 21 k distinct tokens, so the contraction shrinks from 118 GFLOP (dense conv,
+// what the reference executes: models/deepconn/layers.py:46-60) to 9.6 GFLOP, followed by a gather-add over
+// kz rows of T per position that is L2 / Infinity-Cache row traffic.  Same fp32 arithmetic, different summation order
 // (d first, taps second); masked tokens and out-of-document taps contribute exactly 0, as masked_fill and the
 // conv's zero padding do.
 //
-// Stages (all on the caller's stream, nothing allocated here):
-//   1. mark_tokens / compact_tokens : distinct unmasked tokens -> list `tok_of_row`, inverse map `row_of_token`
-//   2. pack_prod                    : W[c, d, j] of every bank -> one kz = 1 bank of sum(kz*ch) "product channels"
-//   3. conv_fwd_kernel (store_rows) : T = table[tok_of_row] @ Wprod on the f32 MFMA pipe (the SAME fused gather +
-//                                     MFMA kernel as the dense path, run over the token list as one long document)
-//   4. gather_pool                  : per 32-position wave-tile, sum the kz rows of T, running max / first argmax
+// Forward stages (all on the caller's stream, nothing allocated here; rbr_textcnn_prod_prepare / _table / _pool):
+//   1. zero_regions                  : token marks, row mask, work-list counters
+//   2. mark_scan                     : marks of the tokens that occur + work list of the documents' 32-token slabs
+//   3. compact_pack                  : marks -> list `tok_of_row` / inverse map `row_of_token`; W[c, d, j] of every bank ->
+//                                      one kz = 1 bank of sum(kz*ch) "product channels" (MFMA tile image) and Wprod^T rows
+//   4. conv_store_kernel             : T = table[tok_of_row] @ Wprod on the f32 MFMA pipe (the fused gather + MFMA kernel
+//                                      of the dense path, run over the token list as one long document, store epilogue)
+//   5. gather_pool                   : per 32-position wave-tile, sum the kz rows of T, running max / first argmax
 //   then pool_finalize as for the dense path.
+// Backward (rbr_textcnn_bwd_dtable_prod): zero_g_rows, build_g (G[token][(tap, channel)] += g, d(gate) from T),
+//   g_times_w (dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product; absent tokens' rows zeroed).
 #include "rbr_common.h"
 
 #include <algorithm>
