@@ -205,6 +205,17 @@ int rbr_datt_global_gate_fwd(int32_t B, int32_t L, int32_t E, const int64_t* ids
 /* Backward of a gate from dgate[b,l] (for the global gate: summed over l inside).
  * dw, db0 overwritten; dtable accumulated (row pad_idx excluded). ws: B*(E*win) / B*... floats, see .hip */
 size_t rbr_datt_gate_bwd_ws_floats(int32_t B, int32_t L, int32_t E, int32_t win, int32_t is_global);
+/* Token-product form of the local gate (same results): S[token][j] = <table[token], w[:,j]> for the DISTINCT tokens of
+ * ids (table of V rows), the gate is a gather of `win` scalars per position; the backward folds dpre into win tap sums
+ * per token and OVERWRITES the whole dtable [V,E] (absent tokens and row pad_idx: 0), dw [E*win] and db0.  `ws`:
+ * rbr_datt_local_gate_prod_ws_bytes bytes (0: not worthwhile / unsupported -> use the functions above), the SAME buffer,
+ * untouched, for the forward and its backward.  win odd, <= 8. */
+size_t rbr_datt_local_gate_prod_ws_bytes(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V);
+int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids, const float* table,
+                                 const float* w, const float* b0, float* gate, void* ws, void* stream);
+int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids, const float* table,
+                                 const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw, float* db0,
+                                 float* dtable, void* ws, void* stream);
 int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
                             const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                             float* db0, float* dtable, float* ws, void* stream);

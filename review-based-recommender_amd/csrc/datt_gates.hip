@@ -66,12 +66,14 @@ __global__ __launch_bounds__(256) void local_gate_fwd_kernel(int B, int L, int E
 // hash table, one wave per distinct token builds the folded row and issues ONE row of contiguous f32 atomics
 // (a per-token atomic row for each of the 1 M tokens of cfg4 ran 1.3 ms: Zipf-hot rows serialise).
 constexpr int kGWin = 256, kGHash = 1024;
+constexpr int kGateWP = 8;       // floats per token row of the tap tables S / c of the token-product local gate (win <= 8)
 
 __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, int win, int is_global, int nwin,
                                                           const long long* __restrict__ ids, const float* __restrict__ w,
                                                           const float* __restrict__ wT, const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, const float* __restrict__ dpre_g,
-                                                          int pad_idx, float* __restrict__ dtable) {
+                                                          int pad_idx, float* __restrict__ dtable,
+                                                          const int* __restrict__ row_of_token, float* __restrict__ c_out) {
     __shared__ int s_tok[kGWin];
     __shared__ short s_leader[kGWin], s_cnt[kGWin], s_start[kGWin], s_sorted[kGWin];
     __shared__ int s_fill[kGWin];
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, i
     for (int k = tid; k < kGHash; k += 256) { s_hkey[k] = -1; s_hval[k] = kGWin; }
     for (int r = tid; r < kGWin; r += 256) {
         int t = -1;
-        if (r < nrow) { t = (int)ids[(long)b * L + p0 + r]; if (t == pad_idx) t = -1; }
+        // c_out mode keeps the pad token: its row feeds the weight gradient (only its TABLE row gets no gradient)
+        if (r < nrow) { t = (int)ids[(long)b * L + p0 + r]; if (t == pad_idx && c_out == nullptr) t = -1; }
         s_tok[r] = t;
         s_fill[r] = 0;
     }
@@ -149,6 +152,16 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, i
         const int cnt = s_cnt[key];
         if (cnt == 0) continue;                      // wave-uniform
         const int base = s_start[key];
+        if (c_out != nullptr) {
+            // token-product backward of the local gate: only the win tap sums c_j of the token leave the workgroup
+            const int row = row_of_token[s_tok[key]];
+            if (lane < win && row >= 0) {
+                float cj = 0.f;
+                for (int q = 0; q < cnt; ++q) cj += s_dpre[s_sorted[base + q] - lane + 2 * pad];
+                atomicAdd(c_out + (long)row * kGateWP + lane, cj);
+            }
+            continue;
+        }
         float* drow = dtable + (long)s_tok[key] * E;
         if (is_global) {
             for (int e = lane; e < E; e += 64) {
@@ -339,6 +352,142 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------- local gate, token-product form
+// The gate's input is an embedding LOOKUP too: pre[b,l] = b0 + sum_j S[ids[b, l+j-pad]][j] with S[t][j] = <table[t,:], w[:,j]>,
+// so S is needed once per DISTINCT token of the batch (21 k of 1 M positions at cfg4) and the gate itself is a gather of
+// `win` scalars per position from a table that lives in L2.  Backward: c[t][j] = sum of dpre over the positions whose tap j
+// lands on token t (LDS-bucketed per 256-position window, gate_bwd_dx_kernel's c_out mode), then
+//   dtable[t,:] = sum_j c[t][j] w[:,j]   (every row written once),   dw[:,j] = sum_t c[t][j] table[t,:],   db0 = sum_t c[t][pad].
+__global__ __launch_bounds__(256) void gp_mark_kernel(long n, const long long* __restrict__ ids, int* __restrict__ used) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) used[ids[k]] = 1;
+}
+
+__global__ __launch_bounds__(256) void gp_compact_kernel(int V, int cap, const int* __restrict__ used, int* __restrict__ row_of_token,
+                                                         int* __restrict__ tok_of_row, int* __restrict__ counter) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int u = (v < V) ? used[v] : 0;
+    const unsigned long long b = __ballot(u);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
+    base = __shfl(base, 0);
+    if (v < V) {
+        int row = -1;
+        if (u) {
+            row = base + __popcll(b & ((1ull << lane) - 1));
+            if (row < cap) tok_of_row[row] = v; else row = -1;
+        }
+        row_of_token[v] = row;
+    }
+}
+
+// S[row][j] = <table[tok_of_row[row], :], w[:, j]>; one wave per row
+__global__ __launch_bounds__(256) void gp_taps_kernel(int E, int win, int cap, const int* __restrict__ counter,
+                                                      const int* __restrict__ tok_of_row, const float* __restrict__ table,
+                                                      const float* __restrict__ w, float* __restrict__ S) {
+    const int n = min(*counter, cap);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+        const float* trow = table + (long)tok_of_row[row] * E;
+        float acc[kGateWP];
+#pragma unroll
+        for (int j = 0; j < kGateWP; ++j) acc[j] = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float x = trow[e];
+#pragma unroll
+            for (int j = 0; j < kGateWP; ++j)
+                if (j < win) acc[j] = fmaf(x, w[(long)e * win + j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kGateWP; ++j) acc[j] = wsum(acc[j]);
+        if (lane < kGateWP) {
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < kGateWP; ++j) if (j == lane) v = acc[j];
+            S[(long)row * kGateWP + lane] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_gate_kernel(int B, int L, int win, const long long* __restrict__ ids,
+                                                      const int* __restrict__ row_of_token, const float* __restrict__ S,
+                                                      const float* __restrict__ b0, float* __restrict__ gate) {
+    const long n = (long)B * L;
+    const int pad = (win - 1) / 2;
+    const float bias = b0[0];
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        const int l = (int)(k % L);
+        float s = 0.f;
+        for (int j = 0; j < win; ++j) {
+            const int p = l + j - pad;
+            if (p < 0 || p >= L) continue;                    // zero padding outside the document
+            const int row = row_of_token[ids[k + j - pad]];
+            s += S[(long)row * kGateWP + j];
+        }
+        gate[k] = sigmoidf_(s + bias);
+    }
+}
+
+// dtable[v, :] = sum_j c[row(v)][j] w[:, j]  (0 for absent tokens and the pad row): the whole [V, E] gradient is overwritten
+__global__ __launch_bounds__(256) void gp_dtable_kernel(int V, int E, int win, int pad_idx, const int* __restrict__ row_of_token,
+                                                        const float* __restrict__ c, const float* __restrict__ w,
+                                                        float* __restrict__ dtable) {
+    const long n = (long)V * E;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        const int v = (int)(k / E), e = (int)(k - (long)v * E);
+        const int row = row_of_token[v];
+        float s = 0.f;
+        if (row >= 0 && v != pad_idx)
+            for (int j = 0; j < win; ++j) s = fmaf(c[(long)row * kGateWP + j], w[(long)e * win + j], s);
+        dtable[k] = s;
+    }
+}
+
+// per-chunk partial of dw[e, j] = sum_rows c[row][j] * table[tok][e]  and  db0 = sum_rows c[row][pad]; 128 rows per workgroup
+constexpr int kGpRows = 128;
+__global__ __launch_bounds__(256) void gp_dw_partial_kernel(int E, int win, int cap, const int* __restrict__ counter,
+                                                            const int* __restrict__ tok_of_row, const float* __restrict__ table,
+                                                            const float* __restrict__ c, float* __restrict__ part) {
+    __shared__ float s_c[kGpRows * kGateWP];
+    __shared__ long s_off[kGpRows];
+    const int n = min(*counter, cap);
+    const int r0 = blockIdx.x * kGpRows, rows = max(0, min(kGpRows, n - r0));
+    const int n_out = win * E + 1;
+    float* my = part + (long)blockIdx.x * n_out;
+    for (int e = threadIdx.x; e < rows * kGateWP; e += 256) s_c[e] = c[(long)r0 * kGateWP + e];
+    for (int r = threadIdx.x; r < rows; r += 256) s_off[r] = (long)tok_of_row[r0 + r] * E;
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) {
+        float acc[kGateWP];
+#pragma unroll
+        for (int j = 0; j < kGateWP; ++j) acc[j] = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const float x = table[s_off[r] + e];
+#pragma unroll
+            for (int j = 0; j < kGateWP; ++j) acc[j] = fmaf(s_c[r * kGateWP + j], x, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kGateWP; ++j)
+            if (j < win) my[(long)e * win + j] = acc[j];
+    }
+    if (threadIdx.x == 0) {
+        float sb = 0.f;
+        const int pad = (win - 1) / 2;
+        for (int r = 0; r < rows; ++r) sb += s_c[r * kGateWP + pad];
+        my[n_out - 1] = sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void gp_dw_final_kernel(int n_chunks, int n_out, const float* __restrict__ part,
+                                                          float* __restrict__ dw, float* __restrict__ db0) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    float t = 0.f;
+    for (int k = 0; k < n_chunks; ++k) t += part[(long)k * n_out + o];
+    if (o < n_out - 1) dw[o] = t; else db0[0] = t;
+}
+
 }  // namespace rbr
 
 using namespace rbr;
@@ -396,7 +545,8 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
     if (dtable != nullptr) {
         const int nwin = (L + kGWin - 1) / kGWin;
         hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
-                           (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable);
+                           (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable, (const int*)nullptr,
+                           (float*)nullptr);
         RBR_CHECK_LAUNCH("datt local gate bwd dx launch");
     }
     return 0;
@@ -420,8 +570,102 @@ extern "C" int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const i
         RBR_CHECK_LAUNCH("datt global gate transpose launch");
         const int nwin = (L + kGWin - 1) / kGWin;
         hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, 1, 1, nwin, ids64, w,
-                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable);
+                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable, (const int*)nullptr, (float*)nullptr);
         RBR_CHECK_LAUNCH("datt global gate bwd dx launch");
+    }
+    return 0;
+}
+
+// ---- token-product local gate (same results as rbr_datt_local_gate_fwd / _bwd; `ws` must survive from forward to backward)
+namespace {
+struct GateProdLayout { size_t used, counter, row_of_token, tok_of_row, S, c, part, total; int cap, n_chunks; };
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+bool gate_prod_layout(int B, int L, int E, int win, int V, GateProdLayout& G) {
+    if (B <= 0 || L <= 0 || E <= 0 || V <= 0 || win <= 0 || win > kGateWP || win % 2 == 0) return false;
+    const long n_pos = (long)B * L;
+    G.cap = (int)std::min<long>(V, n_pos);
+    G.n_chunks = (G.cap + kGpRows - 1) / kGpRows;
+    size_t o = 0;
+    G.used = o;         o += al256((size_t)V * sizeof(int));
+    G.counter = o;      o += 256;                                   // contiguous with `used`: zeroed together
+    G.row_of_token = o; o += al256((size_t)V * sizeof(int));
+    G.tok_of_row = o;   o += al256((size_t)G.cap * sizeof(int));
+    G.S = o;            o += al256((size_t)G.cap * kGateWP * sizeof(float));
+    G.c = o;            o += al256((size_t)G.cap * kGateWP * sizeof(float));
+    G.part = o;         o += al256((size_t)G.n_chunks * ((size_t)win * E + 1) * sizeof(float));
+    G.total = o;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t rbr_datt_local_gate_prod_ws_bytes(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V) {
+    GateProdLayout G;
+    if (!gate_prod_layout(B, L, E, win, V, G)) return 0;
+    // worth it when the vocabulary bounds the distinct tokens well below the position count (as rbr_textcnn_fwd_ws_bytes)
+    const int mode = forced_conv_mode();
+    if (mode == 1) return 0;
+    if (mode != 2 && ((long)V * 5 > (long)B * L * 2 || (long)B * L < 4096)) return 0;
+    return G.total;
+}
+
+extern "C" int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids,
+                                            const float* table, const float* w, const float* b0, float* gate, void* ws,
+                                            void* stream) {
+    GateProdLayout G;
+    if (!gate_prod_layout(B, L, E, win, V, G)) { set_error("bad local gate shape B=%d L=%d E=%d win=%d V=%d", B, L, E, win, V); return RBR_ERR_BAD_ARG; }
+    if (!ids || !table || !w || !b0 || !gate || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(ws);
+    int* used = reinterpret_cast<int*>(base + G.used);
+    int* counter = reinterpret_cast<int*>(base + G.counter);
+    int* row_of_token = reinterpret_cast<int*>(base + G.row_of_token);
+    int* tok_of_row = reinterpret_cast<int*>(base + G.tok_of_row);
+    float* S = reinterpret_cast<float*>(base + G.S);
+    const long long* ids64 = reinterpret_cast<const long long*>(ids);
+    if (int e = zero_words(used, G.row_of_token - G.used, st)) return e;
+    const long n_pos = (long)B * L;
+    hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos, ids64, used);
+    RBR_CHECK_LAUNCH("datt gate mark launch");
+    hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, G.cap, used, row_of_token, tok_of_row, counter);
+    RBR_CHECK_LAUNCH("datt gate compact launch");
+    hipLaunchKernelGGL(gp_taps_kernel, dim3((unsigned)std::min((G.cap + 3) / 4, 4096)), dim3(256), 0, st, E, win, G.cap, counter,
+                       tok_of_row, table, w, S);
+    RBR_CHECK_LAUNCH("datt gate taps launch");
+    hipLaunchKernelGGL(gp_gate_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, B, L, win, ids64,
+                       row_of_token, S, b0, gate);
+    RBR_CHECK_LAUNCH("datt gate gather launch");
+    return 0;
+}
+
+extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids,
+                                            const float* table, const float* w, const float* gate, const float* dgate,
+                                            int32_t pad_idx, float* dw, float* db0, float* dtable, void* ws, void* stream) {
+    GateProdLayout G;
+    if (!gate_prod_layout(B, L, E, win, V, G)) { set_error("bad local gate shape B=%d L=%d E=%d win=%d V=%d", B, L, E, win, V); return RBR_ERR_BAD_ARG; }
+    if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(ws);
+    const int* counter = reinterpret_cast<const int*>(base + G.counter);
+    const int* row_of_token = reinterpret_cast<const int*>(base + G.row_of_token);
+    const int* tok_of_row = reinterpret_cast<const int*>(base + G.tok_of_row);
+    float* c = reinterpret_cast<float*>(base + G.c);
+    float* part = reinterpret_cast<float*>(base + G.part);
+    const long long* ids64 = reinterpret_cast<const long long*>(ids);
+    if (int e = zero_words(c, (size_t)G.cap * kGateWP * sizeof(float), st)) return e;
+    const int nwin = (L + kGWin - 1) / kGWin;
+    hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
+                       (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, (float*)nullptr, row_of_token, c);
+    RBR_CHECK_LAUNCH("datt gate tap-sum launch");
+    const int n_out = win * E + 1;
+    hipLaunchKernelGGL(gp_dw_partial_kernel, dim3(G.n_chunks), dim3(256), 0, st, E, win, G.cap, counter, tok_of_row, table, c, part);
+    RBR_CHECK_LAUNCH("datt gate dw partial launch");
+    hipLaunchKernelGGL(gp_dw_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, G.n_chunks, n_out, part, dw, db0);
+    RBR_CHECK_LAUNCH("datt gate dw final launch");
+    if (dtable != nullptr) {
+        const long n = (long)V * E;
+        hipLaunchKernelGGL(gp_dtable_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, V, E, win, pad_idx,
+                           row_of_token, c, w, dtable);
+        RBR_CHECK_LAUNCH("datt gate dtable launch");
     }
     return 0;
 }

@@ -77,6 +77,8 @@ int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, co
 // Token-product forward (textcnn_prod.hip): returns 1 when it produced pval/pidx, 0 when the dense conv must run.
 int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const unsigned char* mask, const float* gate,
                       const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st);
+// 0 auto, 1 dense forced, 2 token-product forced (rbr_set_conv_mode / RBR_CONV_MODE)
+int forced_conv_mode();
 // Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not
 // hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and stays a chain of
 // plain kernel nodes (memset nodes of these shapes faulted on replay with ROCm 7.2).

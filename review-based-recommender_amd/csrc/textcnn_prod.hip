@@ -435,6 +435,17 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
 
 extern "C" void rbr_set_conv_mode(int32_t mode) { g_conv_mode = (mode >= 0 && mode <= 2) ? mode : -1; }
 
+namespace rbr {
+// 0 auto, 1 dense forced, 2 product forced (rbr_set_conv_mode, else RBR_CONV_MODE): shared with the token-product gate
+int forced_conv_mode() {
+    if (g_conv_mode >= 0) return g_conv_mode;
+    static const char* env = getenv("RBR_CONV_MODE");
+    if (env && !strcmp(env, "dense")) return 1;
+    if (env && !strcmp(env, "product")) return 2;
+    return 0;
+}
+}  // namespace rbr
+
 extern "C" size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return 0;

@@ -561,6 +561,7 @@ class _DattGate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, w, b0, ids, is_global, padding_idx):
+        ctx.gate_ws = None
         B, L = ids.shape
         E = table.shape[1]
         win = w.shape[2]
@@ -574,9 +575,17 @@ class _DattGate(torch.autograd.Function):
                                               dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
                                               current_stream()), "rbr_datt_global_gate_fwd")
         else:
-            check(L_.rbr_datt_local_gate_fwd(B, L, E, win, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
-                                             dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
-                                             current_stream()), "rbr_datt_local_gate_fwd")
+            V = table.shape[0]
+            ws_bytes = L_.rbr_datt_local_gate_prod_ws_bytes(B, L, E, win, V)     # > 0: token-product form of the gate
+            if ws_bytes:
+                ctx.gate_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+                check(L_.rbr_datt_local_gate_fwd_prod(B, L, E, win, V, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                                      dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
+                                                      ctx.gate_ws.data_ptr(), current_stream()), "rbr_datt_local_gate_fwd_prod")
+            else:
+                check(L_.rbr_datt_local_gate_fwd(B, L, E, win, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                                 dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
+                                                 current_stream()), "rbr_datt_local_gate_fwd")
         ctx.args = (B, L, E, win, bool(is_global), -1 if padding_idx is None else int(padding_idx))
         ctx.save_for_backward(table, w, ids, gate)
         return gate
@@ -590,6 +599,14 @@ class _DattGate(torch.autograd.Function):
         dgate = dgate.contiguous()
         dw = torch.empty_like(w)
         db0 = torch.empty(1, dtype=F32, device=dev)
+        if ctx.gate_ws is not None:      # token-product local gate: the whole table gradient is overwritten
+            dtable = torch.empty_like(table) if ctx.needs_input_grad[0] else None
+            check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, table.shape[0], dev_ptr(ids, I64, "ids"),
+                                                  dev_ptr(table, F32, "table"), dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"),
+                                                  dev_ptr(dgate, F32, "dgate"), pad, dev_ptr(dw, F32, "dw"),
+                                                  dev_ptr(db0, F32, "db0"), dev_ptr(dtable, F32, "dtable"),
+                                                  ctx.gate_ws.data_ptr(), current_stream()), "rbr_datt_local_gate_bwd_prod")
+            return dtable, dw, db0, None, None, None
         dtable = torch.zeros_like(table) if ctx.needs_input_grad[0] else None
         ws = torch.empty(max(1, L_.rbr_datt_gate_bwd_ws_floats(B, L, E, win, int(is_global))), dtype=F32, device=dev)
         if is_global:

@@ -157,3 +157,17 @@ def test_dedup_by_id_equals_plain_path(conv_mode):
     for k in outs[0][1]:
         ref = outs[0][1][k]
         assert float((ref - outs[1][1][k]).abs().max()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
+
+
+def test_dataparallel_wrapper_does_not_crash():
+    """the trainers may wrap the model in nn.DataParallel (train_deepconn_pp.py:129-131); on one visible GPU
+    the wrapper calls the module directly -- forward and backward must still work and parameters keep their names."""
+    cfg = synth.DEEPCONN_CFGS["small"]
+    model = _model(cfg, synth.deepconn_params(cfg, 0))
+    dp = torch.nn.DataParallel(model, device_ids=[0])
+    args, ratings = _batch(synth.deepconn_batch(cfg, 1))
+    pred = dp(*args)
+    assert pred.shape == (cfg["B"],)
+    torch.nn.functional.mse_loss(pred, ratings).backward()
+    assert all(p.grad is not None for p in model.parameters())
+    assert [k[len("module."):] for k in dp.state_dict().keys()] == list(model.state_dict().keys())
