@@ -479,13 +479,17 @@ __global__ __launch_bounds__(256) void gp_dw_partial_kernel(int E, int win, int 
     }
 }
 
-__global__ __launch_bounds__(256) void gp_dw_final_kernel(int n_chunks, int n_out, const float* __restrict__ part,
-                                                          float* __restrict__ dw, float* __restrict__ db0) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
+// one wave per output: lanes stride the chunks that hold rows (ceil(n / 128) of them), shuffle reduction, fixed order
+__global__ __launch_bounds__(256) void gp_dw_final_kernel(int cap, int n_out, const int* __restrict__ counter,
+                                                          const float* __restrict__ part, float* __restrict__ dw,
+                                                          float* __restrict__ db0) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= n_out) return;
+    const int n_chunks = (min(*counter, cap) + kGpRows - 1) / kGpRows;
     float t = 0.f;
-    for (int k = 0; k < n_chunks; ++k) t += part[(long)k * n_out + o];
-    if (o < n_out - 1) dw[o] = t; else db0[0] = t;
+    for (int k = lane; k < n_chunks; k += 64) t += part[(long)k * n_out + o];
+    t = wsum(t);
+    if (lane == 0) { if (o < n_out - 1) dw[o] = t; else db0[0] = t; }
 }
 
 }  // namespace rbr
@@ -659,7 +663,7 @@ extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int
     const int n_out = win * E + 1;
     hipLaunchKernelGGL(gp_dw_partial_kernel, dim3(G.n_chunks), dim3(256), 0, st, E, win, G.cap, counter, tok_of_row, table, c, part);
     RBR_CHECK_LAUNCH("datt gate dw partial launch");
-    hipLaunchKernelGGL(gp_dw_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, G.n_chunks, n_out, part, dw, db0);
+    hipLaunchKernelGGL(gp_dw_final_kernel, dim3((n_out + 3) / 4), dim3(256), 0, st, G.cap, n_out, counter, part, dw, db0);
     RBR_CHECK_LAUNCH("datt gate dw final launch");
     if (dtable != nullptr) {
         const long n = (long)V * E;
