@@ -144,3 +144,26 @@ def test_fullsize_backward_properties_cfg2(conv_mode):
     seen = torch.zeros(table.shape[0], dtype=torch.bool, device=DEV)
     seen[ids[mask]] = True
     assert float(gt[~seen].abs().max()) == 0.0
+
+
+def _random_shape(rng):
+    """A random TextCNN problem with heavily repeated tokens (small vocabulary): exercises the token-product tables,
+    the several dW variants (float4 slots x documents, document-centric, scalar) and multi-group channel layouts."""
+    valid = bool(rng.integers(0, 2))
+    n_w = int(rng.integers(1, 4))
+    kzs = sorted(set(int(k) for k in rng.choice([2, 3, 4] if valid else [1, 3, 5, 7, 9], size=n_w, replace=False)))
+    if not valid:
+        kzs = [k for k in kzs if k % 2 == 1]
+    D = int(rng.choice([4, 8, 12, 36, 60, 100, 152, 300]))
+    L = int(rng.integers(max(kzs), 97))
+    n_docs = int(rng.choice([1, 2, 5, 17, 70]))
+    V = int(rng.choice([7, 50, 400]))
+    chans = [int(rng.choice([1, 5, 32, 50, 90])) for _ in kzs]
+    return dict(n_docs=n_docs, L=L, D=D, V=V, kzs=kzs, chans=chans, mask_p=[None, 0.0, 0.3, 0.8][int(rng.integers(0, 4))],
+                gate=bool(rng.integers(0, 2)), valid=valid, tanh=bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_textcnn_random_shapes(case, conv_mode):
+    rng = np.random.default_rng(1000 + case)
+    _case(seed=case, **_random_shape(rng))
