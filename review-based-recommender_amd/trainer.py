@@ -15,7 +15,8 @@ tables (experiment.py:101-123), the step (train_deepconn_pp.py:161-168), the log
 `--reference-quirks` restores the trainers' hard-coded `[3]` / 150 (train_deepconn_pp.py:125,
 train_narre.py:124-125); `parallel: true` means one process per GPU with an RCCL gradient all-reduce
 (launch with torch.distributed.run) instead of nn.DataParallel; running loss / gnorm are accumulated on
-the device and read back only at log lines (the reference calls loss.item() twice per step).
+the device and read back only at log lines (the reference calls loss.item() twice per step); the config key
+`fast_step: true` switches to HipClipAdam and hipGraph replay of the step (train_step.py).
 """
 from __future__ import annotations
 
@@ -30,7 +31,7 @@ import torch
 import torch.nn as nn
 
 from . import data as D
-from .train_step import make_optimizer, train_step
+from .train_step import GraphedTrainStep, make_optimizer, train_step
 
 
 class Args:
@@ -51,7 +52,7 @@ class EarlyStop(Exception):
 
 DEFAULTS = dict(log_dir="logs", dataset="dataset", log=True, log_idx=500, verbose=False, parallel=False, epochs=64,
                 batch_size=50, lr=0.002, max_grad_norm=5.0, patience=5, dropout=0.5, arch="CNN", use_pretrain=False,
-                num_workers=0, device_cache=True)
+                num_workers=0, device_cache=True, fast_step=False)
 
 
 class ReviewExperiment:
@@ -87,7 +88,11 @@ class ReviewExperiment:
         self.valid_set = cls(args.data_dir, "valid", **kw)
         self._make_dir()
         self.build_model()
-        self.optimizer = make_optimizer(self.model, lr=args.lr)
+        # fast_step: clip + Adam as two HIP launches and the whole step replayed as a hipGraph for full-size batches
+        # (same update rule; see train_step.HipClipAdam / GraphedTrainStep)
+        self.optimizer = make_optimizer(self.model, lr=args.lr, hip_clip_adam=bool(args.fast_step))
+        self._graphed = None
+        self._graphed_key = None
         self.loss_func = nn.MSELoss()
         if self.world > 1 and args.parallel:
             from .distributed import GradAllReduce, broadcast_parameters, init_process_group_from_env
@@ -206,7 +211,7 @@ class ReviewExperiment:
         self.model.train()
         for i, batch in enumerate(loader):
             inputs, ratings = self._to_device(batch)
-            loss, gnorm, _ = train_step(self.model, self.optimizer, inputs, ratings, a.max_grad_norm, self.grad_sync)
+            loss, gnorm = self._step(inputs, ratings)
             self.updates += 1
             loss_sum += loss
             sq_err += loss * ratings.size(0)
@@ -223,6 +228,21 @@ class ReviewExperiment:
                 sq_err.zero_()
                 steps = count = 0
                 start = time.time()
+
+    def _step(self, inputs, ratings):
+        """One optimisation step; with `fast_step` the step recorded for this batch shape is replayed (a ragged last
+        batch, or a batch of another shape, runs eagerly)."""
+        a = self.args
+        if a.fast_step:
+            key = tuple((t.shape, t.dtype) for t in inputs) + ((ratings.shape, ratings.dtype),)
+            if self._graphed is None:
+                self._graphed = GraphedTrainStep(self.model, self.optimizer, inputs, ratings, a.max_grad_norm, self.grad_sync)
+                self._graphed_key = key
+            if key == self._graphed_key:
+                loss, gnorm, _ = self._graphed(inputs, ratings)
+                return loss.clone(), gnorm.clone()          # the graph's outputs are overwritten by the next replay
+        loss, gnorm, _ = train_step(self.model, self.optimizer, inputs, ratings, a.max_grad_norm, self.grad_sync)
+        return loss, gnorm
 
     def valid_one_epoch(self):
         loader = self._loader(self.valid_set, shuffle=False)

@@ -53,3 +53,21 @@ def test_early_stop_and_kernel_size_quirk(tmp_path):
     exp.best_rmse = 0.0                                                  # nothing can improve on it
     with pytest.raises(EarlyStop):
         exp.train()
+
+
+def test_fast_step_trains_like_the_eager_step(tmp_path):
+    """`fast_step: true` (HipClipAdam + hipGraph replay, ragged last batch eager) follows the eager trainer's losses."""
+    from review_based_recommender_amd.trainer import ReviewExperiment, parse_args
+    data_dir = str(tmp_path / "data")
+    make_dataset.write_doc_split(data_dir)
+    logs = {}
+    for fast in (False, True):
+        torch.manual_seed(0)
+        exp = ReviewExperiment("deepconn", parse_args(_cfg(tmp_path, "deepconn", data_dir, fast_step=fast, dropout=0.0, batch_size=4)),
+                               uid=f"f{int(fast)}")
+        exp.train()
+        logs[fast] = [l for l in open(os.path.join(exp.out_dir, "log.txt")).read().splitlines() if l.startswith("valid loss:")]
+    assert len(logs[True]) == len(logs[False]) == 3
+    for a, b in zip(logs[False], logs[True]):
+        va, vb = float(a.split()[2].rstrip(",")), float(b.split()[2].rstrip(","))
+        assert abs(va - vb) <= 5e-3 * max(1.0, abs(va)), (a, b)
