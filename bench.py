@@ -149,6 +149,45 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
+def verify_tap_exchange(model, args, ratings, grad_sync, dist):
+    """Start-up self-check of the tap exchange (distributed.TapExchange) on this job's own ranks: one backward whose
+    gradients are all-reduced densely, the same backward with the table gradient exchanged as taps; the two table
+    gradients must agree on every rank, otherwise the job falls back to the dense all-reduce.  Returns the note that goes
+    into the JSON line."""
+    import torch.nn.functional as F
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.distributed import GradAllReduce
+    table = model.word_embeddings.embedding.weight
+    was_training = model.training
+    model.eval()                                   # no dropout: both passes see the same forward
+    ok = True
+    try:
+        RF.set_tap_sink(None)
+        model.zero_grad(set_to_none=True)
+        F.mse_loss(model(*args), ratings).backward()
+        GradAllReduce(model)(model)
+        ref = table.grad.clone()
+        RF.set_tap_sink(grad_sync.tap)
+        model.zero_grad(set_to_none=True)
+        F.mse_loss(model(*args), ratings).backward()
+        grad_sync(model)
+        err = float((table.grad - ref).abs().max())
+        ok = err <= 1e-7 + 2e-5 * float(ref.abs().max())
+    except Exception as e:                          # any refusal of the path: dense exchange
+        ok, err = False, repr(e)[:100]
+    flag = torch.tensor([1 if ok else 0], device=table.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    model.zero_grad(set_to_none=True)
+    model.train(was_training)
+    if int(flag.item()) == 1:
+        return (f"taps of the word-table gradient all-gathered (fp32, {grad_sync.tap.n * 8 / 1e6:.1f} MB per rank instead of a "
+                f"{table.numel() * 4 / 1e6:.0f} MB all-reduce), the other gradients all-reduced; checked against the dense "
+                f"all-reduce at start-up (max |diff| {err:.1e})")
+    RF.set_tap_sink(None)
+    grad_sync.tap = None
+    return f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {err})"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +197,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
+    ap.add_argument("--dense-exchange", action="store_true",
+                    help="N > 1: all-reduce the dense 60 MB word-table gradient instead of exchanging its taps")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -186,6 +227,7 @@ def main():
     cfg = synth.DEEPCONN_CFGS[WORKLOAD]
 
     grad_sync = None
+    exchange_note = None
     if world > 1:
         import torch.distributed as dist
         from review_based_recommender_amd.distributed import GradAllReduce, init_process_group_from_env
@@ -197,7 +239,11 @@ def main():
     opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
-        grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None)
+        use_taps = not a.dense_exchange and a.comm_dtype == "fp32"
+        grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None,
+                                  tap_table=model.word_embeddings.embedding.weight if use_taps else None)
+        if use_taps:
+            exchange_note = verify_tap_exchange(model, args, ratings, grad_sync, dist)
 
     def barrier():
         if world > 1:
@@ -271,7 +317,7 @@ def main():
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
                        "parallelism": f"dp{world}", "launch": launch_note or ("hipGraph replay" if use_graph else "eager"),
                        "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)",
-                       "grad_allreduce": None if world == 1 else f"RCCL, {a.comm_dtype} wire format, before the clip"},
+                       "grad_exchange": None if world == 1 else (exchange_note or f"RCCL all-reduce, {a.comm_dtype} wire format, before the clip")},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
             "kernel_timing": ("HIP events around the C-ABI launches, eager pass over the same steps after the timed region"

@@ -276,8 +276,11 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
+// FIXED: G holds 2^40-scaled 64-bit fixed-point sums (the data-parallel tap exchange accumulates them with integer
+// atomics, so every rank gets bit-identical rows whatever the arrival order); `gscale` converts back (and averages).
+template <bool FIXED>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
-                                                        const float* __restrict__ G, const float* __restrict__ WT,
+                                                        const void* __restrict__ Gv, float gscale, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
                                                         const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
@@ -291,11 +294,19 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
     const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);      // this wave's columns (KGW % 4 == 0)
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
         // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
-        const float* grow = G + (long)row * A.KG;
         int cnt = 0;
         for (int k0 = kbeg; k0 < kend; k0 += 256) {
             const int k = k0 + 4 * lane;
-            const f32x4 v = (k < kend) ? *reinterpret_cast<const f32x4*>(grow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < kend) {
+                if (FIXED) {
+                    const long long* g64 = static_cast<const long long*>(Gv) + (long)row * A.KG + k;
+                    const longlong2 lo = *reinterpret_cast<const longlong2*>(g64), hi = *reinterpret_cast<const longlong2*>(g64 + 2);
+                    v = f32x4{(float)lo.x * gscale, (float)lo.y * gscale, (float)hi.x * gscale, (float)hi.y * gscale};
+                } else {
+                    v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Gv) + (long)row * A.KG + k);
+                }
+            }
 #pragma unroll
             for (int cpt = 0; cpt < 4; ++cpt) {
                 const bool nz = v[cpt] != 0.f;
@@ -360,6 +371,105 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             float* dst = dtable + (long)v * D;
             for (int q4 = ln; q4 < nq4; q4 += 64) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------- data-parallel tap exchange
+// Across data-parallel ranks the table gradient is  dtable = ((1/N) sum_r G_r) @ Wprod^T  with the SAME Wprod on every rank,
+// and G_r has one non-zero per (document, channel, tap): n_docs * sum(kz*ch) (token, value) pairs -- 3 MB at the cfg2 shape
+// against the 60 MB dense gradient.  Ranks therefore all-gather their taps (fixed size, column implied by the position in
+// the array) and each rebuilds the averaged gradient locally: marks -> union token list, 64-bit fixed-point G (integer
+// atomics: order-independent, so replicas stay bit-identical), sparse product as above.
+constexpr float kTapScale = 1099511627776.f;       // 2^40 units per 1.0: +-8.4e6 range, 9e-13 resolution
+
+__global__ __launch_bounds__(256) void taps_kernel(const ProdBwdArgs A, const long long* __restrict__ ids,
+                                                   const unsigned char* __restrict__ mask, const float* __restrict__ feat,
+                                                   const int* __restrict__ argmax, const float* __restrict__ d_feat,
+                                                   int* __restrict__ tok_out, float* __restrict__ val_out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long o = e / A.KF;
+    const int j = (int)(e - o * A.KF);
+    if (o >= (long)A.n_docs * A.C) return;
+    const int doc = (int)(o / A.C), c = (int)(o - (long)doc * A.C);
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < A.n_widths && c >= A.ch_off[k]) w = k;
+    const int kz = A.kz[w];
+    int tok = -1;
+    float val = 0.f;
+    if (j < kz) {
+        const float g = act_grad(A.act, feat[o], d_feat[o]);
+        const int p = argmax[o] + j - ((A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0);
+        if (g != 0.f && p >= 0 && p < A.L) {
+            const long pos = (long)doc * A.L + p;
+            if (mask == nullptr || mask[pos]) {
+                const long long t = ids[pos];
+                if (t != A.padding_idx) { tok = (int)t; val = g; }
+            }
+        }
+    }
+    tok_out[e] = tok;
+    val_out[e] = val;
+}
+
+__global__ __launch_bounds__(256) void taps_mark_kernel(long n, const int* __restrict__ tok, int* __restrict__ used) {
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256)
+        if (tok[k] >= 0) used[tok[k]] = 1;
+}
+
+// token list of the union + Wprod^T rows (second job of the launch, as in compact_pack_kernel)
+__global__ __launch_bounds__(256) void taps_compact_kernel(const PackJob J, int nb_compact, int V, const int* __restrict__ used,
+                                                           int* __restrict__ row_of_token, long long* __restrict__ tok_of_row,
+                                                           int* __restrict__ counter, const PtrArray W, float* __restrict__ WT) {
+    if ((int)blockIdx.x < nb_compact) {
+        const int v = blockIdx.x * 256 + threadIdx.x;
+        const int u = (v < V) ? used[v] : 0;
+        const unsigned long long b = __ballot(u);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
+        base = __shfl(base, 0);
+        if (v < V) {
+            int row = -1;
+            if (u) { row = base + __popcll(b & ((1ull << lane) - 1)); tok_of_row[row] = v; }
+            row_of_token[v] = row;
+        }
+        return;
+    }
+    const long nb = gridDim.x - nb_compact, b0 = blockIdx.x - nb_compact;
+    const long n_wt = (long)J.cp_real * J.D;
+    for (long e = b0 * 256 + threadIdx.x; e < n_wt; e += nb * 256) {
+        const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
+        WT[e] = prod_weight(J, W, pc, d);
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_g64_rows_kernel(const int* __restrict__ counter, int cap, int KG2, longlong2* __restrict__ G) {
+    const long n = (long)min(*counter, cap) * KG2;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = longlong2{0, 0};
+}
+
+// one thread per gathered tap: (set, document, channel, tap) -> G64[row(token)][column] += round(value * 2^40)
+__global__ __launch_bounds__(256) void taps_accumulate_kernel(const ProdBwdArgs A, long n_items, int n_sets,
+                                                              const int* __restrict__ tok, const float* __restrict__ val,
+                                                              const int* __restrict__ row_of_token,
+                                                              unsigned long long* __restrict__ G64) {
+    const long total = n_items * n_sets;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
+        const int t = tok[k];
+        if (t < 0) continue;
+        const long e = k % n_items;
+        const long o = e / A.KF;
+        const int j = (int)(e - o * A.KF), c = (int)(o % A.C);
+        int w = 0;
+#pragma unroll
+        for (int q = 1; q < RBR_MAX_WIDTHS; ++q)
+            if (q < A.n_widths && c >= A.ch_off[q]) w = q;
+        const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
+        const long long q = __float2ll_rn(val[k] * kTapScale);
+        atomicAdd(G64 + (long)row_of_token[t] * A.KG + col, (unsigned long long)q);
     }
 }
 
@@ -535,8 +645,8 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     RBR_CHECK_LAUNCH("textcnn build_g launch");
     if (dtable == nullptr) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                       tok_of_row, row_of_token, d->V, dtable);
+    hipLaunchKernelGGL(g_times_w_kernel<false>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter,
+                       (const void*)G, 1.f, WT, tok_of_row, row_of_token, d->V, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
@@ -649,6 +759,104 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
                        reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
     RBR_CHECK_LAUNCH("textcnn gather_pool launch");
+    return 0;
+}
+
+// ---- data-parallel tap exchange (see taps_kernel): taps of one rank, and the averaged table gradient from all ranks' taps
+namespace {
+bool taps_args(const rbr_textcnn_desc* d, ProdBwdArgs& A, int& cp_real, int& KG) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return false;
+    memset(&A, 0, sizeof(A));
+    A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.D = d->D;
+    A.padding_idx = d->padding_idx; A.pad_mode = d->pad_mode; A.act = d->act; A.n_widths = d->n_widths;
+    cp_real = 0;
+    for (int w = 0; w < d->n_widths; ++w) {
+        A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
+        A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
+    }
+    KG = (cp_real + 3) / 4 * 4;
+    A.KG = KG;
+    return true;
+}
+struct TapsLayout { size_t used, counter, row_of_token, tok_of_row, WT, G64, total; int KGW; };
+bool taps_layout(const rbr_textcnn_desc* d, int cp_real, int KG, TapsLayout& T) {
+    if (d->D % 4 != 0) return false;
+    T.KGW = ((KG / 4 + kWavesPerWG - 1) / kWavesPerWG) * 4;
+    if ((size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;
+    size_t o = 0;
+    T.used = o;         o += align256((size_t)d->V * sizeof(int));
+    T.counter = o;      o += 256;
+    T.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
+    T.tok_of_row = o;   o += align256((size_t)d->V * sizeof(long long));
+    T.WT = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
+    T.G64 = o;          o += align256((size_t)d->V * KG * sizeof(long long));
+    T.total = o;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t rbr_textcnn_taps_count(const rbr_textcnn_desc* d) {
+    ProdBwdArgs A; int cp, KG;
+    if (!taps_args(d, A, cp, KG)) return 0;
+    return (size_t)A.n_docs * A.C * A.KF;
+}
+
+extern "C" int rbr_textcnn_bwd_taps(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* feat,
+                                    const int32_t* argmax, const float* d_feat, int32_t* tok, float* val, void* stream) {
+    ProdBwdArgs A; int cp, KG;
+    if (!taps_args(d, A, cp, KG)) return RBR_ERR_BAD_ARG;
+    if (!ids || !feat || !argmax || !d_feat || !tok || !val) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const long n = (long)A.n_docs * A.C * A.KF;
+    hipLaunchKernelGGL(taps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A,
+                       reinterpret_cast<const long long*>(ids), mask, feat, argmax, d_feat, tok, val);
+    RBR_CHECK_LAUNCH("textcnn taps launch");
+    return 0;
+}
+
+extern "C" size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d) {
+    ProdBwdArgs A; int cp, KG; TapsLayout T;
+    if (!taps_args(d, A, cp, KG) || !taps_layout(d, cp, KG, T)) return 0;
+    return T.total;
+}
+
+extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
+                                            const float* const* W, void* ws, float* dtable, void* stream) {
+    ProdBwdArgs A; int cp_real, KG; TapsLayout T;
+    if (!taps_args(d, A, cp_real, KG) || !taps_layout(d, cp_real, KG, T)) { set_error("tap exchange does not support this shape"); return RBR_ERR_UNSUPPORTED; }
+    if (n_sets <= 0 || !tok || !val || !W || !ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(ws);
+    int* used = reinterpret_cast<int*>(base + T.used);
+    int* counter = reinterpret_cast<int*>(base + T.counter);
+    int* row_of_token = reinterpret_cast<int*>(base + T.row_of_token);
+    long long* tok_of_row = reinterpret_cast<long long*>(base + T.tok_of_row);
+    float* WT = reinterpret_cast<float*>(base + T.WT);
+    long long* G64 = reinterpret_cast<long long*>(base + T.G64);
+    A.cap = d->V;
+    const long n_items = (long)A.n_docs * A.C * A.KF, total = n_items * n_sets;
+    if (int e = zero_words(used, T.row_of_token - T.used, st)) return e;
+    hipLaunchKernelGGL(taps_mark_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, total, tok, used);
+    RBR_CHECK_LAUNCH("textcnn taps mark launch");
+    PackJob J{};
+    J.n_widths = d->n_widths; J.D = d->D; J.cp_real = cp_real;
+    for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = A.poff[w]; }
+    PtrArray wp{};
+    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
+    const int nb_compact = (d->V + 255) / 256;
+    const int nb_pack = (int)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024);
+    hipLaunchKernelGGL(taps_compact_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, used, row_of_token,
+                       tok_of_row, counter, wp, WT);
+    RBR_CHECK_LAUNCH("textcnn taps compact launch");
+    hipLaunchKernelGGL(zero_g64_rows_kernel, dim3(4096), dim3(256), 0, st, counter, d->V, KG / 2, reinterpret_cast<longlong2*>(G64));
+    RBR_CHECK_LAUNCH("textcnn taps zero launch");
+    hipLaunchKernelGGL(taps_accumulate_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, A, n_items,
+                       n_sets, tok, val, row_of_token, reinterpret_cast<unsigned long long*>(G64));
+    RBR_CHECK_LAUNCH("textcnn taps accumulate launch");
+    const size_t lds = (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
+    hipLaunchKernelGGL(g_times_w_kernel<true>, dim3((unsigned)std::min(d->V, 8192)), dim3(256), lds, st, A, T.KGW, counter,
+                       (const void*)G64, 1.f / (kTapScale * (float)n_sets), WT, tok_of_row, row_of_token, d->V, dtable);
+    RBR_CHECK_LAUNCH("textcnn taps product launch");
     return 0;
 }
 

@@ -44,10 +44,106 @@ def broadcast_parameters(model: nn.Module, src: int = 0, group=None) -> None:
         dist.broadcast(t.data, src=src, group=group)
 
 
+class TapExchange:
+    """Exchange of the word-table gradient in tap form (csrc/textcnn_prod.hip, "data-parallel tap exchange").
+
+    With identical conv weights on every rank the table gradient of the max-pooled TextCNN is
+    dtable = ((1/N) sum_r G_r) @ Wprod^T, and G_r has one non-zero per (document, channel, tap): the ranks all-gather
+    n_docs * C * KF (token, value) pairs (4.3 MB at the cfg2 shape) instead of all-reducing the dense [V, D] gradient
+    (60 MB), and each rebuilds the averaged gradient locally.  The rebuild accumulates in 64-bit fixed point with
+    integer atomics, so every rank computes bit-identical rows and the replicas stay in lock-step.
+
+    Handles ONE un-gated conv call over the table per step (DeepCoNN++); a second call, or a model whose table also
+    receives dense gradient pieces, falls back to the dense all-reduce (GradAllReduce does that when `pending` is False)."""
+
+    def __init__(self, table: nn.Parameter, group=None):
+        self.table = table
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n = 0
+        self.tok = self.val = self.dtable = self.ws = None
+        self.desc = self.weights = None
+        self.calls = 0
+        self.sticky = False     # the backward was recorded into a hipGraph: every replay refills the tap buffers
+
+    # ---- called from functional._TextCNN.backward
+    def accepts(self, table: torch.Tensor, desc, L_) -> bool:
+        import ctypes as C
+        if table.data_ptr() != self.table.data_ptr() or self.calls > 0:
+            self.calls += 1          # a second conv over the table in this step: this one goes the dense way
+            return False
+        return L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc)) > 0
+
+    def local_buffers(self, n: int, dev):
+        if self.tok is None or self.n != n or self.tok.device != dev:
+            self.n = n
+            self.tok = torch.empty(self.world * n, dtype=torch.int32, device=dev)
+            self.val = torch.empty(self.world * n, dtype=torch.float32, device=dev)
+        lo = self.rank * n
+        return self.tok[lo:lo + n], self.val[lo:lo + n]
+
+    def record(self, desc, weights) -> None:
+        self.desc, self.weights = desc, weights
+        self.calls += 1
+        if torch.cuda.is_current_stream_capturing():
+            # no Python runs when the graph is replayed: from now on every synchronisation finds fresh taps
+            self.sticky = True
+
+    # ---- called from GradAllReduce
+    @property
+    def pending(self) -> bool:
+        return self.desc is not None
+
+    def start(self):
+        """Issues the all-gather of the taps; returns the work handles."""
+        n, lo = self.n, self.rank * self.n
+        if dist.get_backend(self.group) == "nccl":
+            return [dist.all_gather_into_tensor(self.tok, self.tok[lo:lo + n], group=self.group, async_op=True),
+                    dist.all_gather_into_tensor(self.val, self.val[lo:lo + n], group=self.group, async_op=True)]
+        hs = []
+        for full in (self.tok, self.val):          # gloo (rehearsals / CPU-hosted tests): list form, out-of-place input
+            hs.append(dist.all_gather(list(full.split(n)), full[lo:lo + n].clone(), group=self.group, async_op=True))
+        return hs
+
+    def finish(self) -> None:
+        """Rebuilds the averaged table gradient from all ranks' taps into table.grad; a step that also sent part of
+        the table gradient the dense way (second conv call) keeps that part in table.grad for the dense all-reduce."""
+        import ctypes as C
+        from . import _lib
+        L_ = _lib.lib()
+        dev = self.tok.device
+        if self.dtable is None:
+            self.dtable = torch.empty_like(self.table)
+            self.ws = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(self.desc)), dtype=torch.uint8, device=dev)
+        _lib.check(L_.rbr_textcnn_dtable_from_taps(C.byref(self.desc), self.world, _lib.dev_ptr(self.tok, torch.int32, "tap tokens"),
+                                                   _lib.dev_ptr(self.val, torch.float32, "tap values"),
+                                                   _lib.ptr_array(self.weights, torch.float32, "conv weight"),
+                                                   self.ws.data_ptr(), _lib.dev_ptr(self.dtable, torch.float32, "dtable"),
+                                                   _lib.current_stream()), "rbr_textcnn_dtable_from_taps")
+        dense_part = self.table.grad if self.calls > 1 else None      # already averaged by the dense all-reduce
+        if dense_part is not None and dense_part is not self.dtable:
+            self.dtable.add_(dense_part)
+        self.table.grad = self.dtable
+        if self.sticky:
+            self.calls = 1
+        else:
+            self.desc = self.weights = None
+            self.calls = 0
+
+
 class GradAllReduce:
     """Callable `grad_sync(model)` hook for train_step(): averages .grad over the process group."""
 
-    def __init__(self, model: nn.Module, group=None, comm_dtype: Optional[torch.dtype] = None):
+    def __init__(self, model: nn.Module, group=None, comm_dtype: Optional[torch.dtype] = None,
+                 tap_table: Optional[nn.Parameter] = None):
+        """`tap_table`: the word-table parameter whose gradient is exchanged in tap form (TapExchange) instead of being
+        all-reduced densely; None keeps the dense all-reduce for every parameter."""
+        self.tap = None
+        if tap_table is not None and dist.get_world_size(group) > 1:
+            from . import functional as RF
+            self.tap = TapExchange(tap_table, group)
+            RF.set_tap_sink(self.tap)
         self.group = group
         self.world = dist.get_world_size(group)
         self.comm_dtype = comm_dtype   # e.g. torch.bfloat16 halves the table bucket; None = exact fp32
@@ -63,6 +159,13 @@ class GradAllReduce:
         op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
         inv = 1.0 / self.world
         handles = []
+        tap_pending = self.tap is not None and self.tap.pending
+        if tap_pending:
+            if self.tap.calls == 1:
+                self.tap.table.grad = None          # a stale gradient of the previous step is not part of this one
+            handles += self.tap.start()
+        elif self.tap is not None:
+            self.tap.calls = 0
         small = [p for p in self.small if p.grad is not None]
         flat = None
         if small:
@@ -92,6 +195,8 @@ class GradAllReduce:
             for p in self.big:
                 if p.grad is not None:
                     p.grad.mul_(inv)
+        if tap_pending:
+            self.tap.finish()
 
 
 def shard_batch(tensors, rank: int, world: int):

@@ -22,6 +22,17 @@ def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     raise RuntimeError(f"mask must be bool or uint8, got {mask.dtype}")
 
 
+# Data-parallel tap exchange (distributed.TapExchange): when a sink is installed, the backward of an un-gated conv over the
+# sink's word table emits its (token, value) taps instead of the dense table gradient; the sink rebuilds the averaged
+# gradient of all ranks after an all-gather of the taps (rbr_textcnn_bwd_taps / rbr_textcnn_dtable_from_taps).
+_TAP_SINK = None
+
+
+def set_tap_sink(sink) -> None:
+    global _TAP_SINK
+    _TAP_SINK = sink
+
+
 class _TextCNN(torch.autograd.Function):
     """feat[n_docs, C] = pool(act(conv(mask * gate * table[ids])))  -- see rbr_textcnn_* in rbr_hip.h."""
 
@@ -135,6 +146,10 @@ class _TextCNN(torch.autograd.Function):
         d_feat = d_feat.contiguous()
         dWs = [torch.empty_like(w) for w in ws]
         dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
+        sink = _TAP_SINK
+        use_taps = (sink is not None and need_table and gate is None and sink.accepts(table, desc, L_))
+        if use_taps:
+            need_table = False          # table.grad is produced by the exchange, after the all-gather of the taps
         bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if ctx.prod_ws is not None else 0
         # the token-product backward overwrites the whole table gradient; the window scatter accumulates into zeros
         dtable = (torch.empty_like(table) if bws_bytes else torch.zeros_like(table)) if need_table else None
@@ -151,6 +166,16 @@ class _TextCNN(torch.autograd.Function):
         if ev is not None:
             ev.record()
         ev = TIMER.record("textcnn_bwd_dtable")
+        if use_taps:
+            tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
+            check(L_.rbr_textcnn_bwd_taps(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                          dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                          dev_ptr(d_feat, F32, "d_feat"), dev_ptr(tok, I32, "tap tokens"),
+                                          dev_ptr(val, F32, "tap values"), st), "rbr_textcnn_bwd_taps")
+            sink.record(desc, list(ws))
+            if ev is not None:
+                ev.record()
+            return (None, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
             # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
