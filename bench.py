@@ -197,8 +197,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
-    ap.add_argument("--dense-exchange", action="store_true",
-                    help="N > 1: all-reduce the dense 60 MB word-table gradient instead of exchanging its taps")
+    ap.add_argument("--exchange", choices=["auto", "taps", "dense"], default="auto",
+                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank) or all-reduce "
+                         "the dense 60 MB gradient; auto = taps up to 4 ranks (the replicated rebuild costs 0.17 / 0.26 / 0.41 ms "
+                         "at 2 / 4 / 8 ranks, tools/dev_taps_bench.py, against one / three / seven xGMI links for the all-reduce)")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -239,7 +241,7 @@ def main():
     opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
-        use_taps = not a.dense_exchange and a.comm_dtype == "fp32"
+        use_taps = a.comm_dtype == "fp32" and (a.exchange == "taps" or (a.exchange == "auto" and world <= 4))
         grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None,
                                   tap_table=model.word_embeddings.embedding.weight if use_taps else None)
         if use_taps:
