@@ -149,7 +149,7 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
-def verify_tap_exchange(model, args, ratings, grad_sync, dist):
+def verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=False):
     """Start-up self-check of the tap exchange (distributed.TapExchange) on this job's own ranks: one backward whose
     gradients are all-reduced densely, the same backward with the table gradient exchanged as taps; the two table
     gradients must agree on every rank, otherwise the job falls back to the dense all-reduce.  Returns the note that goes
@@ -161,6 +161,7 @@ def verify_tap_exchange(model, args, ratings, grad_sync, dist):
     was_training = model.training
     model.eval()                                   # no dropout: both passes see the same forward
     ok = True
+    tap_desc = tap_weights = None
     try:
         RF.set_tap_sink(None)
         model.zero_grad(set_to_none=True)
@@ -170,6 +171,7 @@ def verify_tap_exchange(model, args, ratings, grad_sync, dist):
         RF.set_tap_sink(grad_sync.tap)
         model.zero_grad(set_to_none=True)
         F.mse_loss(model(*args), ratings).backward()
+        tap_desc, tap_weights = grad_sync.tap.desc, grad_sync.tap.weights
         grad_sync(model)
         err = float((table.grad - ref).abs().max())
         ok = err <= 1e-7 + 2e-5 * float(ref.abs().max())
@@ -177,15 +179,54 @@ def verify_tap_exchange(model, args, ratings, grad_sync, dist):
         ok, err = False, repr(e)[:100]
     flag = torch.tensor([1 if ok else 0], device=table.device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok = int(flag.item()) == 1
+    note = None
+    if ok and choose_by_time:
+        # which exchange is faster HERE depends on the links of this node: time both on the job's own ranks.  The tap
+        # path replaces the local table-gradient chain (~0.1 ms), so it is charged its time minus that.
+        import time as _t
+        tap = grad_sync.tap
+
+        def timed(fn, k=5):
+            fn()
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            return (_t.perf_counter() - t0) / k
+
+        def taps_once():
+            tap.desc, tap.weights, tap.calls = desc_w[0], desc_w[1], 1
+            for h in tap.start():
+                h.wait()
+            tap.finish()
+
+        desc_w = (tap_desc, tap_weights)
+        dummy = torch.empty_like(table)
+        op = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+        t_taps = timed(taps_once)
+        t_dense = timed(lambda: dist.all_reduce(dummy, op=op))
+        tt = torch.tensor([t_taps, t_dense], dtype=torch.float64, device=table.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_taps, t_dense = float(tt[0]), float(tt[1])
+        if t_taps - 1.0e-4 > t_dense:
+            ok = False
+            note = (f"RCCL all-reduce of every gradient, fp32 (timed at start-up: dense table all-reduce {t_dense * 1e3:.3f} ms vs "
+                    f"tap exchange + rebuild {t_taps * 1e3:.3f} ms)")
+        else:
+            timing = f"; timed at start-up: {t_taps * 1e3:.3f} ms vs {t_dense * 1e3:.3f} ms for the dense all-reduce"
+    else:
+        timing = ""
     model.zero_grad(set_to_none=True)
     model.train(was_training)
-    if int(flag.item()) == 1:
+    if ok:
         return (f"taps of the word-table gradient all-gathered (fp32, {grad_sync.tap.n * 8 / 1e6:.1f} MB per rank instead of a "
                 f"{table.numel() * 4 / 1e6:.0f} MB all-reduce), the other gradients all-reduced; checked against the dense "
-                f"all-reduce at start-up (max |diff| {err:.1e})")
+                f"all-reduce at start-up (max |diff| {err:.1e}){timing}")
     RF.set_tap_sink(None)
     grad_sync.tap = None
-    return f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {err})"
+    return note or f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {err})"
 
 
 def main():
@@ -198,9 +239,9 @@ def main():
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
     ap.add_argument("--exchange", choices=["auto", "taps", "dense"], default="auto",
-                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank) or all-reduce "
-                         "the dense 60 MB gradient; auto = taps up to 4 ranks (the replicated rebuild costs 0.17 / 0.26 / 0.41 ms "
-                         "at 2 / 4 / 8 ranks, tools/dev_taps_bench.py, against one / three / seven xGMI links for the all-reduce)")
+                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank: 0.17 / 0.26 / "
+                         "0.41 ms at 2 / 4 / 8 ranks) or all-reduce the dense 60 MB gradient; auto times both on the job's own "
+                         "ranks at start-up and keeps the faster one")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -241,11 +282,11 @@ def main():
     opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
     args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
     if world > 1:
-        use_taps = a.comm_dtype == "fp32" and (a.exchange == "taps" or (a.exchange == "auto" and world <= 4))
+        use_taps = a.comm_dtype == "fp32" and a.exchange in ("taps", "auto")
         grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None,
                                   tap_table=model.word_embeddings.embedding.weight if use_taps else None)
         if use_taps:
-            exchange_note = verify_tap_exchange(model, args, ratings, grad_sync, dist)
+            exchange_note = verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=(a.exchange == "auto"))
 
     def barrier():
         if world > 1:
