@@ -65,7 +65,7 @@ class TapExchange:
         self.tok = self.val = self.dtable = self.ws = None
         self.desc = self.weights = None
         self.calls = 0
-        self.sticky = False     # the backward was recorded into a hipGraph: every replay refills the tap buffers
+        self.captured = None    # (desc, weights) of a backward that was recorded into a hipGraph
 
     # ---- called from functional._TextCNN.backward
     def accepts(self, table: torch.Tensor, desc, L_) -> bool:
@@ -87,8 +87,13 @@ class TapExchange:
         self.desc, self.weights = desc, weights
         self.calls += 1
         if torch.cuda.is_current_stream_capturing():
-            # no Python runs when the graph is replayed: from now on every synchronisation finds fresh taps
-            self.sticky = True
+            self.captured = (desc, weights)      # no Python runs when the graph is replayed: see mark_replayed()
+
+    def mark_replayed(self) -> None:
+        """The recorded backward has just been replayed (GraphedTrainStep): its taps are in the buffers."""
+        if self.captured is not None:
+            self.desc, self.weights = self.captured
+            self.calls = 1
 
     # ---- called from GradAllReduce
     @property
@@ -125,11 +130,8 @@ class TapExchange:
         if dense_part is not None and dense_part is not self.dtable:
             self.dtable.add_(dense_part)
         self.table.grad = self.dtable
-        if self.sticky:
-            self.calls = 1
-        else:
-            self.desc = self.weights = None
-            self.calls = 0
+        self.desc = self.weights = None
+        self.calls = 0
 
 
 class GradAllReduce:

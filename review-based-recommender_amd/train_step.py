@@ -191,9 +191,11 @@ class GraphedTrainStep:
         mode = capture_error_mode or ("thread_local" if grad_sync is not None else "global")
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
         self.g_update = None
+        self._static_grads = None
         if grad_sync is None:
             with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
                 self.loss, self.gnorm, self.pred = train_step(model, optimizer, self.batch, self.ratings, max_grad_norm)
+            self._static_grads = [(p, p.grad) for p in model.parameters()]
         else:
             with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
                 optimizer.zero_grad()
@@ -203,6 +205,7 @@ class GraphedTrainStep:
                 loss.backward()
                 self.loss, self.pred = loss.detach(), pred.detach()
             grad_sync(model)
+            self._static_grads = [(p, p.grad) for p in model.parameters()]
             self.g_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool(), capture_error_mode=mode):
                 self.gnorm = clip_and_step(model, optimizer, max_grad_norm)
@@ -226,7 +229,15 @@ class GraphedTrainStep:
         if ratings is not None and ratings is not self.ratings:
             self.ratings.copy_(ratings, non_blocking=True)
         self.g_fwd_bwd.replay()
+        if self._static_grads is not None:
+            # the graphs read and write the gradient tensors they were recorded with; an eager step in between (a ragged
+            # last batch) re-points p.grad elsewhere, so hand the recorded tensors back before anything looks at p.grad
+            for p, g in self._static_grads:
+                p.grad = g
         if self.g_update is not None:
+            tap = getattr(self.grad_sync, "tap", None)
+            if tap is not None:
+                tap.mark_replayed()          # the replayed backward refilled the tap buffers (distributed.TapExchange)
             self.grad_sync(self.model)
             self.g_update.replay()
         return self.loss, self.gnorm, self.pred

@@ -80,6 +80,15 @@ def main():
         tol = 1e-5 if step == 0 else 2e-4
         assert abs(float(ld) - float(lt)) <= tol * max(1.0, abs(float(ld))), (step, float(ld), float(lt))
         assert abs(float(gd) - float(gt)) <= max(tol, 1e-4) * max(1.0, abs(float(gd))), (step, float(gd), float(gt))
+    # an eager step between replays (a trainer's ragged last batch) takes the same exchange and stays correct
+    a3, r3 = batch(40 + rank)
+    ld, _, _ = train_step(m_d, o_d, a3, r3, grad_sync=sync_d)
+    lt, _, _ = train_step(m_t, o_t, a3, r3, grad_sync=sync_t)
+    a4, r4 = batch(50 + rank)
+    train_step(m_d, o_d, a4, r4, grad_sync=sync_d)
+    stepper(a4, r4)
+    torch.cuda.synchronize()
+    assert abs(float(ld) - float(lt)) <= 2e-4 * max(1.0, abs(float(ld))), (float(ld), float(lt))
     # replicas of the tap-exchange model are still bit-identical after the steps (every parameter)
     chk = torch.stack([p.detach().view(torch.int32).to(torch.int64).sum() for p in m_t.parameters()]).cpu()
     allc = [torch.zeros_like(chk) for _ in range(world)]
