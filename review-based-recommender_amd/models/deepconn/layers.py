@@ -13,21 +13,30 @@ import torch.nn as nn
 from ... import functional as RF
 
 
+def _new_param(*shape) -> nn.Parameter:
+    """Uninitialised fp32 parameter; the owning module's reset_parameters() fills it."""
+    return nn.Parameter(torch.empty(*shape))
+
+
+def _uniform_(t: torch.Tensor, bound: float) -> None:
+    with torch.no_grad():
+        t.uniform_(-bound, bound)
+
+
 class WordEmbedding(nn.Module):
     """layers.py:9-24: nn.Embedding(V, D, padding_idx) table; optional pretrained rows; freeze flag."""
 
     def __init__(self, vocab_size, embedding_dim, pretrained_embeddings=None, padding_idx=0, freeze_embeddings=False):
         super().__init__()
-        self.freeze_embeddings = freeze_embeddings
-        self.padding_idx = padding_idx
+        self.freeze_embeddings, self.padding_idx = freeze_embeddings, padding_idx
         # nn.Embedding is kept as the parameter container (state_dict key `embedding.weight`,
         # default N(0,1) init with a zero pad row); its forward is never used.
         self.embedding = nn.Embedding(vocab_size, embedding_dim, padding_idx=padding_idx)
-        self.embedding.weight.requires_grad = not self.freeze_embeddings
-        if pretrained_embeddings is not None:
-            self.embedding.load_state_dict({"weight": torch.as_tensor(pretrained_embeddings)})
+        self.embedding.weight.requires_grad_(not freeze_embeddings)
+        if pretrained_embeddings is None:
+            print("[Warning] not use pretrained embeddings ...")          # the reference's message, layers.py:20
         else:
-            print("[Warning] not use pretrained embeddings ...")
+            self.embedding.load_state_dict({"weight": torch.as_tensor(pretrained_embeddings)})
 
     @property
     def weight(self) -> torch.Tensor:
@@ -43,14 +52,16 @@ class MyConv1d(nn.Module):
 
     def __init__(self, kernel_sizes, in_features, out_features):
         super().__init__()
-        if type(kernel_sizes) is str:
-            kernel_sizes = [int(x) for x in kernel_sizes.split(",")]
-        assert out_features % len(kernel_sizes) == 0
-        assert all([kz % 2 == 1 for kz in kernel_sizes])
-        self.kernel_sizes = [int(k) for k in kernel_sizes]
-        self.out_features_per_kz = out_features // len(kernel_sizes)
-        self.list_of_conv1d = nn.ModuleList([
-            nn.Conv1d(in_features, self.out_features_per_kz, kz, padding=(kz - 1) // 2) for kz in self.kernel_sizes])
+        widths = [int(k) for k in (kernel_sizes.split(",") if isinstance(kernel_sizes, str) else kernel_sizes)]
+        per_width, rest = divmod(out_features, len(widths))
+        # the reference asserts both (layers.py:38-39): same exception type for callers that catch it
+        if rest != 0:
+            raise AssertionError("out_features must divide evenly over the kernel sizes")
+        if any(k % 2 == 0 for k in widths):
+            raise AssertionError("kernel sizes must be odd ('same' padding)")
+        self.kernel_sizes, self.out_features_per_kz = widths, per_width
+        # nn.Conv1d modules are the parameter containers (keys list_of_conv1d.{i}.weight / .bias, torch's default init)
+        self.list_of_conv1d = nn.ModuleList(nn.Conv1d(in_features, per_width, k, padding=k // 2) for k in widths)
 
     def weights(self):
         return [c.weight for c in self.list_of_conv1d]
@@ -120,41 +131,48 @@ class NgramFeat(nn.Module):
 class LastFeat(nn.Module):
     """layers.py:138-165 parameters: W [feat, latent], b [latent], ebd [vocab, latent] (pad row re-initialised)."""
 
+    BOUND = 0.1        # U(-0.1, 0.1) for W and the id embedding (pad row included, quirk 4)
+    BIAS_INIT = 0.1    # deepconn / narre: b = 0.1; simple_siamese: 0 (its subclass)
+
     def __init__(self, vocab_size, feat_size, latent_dim, padding_idx):
         super().__init__()
         self.padding_idx = padding_idx
-        self.W = nn.Parameter(torch.Tensor(feat_size, latent_dim))
-        self.b = nn.Parameter(torch.Tensor(latent_dim))
+        self.W, self.b = _new_param(feat_size, latent_dim), _new_param(latent_dim)      # registered in this order
         self.ebd = nn.Embedding(vocab_size, latent_dim, padding_idx=padding_idx)
         self.reset_parameters()
 
     def reset_parameters(self):
-        bound = 0.1
-        nn.init.uniform_(self.W, -bound, bound)
-        nn.init.constant_(self.b, bound)
-        nn.init.uniform_(self.ebd.weight, -bound, bound)
+        _uniform_(self.W, self.BOUND)
+        _uniform_(self.ebd.weight, self.BOUND)
+        with torch.no_grad():
+            self.b.fill_(self.BIAS_INIT)
 
 
 class FM(nn.Module):
     """layers.py:167-209 parameters: h [latent,1], g_bias [1], user_bias [U,1], item_bias [I,1]; Dropout(p)."""
 
+    BOUND = 0.1
+    G_BIAS_INIT = 0.1      # deepconn / narre; simple_siamese starts the global bias at 4.0 (its subclass)
+    WITH_ID_BIASES = True
+
     def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
         super().__init__()
+        self.user_padding_idx, self.item_padding_idx = user_padding_idx, item_padding_idx
         self.dropout = nn.Dropout(dropout)
-        self.user_padding_idx = user_padding_idx
-        self.item_padding_idx = item_padding_idx
-        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
-        self.user_bias = nn.Embedding(user_size, 1, padding_idx=user_padding_idx)
-        self.item_bias = nn.Embedding(item_size, 1, padding_idx=item_padding_idx)
-        self.g_bias = nn.Parameter(torch.Tensor(1))
+        self.h = _new_param(latent_dim, 1)
+        if self.WITH_ID_BIASES:        # registration order h, user_bias, item_bias, g_bias = the reference's state_dict order
+            self.user_bias = nn.Embedding(user_size, 1, padding_idx=user_padding_idx)
+            self.item_bias = nn.Embedding(item_size, 1, padding_idx=item_padding_idx)
+        self.g_bias = _new_param(1)
         self.reset_parameters()
 
     def reset_parameters(self):
-        bound = 0.1
-        nn.init.uniform_(self.h, -bound, bound)
-        nn.init.uniform_(self.user_bias.weight, -bound, bound)
-        nn.init.uniform_(self.item_bias.weight, -bound, bound)
-        nn.init.constant_(self.g_bias, bound)
+        _uniform_(self.h, self.BOUND)
+        if self.WITH_ID_BIASES:
+            _uniform_(self.user_bias.weight, self.BOUND)
+            _uniform_(self.item_bias.weight, self.BOUND)
+        with torch.no_grad():
+            self.g_bias.fill_(self.G_BIAS_INIT)
 
 
 def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm: FM, u_text_feat, i_text_feat, u_ids, i_ids):

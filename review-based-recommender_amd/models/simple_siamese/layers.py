@@ -4,6 +4,8 @@ import torch
 import torch.nn as nn
 
 from ... import functional as RF
+from ..deepconn.layers import FM as _FM
+from ..deepconn.layers import LastFeat as _LastFeat
 from ..deepconn.layers import WordEmbedding as _WordEmbedding
 
 
@@ -68,66 +70,33 @@ class AddictiveAttention(nn.Module):
         return RF.additive_attention(inputs, input_masks, lin.weight, lin.bias, self.inner_product.weight, node_drop=node_drop)
 
 
-class LastFeat(nn.Module):
-    """layers.py:234-261 -- W [feat, latent], b [latent] (init 0), ebd [vocab, latent]; out = feat @ W + b + ebd[id]."""
-
-    def __init__(self, vocab_size, feat_size, latent_dim, padding_idx):
-        super().__init__()
-        self.W = nn.Parameter(torch.Tensor(feat_size, latent_dim))
-        self.b = nn.Parameter(torch.Tensor(latent_dim))
-        self.ebd = nn.Embedding(vocab_size, latent_dim, padding_idx=padding_idx)
-        self.reset_parameters()
-
-    def reset_parameters(self):
-        nn.init.uniform_(self.W, -0.1, 0.1)
-        nn.init.constant_(self.b, 0.)
-        nn.init.uniform_(self.ebd.weight, -0.1, 0.1)
+class LastFeat(_LastFeat):
+    """layers.py:234-261 -- W [feat, latent], b [latent] (starts at 0 here), ebd [vocab, latent]; out = feat @ W + b + ebd[id]."""
+    BIAS_INIT = 0.0
 
 
-class FMWithoutUIBias(nn.Module):
-    """layers.py:263-297 -- h [latent,1], g_bias [1] (init 4.0); pred = dropout(relu(u*i)) @ h + g_bias."""
+class FM(_FM):
+    """layers.py:299-343 -- h [latent,1], user_bias [U,1], item_bias [I,1], g_bias [1] (starts at 4.0 in this model)."""
+    G_BIAS_INIT = 4.0
+
+
+class FMWithoutUIBias(_FM):
+    """layers.py:263-297 -- h [latent,1], g_bias [1] (4.0); pred = dropout(relu(u*i)) @ h + g_bias, no user / item biases."""
+    G_BIAS_INIT = 4.0
+    WITH_ID_BIASES = False
 
     def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
-        super().__init__()
-        self.dropout = nn.Dropout(dropout)
-        self.user_padding_idx, self.item_padding_idx = user_padding_idx, item_padding_idx
-        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
-        self.g_bias = nn.Parameter(torch.Tensor(1))
+        super().__init__(user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx)
         # the head kernel always adds bias rows: frozen zero tables, outside the state_dict
         self.register_buffer("_zero_user_bias", torch.zeros(user_size, 1), persistent=False)
         self.register_buffer("_zero_item_bias", torch.zeros(item_size, 1), persistent=False)
-        self.reset_parameters()
-
-    def reset_parameters(self):
-        nn.init.uniform_(self.h, -0.1, 0.1)
-        nn.init.constant_(self.g_bias, 4.0)
-
-
-class FM(nn.Module):
-    """layers.py:299-343 -- FMWithoutUIBias + user_bias [U,1] / item_bias [I,1] embeddings."""
-
-    def __init__(self, user_size, item_size, latent_dim, dropout, user_padding_idx, item_padding_idx):
-        super().__init__()
-        self.dropout = nn.Dropout(dropout)
-        self.user_padding_idx, self.item_padding_idx = user_padding_idx, item_padding_idx
-        self.h = nn.Parameter(torch.Tensor(latent_dim, 1))
-        self.user_bias = nn.Embedding(user_size, 1, padding_idx=user_padding_idx)
-        self.item_bias = nn.Embedding(item_size, 1, padding_idx=item_padding_idx)
-        self.g_bias = nn.Parameter(torch.Tensor(1))
-        self.reset_parameters()
-
-    def reset_parameters(self):
-        nn.init.uniform_(self.h, -0.1, 0.1)
-        nn.init.uniform_(self.user_bias.weight, -0.1, 0.1)
-        nn.init.uniform_(self.item_bias.weight, -0.1, 0.1)
-        nn.init.constant_(self.g_bias, 4.0)
 
 
 def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm, u_text_feat, i_text_feat, u_ids, i_ids):
     """LastFeat(user) + LastFeat(item) + FM / FMWithoutUIBias in one HIP kernel pair."""
     drop = RF.dropout_multiplier((u_text_feat.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
-    ub = fm.user_bias.weight if isinstance(fm, FM) else fm._zero_user_bias
-    ib = fm.item_bias.weight if isinstance(fm, FM) else fm._zero_item_bias
+    ub = fm.user_bias.weight if fm.WITH_ID_BIASES else fm._zero_user_bias
+    ib = fm.item_bias.weight if fm.WITH_ID_BIASES else fm._zero_item_bias
     return RF.pair_head(u_text_feat, i_text_feat, u_ids, i_ids,
                         user_feat.W, user_feat.b, user_feat.ebd.weight,
                         item_feat.W, item_feat.b, item_feat.ebd.weight,

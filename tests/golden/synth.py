@@ -162,10 +162,10 @@ def siamese_params(cfg, seed=0):
     sd["review_att_layer.proj_layer.0.bias"] = _uniform(rng, (K,), b)
     sd["review_att_layer.inner_product.weight"] = _uniform(rng, (1, K), 1.0 / math.sqrt(K))
     sd["fm.h"] = _uniform(rng, (K, 1), 0.1)
+    sd["fm.g_bias"] = torch.full((1,), 0.1)          # state_dict order: a module's own parameters, then its children
     if c["UB"]:
         sd["fm.user_bias.weight"] = _uniform(rng, (c["U"], 1), 0.1)
         sd["fm.item_bias.weight"] = _uniform(rng, (c["I"], 1), 0.1)
-    sd["fm.g_bias"] = torch.full((1,), 0.1)
     return sd
 
 

@@ -56,9 +56,11 @@ def test_siamese_matches_reference(golden_dir, name, cfgname, edge):
 
 def test_attention_scores_and_state_dict(golden_dir):
     g = golden(golden_dir, "siamese_small")
+    for name in ("tiny", "small"):          # with and without user / item biases and latent transform
+        c = synth.SIAMESE_CFGS[name]
+        assert list(_model(c).state_dict().keys()) == list(synth.siamese_params(c, 0).keys())
     cfg = synth.SIAMESE_CFGS["small"]
     model = _model(cfg).eval()
-    assert list(model.state_dict().keys()) == list(synth.siamese_params(cfg, 0).keys())
     b = synth.siamese_batch(cfg, 1, edge_cases=True)
     seen = []
     h = model.review_att_layer.register_forward_hook(lambda _m, _i, o: seen.append(o[1]))
