@@ -7,7 +7,7 @@
 //   grad_sqnorm : sum of squares of every gradient, fixed-order partials (no atomics: bitwise reproducible)
 //   clip_adam   : every workgroup reduces the partials to the total norm, derives the clip coefficient, and applies
 //                 g*coef -> exp_avg, exp_avg_sq, param in ONE pass (the clipped gradient is written back, as
-//                 clip_grad_norm_ leaves it): 60 + 480 MB.
+//                 clip_grad_norm_ leaves it, unless the coefficient is exactly 1): 60 + 420..480 MB.
 // Math as torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False):
 //   m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // The step count t lives in device memory (a float, as torch's capturable Adam keeps it) and is advanced by the
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
     if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out != nullptr) *gnorm_out = total;
     // clip_grad_norm_: coef = clamp(max_norm / (total + 1e-6), max = 1)
     const float coef = (max_norm > 0.f) ? fminf(max_norm / (total + 1e-6f), 1.f) : 1.f;
+    const bool clipped = coef != 1.f;          // workgroup-uniform
     const double t = (double)*step;
     const float bc1 = (float)(1.0 - pow((double)beta1, t));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
             P.c -= step_size * M.c / (sqrtf(V.c) / bc2_sqrt + eps);
             RBR_ADAM1(x) RBR_ADAM1(y) RBR_ADAM1(z) RBR_ADAM1(w)
 #undef RBR_ADAM1
-            reinterpret_cast<float4*>(g)[i] = G;
+            if (clipped) reinterpret_cast<float4*>(g)[i] = G;       // coef == 1: .grad already holds the "clipped" gradient
             reinterpret_cast<float4*>(m)[i] = M;
             reinterpret_cast<float4*>(v)[i] = V;
             reinterpret_cast<float4*>(p)[i] = P;
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
             const float gg = g[i] * coef;
             const float mm = m[i] + w1 * (gg - m[i]);
             const float vv = beta2 * v[i] + w2 * gg * gg;
-            g[i] = gg; m[i] = mm; v[i] = vv;
+            if (clipped) g[i] = gg;
+            m[i] = mm; v[i] = vv;
             p[i] -= step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
         }
     }
