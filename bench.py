@@ -239,8 +239,8 @@ def main():
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
     ap.add_argument("--exchange", choices=["auto", "taps", "dense"], default="auto",
-                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank: 0.17 / 0.26 / "
-                         "0.41 ms at 2 / 4 / 8 ranks) or all-reduce the dense 60 MB gradient; auto times both on the job's own "
+                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank: 0.16 / 0.23 / "
+                         "0.37 ms at 2 / 4 / 8 ranks) or all-reduce the dense 60 MB gradient; auto times both on the job's own "
                          "ranks at start-up and keeps the faster one")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")

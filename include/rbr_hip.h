@@ -143,14 +143,15 @@ int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, c
  *   rbr_textcnn_bwd_taps           : tok[e] = token the tap lands on or -1 (tap beyond the kernel, g == 0, masked,
  *                                    out of the document, padding_idx), val[e] = d_feat * act'(feat) or 0.  gate == NULL only.
  *   rbr_textcnn_dtable_from_taps   : `tok` / `val` hold n_sets concatenated tap sets of the SAME descriptor (the all-gathered
- *                                    ranks); OVERWRITES the whole dtable [V, D] with the MEAN over the sets.  Accumulation in
- *                                    64-bit fixed point (2^-40 units) with integer atomics: the result does not depend on the
- *                                    order, so replicas stay bit-identical.  W: HOST array of the conv weights;
- *                                    ws: rbr_textcnn_dtable_from_taps_ws_bytes(d) bytes (0: shape unsupported, D % 4 != 0). */
+ *                                    ranks); OVERWRITES the whole dtable [V, D] with the MEAN over the sets.  The taps are
+ *                                    sorted by token, each token's row is accumulated in LDS in 64-bit fixed point (2^-40
+ *                                    units, integer atomics: independent of the order, so replicas stay bit-identical) and
+ *                                    multiplied by Wprod^T.  W: HOST array of the conv weights;
+ *                                    ws: rbr_textcnn_dtable_from_taps_ws_bytes(d, n_sets) bytes (0: unsupported, D % 4 != 0). */
 size_t rbr_textcnn_taps_count(const rbr_textcnn_desc* d);
 int rbr_textcnn_bwd_taps(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* feat,
                          const int32_t* argmax, const float* d_feat, int32_t* tok, float* val, void* stream);
-size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d);
+size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d, int32_t n_sets);
 int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
                                  const float* const* W, void* ws, float* dtable, void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,

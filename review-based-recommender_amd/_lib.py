@@ -80,7 +80,7 @@ SIGNATURES = {
                                               c_f32p, c_f32p, c_stream]),
     "rbr_textcnn_taps_count": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_taps": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_i32p, c_f32p, c_i32p, c_f32p, c_stream]),
-    "rbr_textcnn_dtable_from_taps_ws_bytes": (C.c_size_t, [_DESC]),
+    "rbr_textcnn_dtable_from_taps_ws_bytes": (C.c_size_t, [_DESC, i32]),
     "rbr_textcnn_dtable_from_taps": (C.c_int, [_DESC, i32, c_i32p, c_f32p, _PP, C.c_void_p, c_f32p, c_stream]),
     "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,
                                   c_f32p, c_f32p, c_f32p, c_stream]),

@@ -22,6 +22,8 @@
 //   g_times_w (dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product; absent tokens' rows zeroed).
 #include "rbr_common.h"
 
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -276,11 +278,8 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
-// FIXED: G holds 2^40-scaled 64-bit fixed-point sums (the data-parallel tap exchange accumulates them with integer
-// atomics, so every rank gets bit-identical rows whatever the arrival order); `gscale` converts back (and averages).
-template <bool FIXED>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
-                                                        const void* __restrict__ Gv, float gscale, const float* __restrict__ WT,
+                                                        const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
                                                         const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
@@ -298,15 +297,7 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
         for (int k0 = kbeg; k0 < kend; k0 += 256) {
             const int k = k0 + 4 * lane;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < kend) {
-                if (FIXED) {
-                    const long long* g64 = static_cast<const long long*>(Gv) + (long)row * A.KG + k;
-                    const longlong2 lo = *reinterpret_cast<const longlong2*>(g64), hi = *reinterpret_cast<const longlong2*>(g64 + 2);
-                    v = f32x4{(float)lo.x * gscale, (float)lo.y * gscale, (float)hi.x * gscale, (float)hi.y * gscale};
-                } else {
-                    v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(Gv) + (long)row * A.KG + k);
-                }
-            }
+            if (k < kend) v = *reinterpret_cast<const f32x4*>(G + (long)row * A.KG + k);
 #pragma unroll
             for (int cpt = 0; cpt < 4; ++cpt) {
                 const bool nz = v[cpt] != 0.f;
@@ -414,52 +405,13 @@ __global__ __launch_bounds__(256) void taps_kernel(const ProdBwdArgs A, const lo
     val_out[e] = val;
 }
 
-__global__ __launch_bounds__(256) void taps_mark_kernel(long n, const int* __restrict__ tok, int* __restrict__ used) {
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256)
-        if (tok[k] >= 0) used[tok[k]] = 1;
-}
-
-// token list of the union + Wprod^T rows (second job of the launch, as in compact_pack_kernel)
-__global__ __launch_bounds__(256) void taps_compact_kernel(const PackJob J, int nb_compact, int V, const int* __restrict__ used,
-                                                           int* __restrict__ row_of_token, long long* __restrict__ tok_of_row,
-                                                           int* __restrict__ counter, const PtrArray W, float* __restrict__ WT) {
-    if ((int)blockIdx.x < nb_compact) {
-        const int v = blockIdx.x * 256 + threadIdx.x;
-        const int u = (v < V) ? used[v] : 0;
-        const unsigned long long b = __ballot(u);
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
-        base = __shfl(base, 0);
-        if (v < V) {
-            int row = -1;
-            if (u) { row = base + __popcll(b & ((1ull << lane) - 1)); tok_of_row[row] = v; }
-            row_of_token[v] = row;
-        }
-        return;
-    }
-    const long nb = gridDim.x - nb_compact, b0 = blockIdx.x - nb_compact;
-    const long n_wt = (long)J.cp_real * J.D;
-    for (long e = b0 * 256 + threadIdx.x; e < n_wt; e += nb * 256) {
-        const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
-        WT[e] = prod_weight(J, W, pc, d);
-    }
-}
-
-__global__ __launch_bounds__(256) void zero_g64_rows_kernel(const int* __restrict__ counter, int cap, int KG2, longlong2* __restrict__ G) {
-    const long n = (long)min(*counter, cap) * KG2;
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = longlong2{0, 0};
-}
-
-// one thread per gathered tap: (set, document, channel, tap) -> G64[row(token)][column] += round(value * 2^40)
-__global__ __launch_bounds__(256) void taps_accumulate_kernel(const ProdBwdArgs A, long n_items, int n_sets,
-                                                              const int* __restrict__ tok, const float* __restrict__ val,
-                                                              const int* __restrict__ row_of_token,
-                                                              unsigned long long* __restrict__ G64) {
+// sort key = token (absent taps -> V, behind every token); payload = (product column, value)
+__global__ __launch_bounds__(256) void taps_keys_kernel(const ProdBwdArgs A, long n_items, int n_sets, int V,
+                                                        const int* __restrict__ tok, const float* __restrict__ val,
+                                                        int* __restrict__ keys, unsigned long long* __restrict__ pay) {
     const long total = n_items * n_sets;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
         const int t = tok[k];
-        if (t < 0) continue;
         const long e = k % n_items;
         const long o = e / A.KF;
         const int j = (int)(e - o * A.KF), c = (int)(o % A.C);
@@ -467,9 +419,130 @@ __global__ __launch_bounds__(256) void taps_accumulate_kernel(const ProdBwdArgs 
 #pragma unroll
         for (int q = 1; q < RBR_MAX_WIDTHS; ++q)
             if (q < A.n_widths && c >= A.ch_off[q]) w = q;
-        const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
-        const long long q = __float2ll_rn(val[k] * kTapScale);
-        atomicAdd(G64 + (long)row_of_token[t] * A.KG + col, (unsigned long long)q);
+        const int col = A.poff[w] + min(j, A.kz[w] - 1) * A.ch[w] + (c - A.ch_off[w]);
+        keys[k] = (t >= 0) ? t : V;
+        pay[k] = ((unsigned long long)(unsigned)col << 32) | (unsigned)__float_as_int(val[k]);
+    }
+}
+
+// first / one-past-last sorted position of every token that has taps (start1 = first + 1, 0 = none)
+__global__ __launch_bounds__(256) void taps_bounds_kernel(long total, int V, const int* __restrict__ keys, int* __restrict__ start1,
+                                                          int* __restrict__ end) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = keys[i];
+        if (k >= V) continue;
+        if (i == 0 || keys[i - 1] != k) start1[k] = (int)i + 1;
+        if (i == total - 1 || keys[i + 1] != k) end[k] = (int)i + 1;
+    }
+}
+
+// Wprod^T rows for the rebuild (the forward's copy lives in a per-call workspace the exchange does not see)
+__global__ __launch_bounds__(256) void taps_wt_kernel(const PackJob J, const PtrArray W, float* __restrict__ WT) {
+    const long n_wt = (long)J.cp_real * J.D;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_wt; e += (long)gridDim.x * 256) {
+        const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
+        WT[e] = prod_weight(J, W, pc, d);
+    }
+}
+
+// One workgroup per token id (grid-stride over the vocabulary).  The token's taps (all ranks, adjacent after the sort)
+// are summed into an LDS row of 64-bit fixed-point cells (2^-40 units, integer atomics: the sum does not depend on the
+// order, so every rank gets the same bits), then the row goes through the same compaction + sparse product as
+// g_times_w_kernel; tokens without taps get a zero row.  No global G, no zero-fill, no global atomics.
+__global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, const int KGW, int V, const int* __restrict__ start1,
+                                                        const int* __restrict__ end, const unsigned long long* __restrict__ pay,
+                                                        float gscale, const float* __restrict__ WT, float* __restrict__ dtable) {
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    long long* s_g = reinterpret_cast<long long*>(s_dyn);                          // [KG]
+    int* s_lists = s_dyn + 2 * A.KG;
+    int* s_pc = s_lists + wave * 2 * KGW;
+    float* s_val = reinterpret_cast<float*>(s_pc + KGW);
+    float* s_part = reinterpret_cast<float*>(s_lists + kWavesPerWG * 2 * KGW);     // [4][D]
+    const int D = A.D, nq4 = D >> 2;
+    const unsigned long long lt = (1ull << lane) - 1;
+    const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);
+    for (int v = blockIdx.x; v < V; v += gridDim.x) {
+        const int s1 = start1[v];                        // workgroup-uniform
+        float* drow = dtable + (long)v * D;
+        if (s1 == 0) {
+            for (int q4 = tid; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(drow + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
+        const int s = s1 - 1, e = end[v];
+        for (int k = tid; k < A.KG; k += 256) s_g[k] = 0;
+        __syncthreads();
+        for (int i0 = s; i0 < e; i0 += 256 * 8) {          // 8 coalesced payload reads in flight per thread
+            unsigned long long pl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256 + tid;
+                pl[u] = (i < e) ? pay[i] : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (pl[u] != ~0ull) {
+                    const float x = __int_as_float((int)(unsigned)(pl[u] & 0xffffffffu));
+                    const long long q = __float2ll_rn(x * kTapScale);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(s_g) + (unsigned)(pl[u] >> 32), (unsigned long long)q);
+                }
+            }
+        }
+        __syncthreads();
+        // non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
+        int cnt = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            const int k = k0 + lane;
+            const float x = (k < kend) ? (float)s_g[k] * gscale : 0.f;
+            const bool nz = x != 0.f;
+            const unsigned long long b = __ballot(nz);
+            if (nz) {
+                const int pos = cnt + __popcll(b & lt);
+                s_pc[pos] = k * D;
+                s_val[pos] = x;
+            }
+            cnt += __popcll(b);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int qblk = 0; qblk < nq4; qblk += 64 * kSpQ4) {
+            f32x4 sum[kSpQ4];
+            int doff[kSpQ4];
+#pragma unroll
+            for (int u = 0; u < kSpQ4; ++u) {
+                const int q4 = qblk + lane + 64 * u;
+                doff[u] = (q4 < nq4) ? 4 * q4 : -1;
+                sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int q0 = 0; q0 < cnt; q0 += 4) {
+                f32x4 wv[4][kSpQ4];
+                float gv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bool ok = q0 + t < cnt;
+                    const int it = ok ? q0 + t : q0;
+                    const float* wrow = WT + s_pc[it];
+                    gv[t] = ok ? s_val[it] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < kSpQ4; ++u)
+                        wv[t][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < kSpQ4; ++u) sum[u] += gv[t] * wv[t][u];
+            }
+#pragma unroll
+            for (int u = 0; u < kSpQ4; ++u)
+                if (doff[u] >= 0) *reinterpret_cast<f32x4*>(s_part + wave * D + doff[u]) = sum[u];
+        }
+        __syncthreads();
+        for (int q4 = tid; q4 < nq4; q4 += 256) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(s_part + 4 * q4);
+#pragma unroll
+            for (int w = 1; w < kWavesPerWG; ++w) r += *reinterpret_cast<const f32x4*>(s_part + w * D + 4 * q4);
+            *reinterpret_cast<f32x4*>(drow + 4 * q4) = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -645,8 +718,8 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     RBR_CHECK_LAUNCH("textcnn build_g launch");
     if (dtable == nullptr) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    hipLaunchKernelGGL(g_times_w_kernel<false>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter,
-                       (const void*)G, 1.f, WT, tok_of_row, row_of_token, d->V, dtable);
+    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
+                       tok_of_row, row_of_token, d->V, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
@@ -779,18 +852,25 @@ bool taps_args(const rbr_textcnn_desc* d, ProdBwdArgs& A, int& cp_real, int& KG)
     A.KG = KG;
     return true;
 }
-struct TapsLayout { size_t used, counter, row_of_token, tok_of_row, WT, G64, total; int KGW; };
-bool taps_layout(const rbr_textcnn_desc* d, int cp_real, int KG, TapsLayout& T) {
-    if (d->D % 4 != 0) return false;
+struct TapsLayout { size_t keys_in, keys, pay_in, pay, start1, end, WT, temp, total; size_t temp_bytes; int KGW; };
+bool taps_layout(const rbr_textcnn_desc* d, int n_sets, long n_items, int cp_real, int KG, TapsLayout& T) {
+    if (d->D % 4 != 0 || n_sets <= 0) return false;
     T.KGW = ((KG / 4 + kWavesPerWG - 1) / kWavesPerWG) * 4;
-    if ((size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;
+    if ((size_t)KG * 8 + (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;
+    const size_t total = (size_t)n_items * n_sets;
+    if (total >= (size_t)1 << 31) return false;
+    T.temp_bytes = 0;
+    int* ni = nullptr; unsigned long long* nl = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, T.temp_bytes, ni, ni, nl, nl, total, 0, 32, (hipStream_t)0);
     size_t o = 0;
-    T.used = o;         o += align256((size_t)d->V * sizeof(int));
-    T.counter = o;      o += 256;
-    T.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
-    T.tok_of_row = o;   o += align256((size_t)d->V * sizeof(long long));
-    T.WT = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
-    T.G64 = o;          o += align256((size_t)d->V * KG * sizeof(long long));
+    T.keys_in = o; o += align256(total * sizeof(int));
+    T.keys = o;    o += align256(total * sizeof(int));
+    T.pay_in = o;  o += align256(total * sizeof(unsigned long long));
+    T.pay = o;     o += align256(total * sizeof(unsigned long long));
+    T.start1 = o;  o += align256((size_t)d->V * sizeof(int));
+    T.end = o;     o += align256((size_t)d->V * sizeof(int));
+    T.WT = o;      o += align256((size_t)cp_real * d->D * sizeof(float));
+    T.temp = o;    o += align256(T.temp_bytes) + 256;
     T.total = o;
     return true;
 }
@@ -814,49 +894,54 @@ extern "C" int rbr_textcnn_bwd_taps(const rbr_textcnn_desc* d, const int64_t* id
     return 0;
 }
 
-extern "C" size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d) {
+extern "C" size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d, int32_t n_sets) {
     ProdBwdArgs A; int cp, KG; TapsLayout T;
-    if (!taps_args(d, A, cp, KG) || !taps_layout(d, cp, KG, T)) return 0;
+    if (!taps_args(d, A, cp, KG) || !taps_layout(d, n_sets, (long)A.n_docs * A.C * A.KF, cp, KG, T)) return 0;
     return T.total;
 }
 
 extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
                                             const float* const* W, void* ws, float* dtable, void* stream) {
     ProdBwdArgs A; int cp_real, KG; TapsLayout T;
-    if (!taps_args(d, A, cp_real, KG) || !taps_layout(d, cp_real, KG, T)) { set_error("tap exchange does not support this shape"); return RBR_ERR_UNSUPPORTED; }
-    if (n_sets <= 0 || !tok || !val || !W || !ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!taps_args(d, A, cp_real, KG)) return RBR_ERR_BAD_ARG;
+    const long n_items = (long)A.n_docs * A.C * A.KF;
+    if (!taps_layout(d, n_sets, n_items, cp_real, KG, T)) { set_error("tap exchange does not support this shape"); return RBR_ERR_UNSUPPORTED; }
+    if (!tok || !val || !W || !ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     char* base = static_cast<char*>(ws);
-    int* used = reinterpret_cast<int*>(base + T.used);
-    int* counter = reinterpret_cast<int*>(base + T.counter);
-    int* row_of_token = reinterpret_cast<int*>(base + T.row_of_token);
-    long long* tok_of_row = reinterpret_cast<long long*>(base + T.tok_of_row);
+    int* keys_in = reinterpret_cast<int*>(base + T.keys_in);
+    int* keys = reinterpret_cast<int*>(base + T.keys);
+    unsigned long long* pay_in = reinterpret_cast<unsigned long long*>(base + T.pay_in);
+    unsigned long long* pay = reinterpret_cast<unsigned long long*>(base + T.pay);
+    int* start1 = reinterpret_cast<int*>(base + T.start1);
+    int* end = reinterpret_cast<int*>(base + T.end);
     float* WT = reinterpret_cast<float*>(base + T.WT);
-    long long* G64 = reinterpret_cast<long long*>(base + T.G64);
+    const long total = n_items * n_sets;
     A.cap = d->V;
-    const long n_items = (long)A.n_docs * A.C * A.KF, total = n_items * n_sets;
-    if (int e = zero_words(used, T.row_of_token - T.used, st)) return e;
-    hipLaunchKernelGGL(taps_mark_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, total, tok, used);
-    RBR_CHECK_LAUNCH("textcnn taps mark launch");
+    hipLaunchKernelGGL(taps_keys_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, A, n_items, n_sets,
+                       d->V, tok, val, keys_in, pay_in);
+    RBR_CHECK_LAUNCH("textcnn taps keys launch");
+    int bits = 1;
+    while ((1L << bits) <= d->V) ++bits;                 // keys are in [0, V]
+    size_t temp_bytes = T.temp_bytes;
+    if (int e = check_hip(rocprim::radix_sort_pairs(base + T.temp, temp_bytes, keys_in, keys, pay_in, pay, (size_t)total, 0, bits, st),
+                          "textcnn taps radix sort"))
+        return e;
+    if (int e = zero_words(start1, align256((size_t)d->V * sizeof(int)), st)) return e;
+    hipLaunchKernelGGL(taps_bounds_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, total, d->V, keys,
+                       start1, end);
+    RBR_CHECK_LAUNCH("textcnn taps bounds launch");
     PackJob J{};
     J.n_widths = d->n_widths; J.D = d->D; J.cp_real = cp_real;
     for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = A.poff[w]; }
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
-    const int nb_compact = (d->V + 255) / 256;
-    const int nb_pack = (int)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024);
-    hipLaunchKernelGGL(taps_compact_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, used, row_of_token,
-                       tok_of_row, counter, wp, WT);
-    RBR_CHECK_LAUNCH("textcnn taps compact launch");
-    hipLaunchKernelGGL(zero_g64_rows_kernel, dim3(4096), dim3(256), 0, st, counter, d->V, KG / 2, reinterpret_cast<longlong2*>(G64));
-    RBR_CHECK_LAUNCH("textcnn taps zero launch");
-    hipLaunchKernelGGL(taps_accumulate_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, A, n_items,
-                       n_sets, tok, val, row_of_token, reinterpret_cast<unsigned long long*>(G64));
-    RBR_CHECK_LAUNCH("textcnn taps accumulate launch");
-    const size_t lds = (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    hipLaunchKernelGGL(g_times_w_kernel<true>, dim3((unsigned)std::min(d->V, 8192)), dim3(256), lds, st, A, T.KGW, counter,
-                       (const void*)G64, 1.f / (kTapScale * (float)n_sets), WT, tok_of_row, row_of_token, d->V, dtable);
-    RBR_CHECK_LAUNCH("textcnn taps product launch");
+    hipLaunchKernelGGL(taps_wt_kernel, dim3((unsigned)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024)), dim3(256), 0, st, J, wp, WT);
+    RBR_CHECK_LAUNCH("textcnn taps weights launch");
+    const size_t lds = (size_t)KG * 8 + (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
+    hipLaunchKernelGGL(taps_rows_kernel, dim3((unsigned)std::min(d->V, 16384)), dim3(256), lds, st, A, T.KGW, d->V, start1, end, pay,
+                       1.f / (kTapScale * (float)n_sets), WT, dtable);
+    RBR_CHECK_LAUNCH("textcnn taps rows launch");
     return 0;
 }
 

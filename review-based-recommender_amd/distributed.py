@@ -73,7 +73,7 @@ class TapExchange:
         if table.data_ptr() != self.table.data_ptr() or self.calls > 0:
             self.calls += 1          # a second conv over the table in this step: this one goes the dense way
             return False
-        return L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc)) > 0
+        return L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc), self.world) > 0
 
     def local_buffers(self, n: int, dev):
         if self.tok is None or self.n != n or self.tok.device != dev:
@@ -120,7 +120,8 @@ class TapExchange:
         dev = self.tok.device
         if self.dtable is None:
             self.dtable = torch.empty_like(self.table)
-            self.ws = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(self.desc)), dtype=torch.uint8, device=dev)
+            self.ws = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(self.desc), self.world), dtype=torch.uint8,
+                                  device=dev)
         _lib.check(L_.rbr_textcnn_dtable_from_taps(C.byref(self.desc), self.world, _lib.dev_ptr(self.tok, torch.int32, "tap tokens"),
                                                    _lib.dev_ptr(self.val, torch.float32, "tap values"),
                                                    _lib.ptr_array(self.weights, torch.float32, "conv weight"),

@@ -25,7 +25,7 @@ for n_sets in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]:
         argmax = (torch.rand(ids.shape[0], 150, generator=g).to(dev) * lens).to(torch.int32)
         assert L_.rbr_textcnn_bwd_taps(C.byref(d), ids.data_ptr(), mask.data_ptr(), feat.data_ptr(), argmax.data_ptr(), dfeat.data_ptr(),
                                        tok[s * n:].data_ptr(), val[s * n:].data_ptr(), st) == 0
-    wsb = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+    wsb = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(d), n_sets), dtype=torch.uint8, device=dev)
     dtable = torch.empty(V, D, device=dev)
     W = _lib.ptr_array(ws, torch.float32, "w")
     for _ in range(3):
