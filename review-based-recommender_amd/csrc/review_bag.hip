@@ -307,6 +307,15 @@ extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V
     const long n_pos = (long)n_rev * T;
     if (n_pos >= (1L << 31)) { set_error("too many token positions"); return RBR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
+    if (n_pos > (1L << 20)) {
+        // above rocPRIM's merge-sort limit the radix sort re-initialises its state with hipMemsetAsync; memset nodes of this
+        // kind faulted when a recorded hipGraph was replayed (ROCm 7.2): refuse to be recorded rather than fault later
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            set_error("review_bag backward over %ld token positions cannot be recorded into a hipGraph (sort uses memset nodes)", n_pos);
+            return RBR_ERR_UNSUPPORTED;
+        }
+    }
     const size_t arr = (((size_t)n_pos * sizeof(int)) + 255) & ~(size_t)255;
     char* base = static_cast<char*>(ws);
     int* keys_in = reinterpret_cast<int*>(base);
