@@ -136,6 +136,13 @@ size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                 const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                 float* dtable, float* dgate, void* stream);
+/* Conv weight / bias gradients from the G the call above left in `bwd_ws` (dW = G^T @ table[distinct tokens] on the f32
+ * MFMA pipe, split over token ranges, fixed-order reduce).  For many short documents (NARRE's reviews) this replaces
+ * rbr_textcnn_bwd_dw; rbr_textcnn_bwd_dw_from_g_ws_floats(d) == 0 means "use rbr_textcnn_bwd_dw".  Needs the SAME fwd_ws /
+ * bwd_ws as the rbr_textcnn_bwd_dtable_prod call that ran just before it (with dtable != NULL). */
+size_t rbr_textcnn_bwd_dw_from_g_ws_floats(const rbr_textcnn_desc* d);
+int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float* table, const float* feat, const float* d_feat,
+                              void* fwd_ws, void* bwd_ws, float* const* dW, float* const* dbias, float* ws, void* stream);
 /* Data-parallel exchange of the table gradient in "tap" form (replaces the dense all-reduce of the [V, D] gradient that
  * nn.DataParallel / a DDP bucket would do for the embedding, train_deepconn_pp.py:129-131): with identical conv weights on
  * every rank, dtable = ((1/N) sum_r G_r) @ Wprod^T, and G_r has one non-zero per (document, channel, tap).

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
     if (row < 0) return;
     const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
     if (dgate != nullptr) atomicAdd(dgate + tok, g * T[(long)row * A.t_pitch + col]);
-    if (t == A.padding_idx || G == nullptr) return;     // nn.Embedding(padding_idx): that row gets no gradient
+    if (G == nullptr) return;
+    // the pad token's row stays in G (the weight gradient needs it); its TABLE row gets no gradient: g_times_w zeroes it
     atomicAdd(G + (long)row * A.KG + col, (gate != nullptr) ? g * gate[tok] : g);
 }
 
@@ -292,6 +293,11 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
     const unsigned long long lt = (1ull << lane) - 1;
     const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);      // this wave's columns (KGW % 4 == 0)
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        if (tok_of_row[row] == A.padding_idx) {             // nn.Embedding(padding_idx): that row gets no gradient
+            float* dst = dtable + (long)A.padding_idx * D;
+            for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;                                        // workgroup-uniform
+        }
         // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
         int cnt = 0;
         for (int k0 = kbeg; k0 < kend; k0 += 256) {
@@ -543,6 +549,104 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
             *reinterpret_cast<f32x4*>(drow + 4 * q4) = r;
         }
         __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------- conv weight gradient from G
+// dW[(w,j,cl), :] = sum over distinct tokens t of G[t][(w,j,cl)] * table[t, :]  =  G^T @ E  (gate and mask are already
+// inside G).  For MANY SHORT documents (NARRE: 5120 reviews of 50 tokens) this contraction over ~20 k distinct tokens
+// (5 GFLOP on the MFMA pipe) replaces 2.3 M window-row reads.  Split over token ranges (grid.z) for parallelism; the
+// partials are reduced in fixed order.  K-major operands: tiles are staged [k][m] in LDS and read with scalar ds_reads.
+constexpr int kDwgSplit = 32;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void dw_from_g_kernel(int KG, int D, int cap, const int* __restrict__ counter,
+                                                        const float* __restrict__ G, const long long* __restrict__ tok_of_row,
+                                                        const float* __restrict__ table, float* __restrict__ part) {
+    __shared__ float As[32][68];          // [k][col]
+    __shared__ float Bs[32][68];          // [k][d]
+    __shared__ long s_off[32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.x * 64, d0 = blockIdx.y * 64, z = blockIdx.z;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n = min(*counter, cap);
+    const int rps = (((n + kDwgSplit - 1) / kDwgSplit) + 31) & ~31;      // token rows per split, multiple of 32
+    const int r_begin = z * rps, r_end = min(n, r_begin + rps);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int c = tid & 63, kq = tid >> 6;                                // element (k = kq + 4 q, c)
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();
+        if (tid < 32) s_off[tid] = (r0 + tid < r_end) ? tok_of_row[r0 + tid] * (long)D : -1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = kq + 4 * q;
+            const int row = r0 + k;
+            As[k][c] = (row < r_end && col0 + c < KG) ? G[(long)row * KG + col0 + c] : 0.f;
+            const long off = s_off[k];
+            Bs[k][c] = (off >= 0 && d0 + c < D) ? table[off + d0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + h][wm * 32 + i], Bs[kk + h][wn * 32 + i], acc, 0, 0, 0);
+    }
+    const int dcol = d0 + wn * 32 + i;
+    if (dcol < D) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = col0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (col < KG) part[((long)z * KG + col) * D + dcol] = acc[r];
+        }
+    }
+}
+
+// dbias partials: chunk b of documents -> part_b[b][c] = sum of g over the chunk (fixed order)
+constexpr int kDbChunks = 64;
+__global__ __launch_bounds__(256) void dbias_partial_kernel(int n_docs, int C, int act, const float* __restrict__ feat,
+                                                            const float* __restrict__ d_feat, float* __restrict__ part_b) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    const int per = (n_docs + kDbChunks - 1) / kDbChunks;
+    const int d_begin = b * per, d_end = min(n_docs, d_begin + per);
+    float s = 0.f;
+    for (int doc = d_begin; doc < d_end; ++doc) s += act_grad(act, feat[(long)doc * C + c], d_feat[(long)doc * C + c]);
+    part_b[(long)b * C + c] = s;
+}
+
+// dW_w[cl, d, j] = sum_z part[z][(w,j,cl)][d];  dbias[c] = sum_b part_b[b][c]   (torch layouts, fixed order)
+__global__ __launch_bounds__(256) void dw_from_g_reduce_kernel(const ProdBwdArgs A, int cp_real, const float* __restrict__ part,
+                                                               const float* __restrict__ part_b, const MutPtrArray dW,
+                                                               const MutPtrArray dbias) {
+    const long n_w = (long)cp_real * A.D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_w + A.C; idx += (long)gridDim.x * 256) {
+        if (idx < n_w) {
+            const int pc = (int)(idx / A.D), d = (int)(idx - (long)pc * A.D);
+            float t = 0.f;
+#pragma unroll 4
+            for (int z = 0; z < kDwgSplit; ++z) t += part[((long)z * A.KG + pc) * A.D + d];
+            int w = 0;
+#pragma unroll
+            for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+                if (k < A.n_widths && pc >= A.poff[k]) w = k;
+            const int rel = pc - A.poff[w];
+            const int j = rel / A.ch[w], cl = rel - j * A.ch[w];
+            dW.p[w][((long)cl * A.D + d) * A.kz[w] + j] = t;
+        } else {
+            const int c = (int)(idx - n_w);
+            float t = 0.f;
+            for (int b = 0; b < kDbChunks; ++b) t += part_b[(long)b * A.C + c];
+            int w = 0;
+#pragma unroll
+            for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+                if (k < A.n_widths && c >= A.ch_off[k]) w = k;
+            dbias.p[w][c - A.ch_off[w]] = t;
+        }
     }
 }
 
@@ -832,6 +936,60 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
                        reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
     RBR_CHECK_LAUNCH("textcnn gather_pool launch");
+    return 0;
+}
+
+// ---- conv weight / bias gradient from G (see dw_from_g_kernel): after rbr_textcnn_bwd_dtable_prod built G in `bwd_ws`
+static bool dw_from_g_applicable(const rbr_textcnn_desc* d) {
+    // the shapes the document-centric dW kernel serves (textcnn_bwd.hip): many short documents
+    long cp = 0;
+    for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
+    return prod_applicable(d) && d->D % 4 == 0 && d->L <= 128 && d->n_docs >= 512 && cp <= 2048;
+}
+
+extern "C" size_t rbr_textcnn_bwd_dw_from_g_ws_floats(const rbr_textcnn_desc* d) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans) || !dw_from_g_applicable(d)) return 0;
+    ProdLayout Lo; ProdBwdLayout B;
+    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return 0;
+    return (size_t)kDwgSplit * B.KG * d->D + (size_t)kDbChunks * plans[0].C;
+}
+
+extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float* table, const float* feat, const float* d_feat,
+                                         void* fwd_ws, void* bwd_ws, float* const* dW, float* const* dbias, float* ws, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (!dw_from_g_applicable(d)) { set_error("dW-from-G does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    if (!table || !feat || !d_feat || !fwd_ws || !bwd_ws || !dW || !dbias || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    ProdLayout Lo; ProdBwdLayout B;
+    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char* fbase = static_cast<char*>(fwd_ws);
+    const long long* tok_of_row = reinterpret_cast<const long long*>(fbase + Lo.tok_of_row);
+    const int* counter = reinterpret_cast<const int*>(fbase + Lo.counter);
+    const float* G = reinterpret_cast<const float*>(static_cast<char*>(bwd_ws) + B.G);
+    ProdBwdArgs A{};
+    A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.KG = B.KG; A.D = d->D; A.cap = Lo.cap;
+    A.act = d->act; A.n_widths = d->n_widths;
+    int cp_real = 0;
+    for (int w = 0; w < d->n_widths; ++w) {
+        A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
+        A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
+    }
+    float* part = ws;
+    float* part_b = ws + (size_t)kDwgSplit * B.KG * d->D;
+    hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                       counter, G, tok_of_row, table, part);
+    RBR_CHECK_LAUNCH("textcnn dw_from_g launch");
+    hipLaunchKernelGGL(dbias_partial_kernel, dim3((A.C + 255) / 256, kDbChunks), dim3(256), 0, st, d->n_docs, A.C, d->act, feat, d_feat,
+                       part_b);
+    RBR_CHECK_LAUNCH("textcnn dbias partial launch");
+    MutPtrArray dWp{}, dbp{};
+    for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
+    const long total = (long)cp_real * d->D + A.C;
+    hipLaunchKernelGGL(dw_from_g_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, A, cp_real,
+                       part, part_b, dWp, dbp);
+    RBR_CHECK_LAUNCH("textcnn dw_from_g reduce launch");
     return 0;
 }
 

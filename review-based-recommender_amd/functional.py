@@ -159,12 +159,16 @@ class _TextCNN(torch.autograd.Function):
         st = current_stream()
         common = (C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(gate, F32, "gate"),
                   dev_ptr(table, F32, "table"))
-        ev = TIMER.record("textcnn_bwd_dw")
-        check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                    dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
-                                    dev_ptr(wsb, F32, "ws"), st), "rbr_textcnn_bwd_dw")
-        if ev is not None:
-            ev.record()
+        # many short documents (NARRE's reviews): dW = G^T @ table[distinct tokens] on the MFMA pipe, from the G the
+        # table-gradient call builds anyway (0 floats of workspace = not this shape: the window-row kernels below)
+        dwg_floats = L_.rbr_textcnn_bwd_dw_from_g_ws_floats(C.byref(desc)) if (need_table and bws_bytes) else 0
+        if not dwg_floats:
+            ev = TIMER.record("textcnn_bwd_dw")
+            check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                        dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                        dev_ptr(wsb, F32, "ws"), st), "rbr_textcnn_bwd_dw")
+            if ev is not None:
+                ev.record()
         ev = TIMER.record("textcnn_bwd_dtable")
         if use_taps:
             tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
@@ -187,6 +191,15 @@ class _TextCNN(torch.autograd.Function):
                                                  dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
+            if dwg_floats:
+                ev = TIMER.record("textcnn_bwd_dw")
+                dwg_ws = torch.empty(dwg_floats, dtype=F32, device=dev)
+                check(L_.rbr_textcnn_bwd_dw_from_g(C.byref(desc), dev_ptr(table, F32, "table"), dev_ptr(feat, F32, "feat"),
+                                                   dev_ptr(d_feat, F32, "d_feat"), ctx.prod_ws.data_ptr(), bws.data_ptr(),
+                                                   ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                                   dev_ptr(dwg_ws, F32, "ws"), st), "rbr_textcnn_bwd_dw_from_g")
+                if ev is not None:
+                    ev.record()
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if packed is None:
             packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
