@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void dw_from_g_kernel(int KG, int D, int cap, 
 }
 
 // dbias partials: chunk b of documents -> part_b[b][c] = sum of g over the chunk (fixed order)
-constexpr int kDbChunks = 64;
+constexpr int kDbChunks = 256;
 __global__ __launch_bounds__(256) void dbias_partial_kernel(int n_docs, int C, int act, const float* __restrict__ feat,
                                                             const float* __restrict__ d_feat, float* __restrict__ part_b) {
     const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
