@@ -19,6 +19,7 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+typedef float f32x4g __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------- local gate
 // One workgroup per (document, tile of 64 tokens): the 64 + win - 1 token rows are staged ONCE in LDS (each row is
@@ -303,11 +304,22 @@ __global__ __launch_bounds__(256) void global_gate_fwd_kernel(int B, int L, int 
                                                               const float* __restrict__ b0, float* __restrict__ gate) {
     __shared__ float s_red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool vec = (E % 4 == 0) && ((((uintptr_t)table) & 15) == 0);
     float part = 0.f;
     for (int l = tid; l < L; l += 256) {
         const float* row = table + ids[(long)b * L + l] * (long)E;
         float s = 0.f;
-        for (int e = 0; e < E; ++e) s = fmaf(row[e], w[(long)e * L + l], s);   // w reads coalesced across threads
+        if (vec) {      // the thread's own row in 16-byte pieces (a quarter of the cache-line touches); w coalesced across threads
+            for (int e = 0; e < E; e += 4) {
+                const f32x4g x = *reinterpret_cast<const f32x4g*>(row + e);
+                s = fmaf(x.x, w[(long)e * L + l], s);
+                s = fmaf(x.y, w[(long)(e + 1) * L + l], s);
+                s = fmaf(x.z, w[(long)(e + 2) * L + l], s);
+                s = fmaf(x.w, w[(long)(e + 3) * L + l], s);
+            }
+        } else {
+            for (int e = 0; e < E; ++e) s = fmaf(row[e], w[(long)e * L + l], s);   // w reads coalesced across threads
+        }
         part += s;
     }
     s_red[tid] = part;
@@ -336,19 +348,45 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dpre_kernel(int B, int L,
     if (tid == 0) { const float g = gate[(long)b * L]; dpre[b] = s_red[0] * g * (1.f - g); }
 }
 
-// dw[e, l] = sum_b dpre[b] * x[b,l,e]  (one workgroup per position l, fixed order);  block L computes db0
+// dw[e, l] = sum_b dpre[b] * x[b,l,e]  (one workgroup per position l);  block L computes db0.  The 256 threads split
+// into document classes x embedding columns (E = 100: two classes), 8 independent row reads in flight per thread; the
+// classes meet in LDS in fixed order.
 __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, int E, const long long* __restrict__ ids,
                                                                  const float* __restrict__ table, const float* __restrict__ dpre,
                                                                  float* __restrict__ dw, float* __restrict__ db0) {
+    __shared__ float s_part[256];
     const int l = blockIdx.x, tid = threadIdx.x;
     if (l == L) {
         if (tid == 0) { float s = 0.f; for (int b = 0; b < B; ++b) s += dpre[b]; db0[0] = s; }
         return;
     }
-    for (int e = tid; e < E; e += 256) {
+    const int ncls = max(1, 256 / E);                 // document classes that fit beside E columns
+    for (int e0 = 0; e0 < E; e0 += 256) {
+        const int cls = (E >= 256) ? 0 : tid / E, e = e0 + ((E >= 256) ? tid : tid - cls * E);
+        const bool live = cls < ncls && e < E;
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s = fmaf(dpre[b], table[ids[(long)b * L + l] * (long)E + e], s);
-        dw[(long)e * L + l] = s;
+        if (live) {
+            for (int b0i = cls; b0i < B; b0i += 8 * ncls) {
+                float x[8], dp[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0i + u * ncls;
+                    const bool ok = b < B;
+                    dp[u] = ok ? dpre[b] : 0.f;
+                    x[u] = ok ? table[ids[(long)b * L + l] * (long)E + e] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fmaf(dp[u], x[u], s);
+            }
+        }
+        __syncthreads();
+        s_part[tid] = live ? s : 0.f;
+        __syncthreads();
+        if (live && cls == 0) {
+            float t = s_part[tid];
+            for (int c2 = 1; c2 < ncls; ++c2) t += s_part[tid + c2 * E];
+            dw[(long)e * L + l] = t;
+        }
     }
 }
 
