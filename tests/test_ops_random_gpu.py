@@ -1,0 +1,156 @@
+"""Seeded random-shape sweeps of the smaller HIP ops against plain torch CPU restatements (oracle/ref_cpu.py and inline
+formulas from the reference files): forward and every gradient, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import max_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+def _cmp_grads(gpu_leaves, cpu_leaves, rtol=2e-4, atol=2e-6):
+    for a, b in zip(gpu_leaves, cpu_leaves):
+        scale = float(b.grad.norm()) + 1e-6
+        assert max_err(a.grad.cpu().numpy(), b.grad.numpy()) <= atol + rtol * scale
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_datt_gates_random(case, conv_mode):
+    """LocalAttention / GlobalAttention gate branches (dual_att/layers.py:34-36,50 and 65-67,84) incl. the token-product gate."""
+    from review_based_recommender_amd import functional as RF
+    rng = np.random.default_rng(200 + case)
+    B, L = int(rng.choice([1, 3, 8])), int(rng.integers(5, 90))
+    E, V = int(rng.choice([4, 12, 100])), int(rng.choice([6, 40, 300]))
+    win = int(rng.choice([1, 3, 5, 7]))
+    is_global = bool(case % 2)
+    g = torch.Generator().manual_seed(case)
+    table = torch.randn(V, E, generator=g) * 0.5
+    ids = torch.randint(0, V, (B, L), generator=g)
+    kw = L if is_global else win
+    w = torch.randn(1, E, kw, generator=g) / np.sqrt(E * kw)
+    b0 = torch.randn(1, generator=g) * 0.1
+    cl = [_leaf(table), _leaf(w), _leaf(b0)]
+    x = F.embedding(ids, cl[0], padding_idx=0).permute(0, 2, 1)
+    ref = torch.sigmoid(F.conv1d(x, cl[1], cl[2], padding=0 if is_global else (win - 1) // 2))      # [B,1,L] or [B,1,1]
+    ref = ref.view(B, -1).expand(B, L)
+    d = torch.randn(B, L, generator=g)
+    (ref * d).sum().backward()
+    gl = [_leaf(t.detach().to(DEV)) for t in (table, w, b0)]
+    out = RF.datt_gate(gl[0], gl[1], gl[2], ids.to(DEV), is_global=is_global, padding_idx=0)
+    (out * d.to(DEV)).sum().backward()
+    assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-6
+    _cmp_grads(gl, cl)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_review_attention_random(case):
+    """NARRE LinearAttention (narre.py:40-64)."""
+    from oracle import ref_cpu as O
+    from review_based_recommender_amd import functional as RF
+    rng = np.random.default_rng(300 + case)
+    B, R, H, A, NI = int(rng.choice([1, 4, 33])), int(rng.integers(1, 13)), int(rng.choice([5, 24, 150])), int(rng.choice([3, 8, 32])), 17
+    g = torch.Generator().manual_seed(case)
+    feat = torch.randn(B, R, H, generator=g) * 0.5
+    oid = torch.randint(0, NI, (B, R), generator=g)
+    ps = [torch.randn(H, A, generator=g) * 0.1, torch.randn(A, A, generator=g) * 0.1, torch.randn(A, 1, generator=g) * 0.1,
+          torch.randn(A, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1, torch.randn(NI, A, generator=g) * 0.1]
+    cl = [_leaf(feat)] + [_leaf(p) for p in ps]
+    ro, ra = O.linear_attention(cl[0], oid, *cl[1:])
+    d = torch.randn(B, H, generator=g)
+    (ro * d).sum().backward()
+    gl = [_leaf(t.detach().to(DEV)) for t in [feat] + ps]
+    go, ga = RF.review_attention(gl[0], oid.to(DEV), *gl[1:], pad_idx=0)
+    (go * d.to(DEV)).sum().backward()
+    assert max_err(go.detach().cpu().numpy(), ro.detach().numpy()) <= 1e-5
+    assert max_err(ga.detach().cpu().numpy(), ra.detach().numpy()) <= 1e-6
+    _cmp_grads(gl, cl)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_siamese_ops_random(case):
+    """review_bag (lookup + variational dropout multiplier + masked mean) and additive attention (+ node dropout multiplier)."""
+    from oracle import ref_cpu as O
+    from review_based_recommender_amd import functional as RF
+    rng = np.random.default_rng(400 + case)
+    n_rev, T, D, V = int(rng.choice([1, 5, 40])), int(rng.integers(1, 40)), int(rng.choice([3, 8, 108])), int(rng.choice([5, 60]))
+    g = torch.Generator().manual_seed(case)
+    table = torch.randn(V, D, generator=g)
+    ids = torch.randint(0, V, (n_rev, T), generator=g)
+    mask = torch.rand(n_rev, T, generator=g) > 0.3
+    drop = (torch.rand(n_rev, D, generator=g) > 0.2).float() / 0.8
+    ct = _leaf(table)
+    x = F.embedding(ids, ct, padding_idx=0) * drop.unsqueeze(1)
+    ref = O.masked_avg_pool(x, mask)
+    d = torch.randn(n_rev, D, generator=g)
+    (ref * d).sum().backward()
+    gt = _leaf(table.to(DEV))
+    out = RF.review_bag(gt, ids.to(DEV), mask.to(DEV), drop=drop.to(DEV), padding_idx=0)
+    (out * d.to(DEV)).sum().backward()
+    assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    _cmp_grads([gt], [ct])
+
+    B, R, H, K = int(rng.choice([1, 6])), int(rng.integers(1, 12)), int(rng.choice([4, 27, 108])), int(rng.choice([2, 32]))
+    rev = torch.randn(B, R, H, generator=g) * 0.5
+    rmask = torch.rand(B, R, generator=g) > 0.3
+    nd = (torch.rand(B, R, generator=g) > 0.25).float() / 0.75
+    ps = [torch.randn(K, H, generator=g) * 0.2, torch.randn(K, generator=g) * 0.1, torch.randn(1, K, generator=g) * 0.3]
+    cl = [_leaf(rev)] + [_leaf(p) for p in ps]
+    ro, rs = O.additive_attention(cl[0] * nd.unsqueeze(2), rmask, *cl[1:])
+    d2 = torch.randn(B, H, generator=g)
+    (ro * d2).sum().backward()
+    gl = [_leaf(t.to(DEV)) for t in [rev] + ps]
+    go, gs = RF.additive_attention(gl[0], rmask.to(DEV), gl[1], gl[2], gl[3], node_drop=nd.to(DEV))
+    (go * d2.to(DEV)).sum().backward()
+    assert max_err(go.detach().cpu().numpy(), ro.detach().numpy()) <= 1e-5
+    assert max_err(gs.detach().cpu().numpy(), rs.detach().numpy()) <= 1e-6
+    _cmp_grads(gl, cl)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_linear_and_head_random(case):
+    """nn.Linear with ReLU / Tanh / dropout multiplier on the MFMA GEMM, and LastFeat x2 + FM."""
+    from oracle import ref_cpu as O
+    from review_based_recommender_amd import functional as RF
+    rng = np.random.default_rng(500 + case)
+    N, IN, OUT = int(rng.choice([1, 37, 130])), int(rng.choice([3, 50, 129])), int(rng.choice([1, 31, 70]))
+    g = torch.Generator().manual_seed(case)
+    x, W, b = torch.randn(N, IN, generator=g), torch.randn(OUT, IN, generator=g) / np.sqrt(IN), torch.randn(OUT, generator=g) * 0.1
+    drop = (torch.rand(N, OUT, generator=g) > 0.5).float() * 2
+    act = ["none", "relu", "tanh"][case % 3]
+    cl = [_leaf(t) for t in (x, W, b)]
+    z = F.linear(*cl)
+    z = F.relu(z) if act == "relu" else torch.tanh(z) if act == "tanh" else z
+    ref = z * drop
+    d = torch.randn(N, OUT, generator=g)
+    (ref * d).sum().backward()
+    gl = [_leaf(t.to(DEV)) for t in (x, W, b)]
+    out = RF.linear(gl[0], gl[1], gl[2], relu=(act == "relu"), tanh=(act == "tanh"), drop=drop.to(DEV))
+    (out * d.to(DEV)).sum().backward()
+    assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 2e-5
+    _cmp_grads(gl, cl)
+
+    B, H, K, U, I = int(rng.choice([1, 9, 64])), int(rng.choice([4, 150])), int(rng.choice([3, 32, 40])), 11, 13
+    uf, itf = torch.randn(B, H, generator=g) * 0.3, torch.randn(B, H, generator=g) * 0.3
+    uid, iid = torch.randint(0, U, (B,), generator=g), torch.randint(0, I, (B,), generator=g)
+    ps = [torch.randn(H, K, generator=g) * 0.1, torch.randn(K, generator=g) * 0.1, torch.randn(U, K, generator=g) * 0.1,
+          torch.randn(H, K, generator=g) * 0.1, torch.randn(K, generator=g) * 0.1, torch.randn(I, K, generator=g) * 0.1,
+          torch.randn(K, 1, generator=g) * 0.3, torch.randn(1, generator=g), torch.randn(U, 1, generator=g) * 0.1,
+          torch.randn(I, 1, generator=g) * 0.1]
+    cl = [_leaf(uf), _leaf(itf)] + [_leaf(p) for p in ps]
+    ul = O.last_feat(cl[0], uid, cl[2], cl[3], cl[4])
+    il = O.last_feat(cl[1], iid, cl[5], cl[6], cl[7])
+    ref = O.fm(ul, il, uid, iid, cl[8], cl[9], cl[10], cl[11]).view(-1)
+    d3 = torch.randn(B, generator=g)
+    (ref * d3).sum().backward()
+    gl = [_leaf(t.to(DEV)) for t in [uf, itf] + ps]
+    out = RF.pair_head(gl[0], gl[1], uid.to(DEV), iid.to(DEV), *gl[2:], pad_u=0, pad_i=0)
+    (out * d3.to(DEV)).sum().backward()
+    assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    _cmp_grads(gl, cl)
