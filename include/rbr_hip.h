@@ -198,6 +198,13 @@ int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
                       const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream);
 
+/* ---- nn.MSELoss(reduction="mean") of the trainers (trainer/train_deepconn_pp.py:137,164):
+ *   loss[0] = sum_i (pred[i]-target[i])^2 / n   (one workgroup, fixed summation order)
+ *   d_pred[i] = 2 (pred[i]-target[i]) / n * d_loss[0]       (d_loss is a device scalar)          ---- */
+int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, void* stream);
+int rbr_mse_loss_bwd(int64_t n, const float* pred, const float* target, const float* d_loss, float* d_pred,
+                     void* stream);
+
 /* ---- NARRE review-level attention pool (narre.py:40-64)
  *   e = ebd[other_id];  logit = relu(feat@W_rv + e@W_id + b1) @ h + b2
  *   att = exp(logit) / (sum_R exp(logit) + 1e-8)   (unmasked, no max subtraction)

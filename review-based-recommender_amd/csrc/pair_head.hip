@@ -166,6 +166,47 @@ static bool head_args_ok(int B, int H, int K) {
     return true;
 }
 
+namespace rbr {
+// ---- nn.MSELoss (mean) of the trainers.  One workgroup, fixed summation order: the loss is bitwise reproducible.
+__global__ __launch_bounds__(256) void mse_fwd_kernel(long n, const float* __restrict__ pred, const float* __restrict__ target,
+                                                      float* __restrict__ loss) {
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float d = pred[i] - target[i];
+        acc += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)n;
+}
+
+__global__ __launch_bounds__(256) void mse_bwd_kernel(long n, const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ d_loss, float* __restrict__ d_pred) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d_pred[i] = (pred[i] - target[i]) * (2.f / (float)n) * d_loss[0];
+}
+
+}  // namespace rbr
+
+extern "C" int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, void* stream) {
+    if (n <= 0 || !pred || !target || !loss) { rbr::set_error("mse_loss_fwd: n=%lld or null pointer", (long long)n); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(rbr::mse_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long)n, pred, target, loss);
+    RBR_CHECK_LAUNCH("mse_fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_mse_loss_bwd(int64_t n, const float* pred, const float* target, const float* d_loss, float* d_pred,
+                                void* stream) {
+    if (n <= 0 || !pred || !target || !d_loss || !d_pred) { rbr::set_error("mse_loss_bwd: n=%lld or null pointer", (long long)n); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(rbr::mse_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)n, pred,
+                       target, d_loss, d_pred);
+    RBR_CHECK_LAUNCH("mse_bwd launch");
+    return 0;
+}
+
 extern "C" int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
                                  const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                                  float* ul, float* il, float* pred, void* stream) {

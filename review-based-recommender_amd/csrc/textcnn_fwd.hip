@@ -425,6 +425,200 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const long long* __
 #endif
 }
 
+// ------------------------------------------------------------------------------------ token-product GEMM, static form
+// The same computation as conv_body<8, DC, true, true> for the common shape (one tap, groups of exactly 8 channel
+// tiles, 16-byte aligned rows), written with everything static: the four tile pairs of a chunk are unrolled, so the
+// accumulator tiles have fixed registers; the weight operands of a pair stream through a three-quad register window
+// (requested two k-steps ahead) and the two accumulation chains are interleaved -- no LDS latency and no dependent-
+// issue gap between MFMAs, and no second whole weight fragment in registers.
+template <int DC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void prod_gemm_kernel(const ConvPlan P, const long long* __restrict__ ids, const unsigned char* __restrict__ mask,
+                      const float* __restrict__ table, const float* __restrict__ packed, float* __restrict__ out,
+                      const int* __restrict__ sched) {
+    static_assert(DC % 4 == 0 && (DC / 4) % 2 == 1, "row stride must be 4*odd floats");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT = 8, TILE_F = kTile * DC, PIECE = 2 * TILE_F, NLD = (PIECE / 4 + 255) / 256, Q = DC / 8;
+    constexpr int XR = kTile, QPR = DC / 4, NX = (XR * QPR + 63) / 64;
+    float* Ws = smem;                              // [2 slots][2 tiles][32][DC]
+    float* Xs = smem + 2 * PIECE;                  // [4 waves][32][DC]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int L = P.L, D = P.D;
+    float* Xw = Xs + wave * XR * DC;
+    long* s_row = reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + wave * XR;
+    int* s_item = reinterpret_cast<int*>(reinterpret_cast<long*>(Xs + kWavesPerWG * XR * DC) + kWavesPerWG * XR);
+    const int ngroups = P.tiles_total / NT;
+    const int n_active = (sched[2 * (long)P.total_wt] + kTile - 1) / kTile;
+    const int nrow_items = (n_active + kWavesPerWG - 1) / kWavesPerWG;
+    const int nitems = nrow_items * ngroups;
+    int* item_counter = const_cast<int*>(sched) + 2 * (long)P.total_wt + 1 + P.group;
+
+    auto issue_round = [&](int k, float* dst, const float* src) {      // one LDS-DMA instruction of a 2-tile piece
+        const int v0 = 256 * k + 64 * wave;
+        if (v0 + lane < PIECE / 4) dma16(src + 4 * (v0 + lane), dst + 4 * v0);
+    };
+
+#ifdef RBR_DIAG
+    unsigned long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+    diag[5] = t_last;                                    // absolute start
+#endif
+    bool first_item = true;
+    for (;;) {
+        int item;
+        if (first_item) {
+            item = blockIdx.x;
+            first_item = false;
+        } else {
+            if ((int)gridDim.x >= nitems) break;
+            __syncthreads();
+            if (tid == 0) *s_item = (int)gridDim.x + atomicAdd(item_counter, 1);
+            __syncthreads();
+            item = *s_item;
+        }
+        if (item >= nitems) break;
+        const int grp = item / nrow_items;
+        const int tile_base = grp * NT;
+        const float* wbase = packed + (long)tile_base * TILE_F;
+        const int slot_in_list = (item - grp * nrow_items) * kWavesPerWG + wave;
+        const bool active = slot_in_list < n_active;
+        const int l0 = (active ? slot_in_list : 0) * kTile;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        auto piece_src = [&](int dcq, int pair) -> const float* { return wbase + ((long)dcq * P.tiles_total + 2 * pair) * TILE_F; };
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) issue_round(k, Ws, piece_src(0, 0));
+        if (active) {
+            for (int row = lane; row < XR; row += 64) {
+                const int p = l0 + row;
+                long ro = -1;
+                if (p < L && (mask == nullptr || mask[p])) ro = ids[p] * (long)D;
+                s_row[row] = ro;
+            }
+        }
+        auto gather_chunk = [&](int dcq) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < XR * QPR) {
+                    const int row = idx / QPR, qq = idx - row * QPR;
+                    const int d = dcq * DC + 4 * qq;
+                    const long ro = s_row[row];
+                    dma16((ro >= 0 && d < D) ? table + ro + d : g_zero_row, Xw + 256 * k);
+                }
+            }
+        };
+        if (active) gather_chunk(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        RBR_STAMP(2);
+
+        int cur = 0;
+        Frag<DC> a;
+        for (int dc = 0; dc < P.nchunks; ++dc) {
+            if (active) {
+                a.load(Xw + i * DC + 4 * h, h);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (dc + 1 < P.nchunks) gather_chunk(dc + 1);       // the slab is free again: next chunk's rows behind the MFMAs
+            }
+#pragma unroll
+            for (int pair = 0; pair < NT / 2; ++pair) {
+                const bool last = (dc + 1 == P.nchunks) && (pair == NT / 2 - 1);
+                float* nxt_dst = Ws + (cur ^ 1) * PIECE;
+                const float* nxt_src = (pair + 1 < NT / 2) ? piece_src(dc, pair + 1) : piece_src(dc + 1, 0);
+                if (active) {
+                    const float* w0p = Ws + cur * PIECE + i * DC + 4 * h;
+                    const float* w1p = w0p + TILE_F;
+                    f32x4 w0[3], w1[3];
+                    w0[0] = *reinterpret_cast<const f32x4*>(w0p);
+                    w1[0] = *reinterpret_cast<const f32x4*>(w1p);
+                    w0[1] = *reinterpret_cast<const f32x4*>(w0p + 8);
+                    w1[1] = *reinterpret_cast<const f32x4*>(w1p + 8);
+                    f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        if (q + 2 < Q) {
+                            w0[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(w0p + 8 * (q + 2));
+                            w1[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(w1p + 8 * (q + 2));
+                        } else if (q + 2 == Q && DC % 8 == 4) {
+                            t0 = *reinterpret_cast<const f32x2*>(w0p - 4 * h + (DC - 4) + 2 * h);
+                            t1 = *reinterpret_cast<const f32x2*>(w1p - 4 * h + (DC - 4) + 2 * h);
+                        }
+                        const f32x4 x0 = w0[q % 3], x1 = w1[q % 3];
+                        f32x16& c0 = acc[2 * pair];
+                        f32x16& c1 = acc[2 * pair + 1];
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].x, x0.x, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].x, x1.x, c1, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].y, x0.y, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].y, x1.y, c1, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].z, x0.z, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].z, x1.z, c1, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, x0.w, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, x1.w, c1, 0, 0, 0);
+                        if (!last && q < NLD) issue_round(q, nxt_dst, nxt_src);
+                    }
+                    if (DC % 8 == 4) {
+                        f32x16& c0 = acc[2 * pair];
+                        f32x16& c1 = acc[2 * pair + 1];
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.x, t0.x, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.x, t1.x, c1, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.y, t0.y, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.t.y, t1.y, c1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = Q; r < NLD; ++r)
+                        if (!last) issue_round(r, nxt_dst, nxt_src);
+                } else if (!last) {
+#pragma unroll
+                    for (int k = 0; k < NLD; ++k) issue_round(k, nxt_dst, nxt_src);
+                }
+                RBR_STAMP(4);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                RBR_STAMP(6);
+                cur ^= 1;
+            }
+        }
+        // epilogue: each 32 x 32 tile through the wave's idle slab, 8 rows x 128 contiguous bytes per store instruction
+        constexpr int TS = 36;
+        static_assert(32 * TS <= kTile * DC, "transpose staging must fit the wave's slab");
+        const int trow = lane >> 3, tcq = lane & 7;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xw[((r & 3) + 8 * (r >> 2) + 4 * h) * TS + i] = acc[tt][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int rr = trow + 8 * pass;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Xw + rr * TS + 4 * tcq);
+                    const int row = l0 + rr;
+                    if (row < L) *reinterpret_cast<f32x4*>(out + (long)row * P.nslots_total + (long)(tile_base + tt) * kTile + 4 * tcq) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        RBR_STAMP(7);
+    }
+#ifdef RBR_DIAG
+    if (tid == 0 && blockIdx.x < 1024) {
+        diag[3] = t_last;                                // absolute end
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g_diag[8 * blockIdx.x + k] = diag[k];
+    }
+#endif
+}
+
 // pooling conv: up to 5 channel tiles per launch group (2 waves/SIMD with the default register split)
 template <int NT, int DC, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvPlan P, const long long* __restrict__ ids,
@@ -508,6 +702,21 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
     const dim3 grid(std::min(nitems, num_cus() * occ[sm])), block(256);
     if (p.store_rows) {
         if (gate != nullptr) { set_error("store mode takes no gate"); return RBR_ERR_UNSUPPORTED; }
+        static const bool generic_only = getenv("RBR_DEV_GENERIC_GEMM") != nullptr;      // tuning aid
+        if constexpr (NT == 8 && VEC && DC >= 36 && (DC / 4) % 2 == 1) if (p.KF == 1 && p.n_docs == 1 && !generic_only) {
+            const size_t smem2 = (size_t)(4 * kTile * DC + kWavesPerWG * kTile * DC) * sizeof(float) +
+                                 (size_t)kWavesPerWG * kTile * sizeof(long) + 16;
+            static int occ2 = 0;
+            if (occ2 == 0) {
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prod_gemm_kernel<DC>, 256, smem2) != hipSuccess || nb <= 0) nb = 2;
+                occ2 = nb;
+            }
+            hipLaunchKernelGGL((prod_gemm_kernel<DC>), dim3(std::min(nitems, num_cus() * occ2)), block, smem2, st, p, ids, mask, table,
+                               packed, pval, sched);
+            RBR_CHECK_LAUNCH("textcnn prod_gemm launch");
+            return 0;
+        }
         hipLaunchKernelGGL((conv_store_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, table, packed, pval, sched);
     } else {
         hipLaunchKernelGGL((conv_fwd_kernel<NT, DC, VEC>), grid, block, smem, st, p, ids, mask, gate, table, packed, pval,

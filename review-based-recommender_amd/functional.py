@@ -229,6 +229,14 @@ class _PairHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib):
+        # i_feat None: u_feat is the [2B,H] output of the shared encoder, user rows first -- one tensor in, one gradient
+        # tensor out (slicing it outside costs autograd two zero fills, two copies and an add per step)
+        ctx.stacked = i_feat is None
+        if ctx.stacked:
+            pair = u_feat.contiguous()
+            if pair.shape[0] % 2:
+                raise RuntimeError(f"stacked pair features need an even row count, got {tuple(pair.shape)}")
+            u_feat, i_feat = pair[:pair.shape[0] // 2], pair[pair.shape[0] // 2:]
         B, H = u_feat.shape
         K = Wu.shape[1]
         dev = u_feat.device
@@ -269,8 +277,8 @@ class _PairHead(torch.autograd.Function):
         zeroed = iter(v.view_as(t) for v, t in zip(flat.split([t.numel() for t in acc]), acc))
         grads = [next(zeroed) if n in ("Eu", "Ei", "ub", "ib") else torch.empty_like(t) for t, n in zip(params, names)]
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
-        d_uf = torch.empty_like(u_feat)
-        d_if = torch.empty_like(i_feat)
+        d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
+        d_uf, d_if = d_pair[:B], d_pair[B:]
         ws = torch.empty(L_.rbr_pair_head_bwd_ws_floats(B, K), dtype=F32, device=dev)
         d_pred = d_pred.contiguous()
         check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
@@ -279,12 +287,46 @@ class _PairHead(torch.autograd.Function):
                                    dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
                                    dev_ptr(d_uf, F32, "d_ufeat"), dev_ptr(d_if, F32, "d_ifeat"), dev_ptr(ws, F32, "ws"),
                                    current_stream()), "rbr_pair_head_bwd")
+        if ctx.stacked:
+            return (d_pair, None, None, None, None, None, None, *grads)
         return (d_uf, d_if, None, None, None, None, None, *grads)
 
 
 def pair_head(u_feat, i_feat, u_id, i_id, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib, *, drop=None, pad_u=0, pad_i=0):
-    """LastFeat x2 + FM.  u_feat/i_feat [B,H]; ids [B] int64; returns pred [B]."""
+    """LastFeat x2 + FM.  u_feat/i_feat [B,H] (or u_feat [2B,H] = user rows then item rows, i_feat None);
+    ids [B] int64; returns pred [B]."""
     return _PairHead.apply(u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)
+
+
+def stack_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], 0) of two input tensors; no copy when b already follows a in the same allocation (the
+    static batch buffers of train_step.GraphedTrainStep, or a loader that delivers both towers in one block)."""
+    if (a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and a.is_contiguous() and b.is_contiguous()
+            and not a.requires_grad and not b.requires_grad and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        return a.as_strided((a.shape[0] + b.shape[0], *a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], dim=0)
+
+
+def clone_adjacent(tensors):
+    """Clones of `tensors`; neighbours (2k, 2k+1) of equal shape and dtype share one allocation, first then second,
+    so stack_rows() on the clones is a view."""
+    out = list(tensors)
+    k = 0
+    while k < len(out):
+        a = out[k]
+        b = out[k + 1] if k + 1 < len(out) else None
+        if b is not None and a.shape == b.shape and a.dtype == b.dtype and a.device == b.device and a.dim() >= 1:
+            both = torch.empty((2 * a.shape[0], *a.shape[1:]), dtype=a.dtype, device=a.device)
+            both[:a.shape[0]].copy_(a)
+            both[a.shape[0]:].copy_(b)
+            out[k], out[k + 1] = both[:a.shape[0]], both[a.shape[0]:]
+            k += 2
+        else:
+            out[k] = a.clone()
+            k += 1
+    return tuple(out)
 
 
 def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torch.Tensor]:
@@ -293,8 +335,46 @@ def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torc
         return None
     if p >= 1.0:
         return torch.zeros(shape, dtype=F32, device=device)
-    return torch.empty(shape, dtype=F32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
+    # native_dropout(ones) = mask / (1-p): one launch instead of bernoulli_ + div_
+    key = (tuple(shape), str(device))
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones(shape, dtype=F32, device=device)
+    return torch.native_dropout(ones, p, True)[0]
 
+
+_ONES: dict = {}
+
+
+
+class _MseLoss(torch.autograd.Function):
+    """mean((pred - target)^2) -- the trainers' nn.MSELoss (train_deepconn_pp.py:137,164) as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = pred.contiguous(), target.contiguous()
+        if pred.shape != target.shape:
+            raise RuntimeError(f"mse_loss: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+        loss = torch.empty((), dtype=F32, device=pred.device)
+        check(_lib.lib().rbr_mse_loss_fwd(pred.numel(), dev_ptr(pred, F32, "pred"), dev_ptr(target, F32, "target"),
+                                          dev_ptr(loss, F32, "loss"), current_stream()), "rbr_mse_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        pred, target = ctx.saved_tensors
+        d_pred = torch.empty_like(pred)
+        d_loss = d_loss.contiguous()
+        check(_lib.lib().rbr_mse_loss_bwd(pred.numel(), dev_ptr(pred, F32, "pred"), dev_ptr(target, F32, "target"),
+                                          dev_ptr(d_loss, F32, "d_loss"), dev_ptr(d_pred, F32, "d_pred"), current_stream()),
+              "rbr_mse_loss_bwd")
+        return d_pred, None
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """F.mse_loss(pred, target) (mean reduction) for f32 device tensors of equal shape."""
+    return _MseLoss.apply(pred, target)
 
 
 # --------------------------------------------------------------------------- NARRE attention pool

@@ -3,6 +3,7 @@
 import torch
 import torch.nn as nn
 
+from ... import functional as RF
 from .layers import FM, LastFeat, NgramFeat, WordEmbedding, rating_head
 
 
@@ -41,10 +42,10 @@ class DeepCoNNpp(nn.Module):
             u_rev_feats = feats[:nu].index_select(0, u_inv)
             i_rev_feats = feats[nu:].index_select(0, i_inv)
         else:
-            ids = torch.cat([u_revs, i_revs], dim=0)
-            masks = torch.cat([u_rev_masks, i_rev_masks], dim=0)
+            ids = RF.stack_rows(u_revs, i_revs)
+            masks = RF.stack_rows(u_rev_masks, i_rev_masks)
             feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
-            u_rev_feats, i_rev_feats = feats[:bz], feats[bz:]
+            u_rev_feats, i_rev_feats = feats, None          # [2*bz, H], user rows first: the head takes it whole
         preds = rating_head(self.user_feat, self.item_feat, self.fm, u_rev_feats, i_rev_feats, u_ids, i_ids)
         return preds.view(bz)
 

@@ -65,8 +65,8 @@ class NARRE(nn.Module):
         fused gather+conv+pool kernel as 2*bz*doc_num documents of doc_len tokens."""
         bz = u_text.shape[0]
         R, T = self.doc_num, self.doc_len
-        ids = torch.cat([u_text.reshape(-1, T), i_text.reshape(-1, T)], dim=0)
-        masks = torch.cat([u_text_masks.reshape(-1, T), i_text_masks.reshape(-1, T)], dim=0)
+        ids = RF.stack_rows(u_text.reshape(-1, T), i_text.reshape(-1, T))
+        masks = RF.stack_rows(u_text_masks.reshape(-1, T), i_text_masks.reshape(-1, T))
         feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
         u_feat = feats[:bz * R].view(bz, R, self.hiddem_dim)
         i_feat = feats[bz * R:].view(bz, R, self.hiddem_dim)

@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import functional as RF
+
 LR = 2e-3            # default_deepconn_pp.json:24
 MAX_GRAD_NORM = 5.0  # default_deepconn_pp.json:27
 
@@ -136,12 +138,27 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     optimizer.zero_grad()
     out = model(*batch)
     pred = out[0] if isinstance(out, tuple) else out
-    loss = F.mse_loss(pred, ratings)
-    loss.backward()
+    if pred.is_cuda and pred.dtype == torch.float32 and ratings.dtype == torch.float32 and pred.shape == ratings.shape:
+        # one launch each way, and the root gradient is a cached device scalar (no fill per step)
+        loss = RF.mse_loss(pred, ratings)
+        loss.backward(_unit(pred.device))
+    else:
+        loss = F.mse_loss(pred, ratings)
+        loss.backward()
     if grad_sync is not None:
         grad_sync(model)
     gnorm = clip_and_step(model, optimizer, max_grad_norm)
     return loss.detach(), gnorm, pred.detach()
+
+
+_UNIT: dict = {}
+
+
+def _unit(device) -> torch.Tensor:
+    t = _UNIT.get(device)
+    if t is None:
+        t = _UNIT[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 def clip_and_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_grad_norm: float) -> torch.Tensor:
@@ -171,7 +188,7 @@ class GraphedTrainStep:
         if not ratings.is_cuda:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         self.model, self.optimizer, self.grad_sync, self.max_grad_norm = model, optimizer, grad_sync, max_grad_norm
-        self.batch = tuple(t.clone() for t in batch)
+        self.batch = RF.clone_adjacent(batch)       # both towers' inputs in one block: the models stack them as a view
         self.ratings = ratings.clone()
         # the warm-up steps below must not count as training: parameters and Adam state are put back in place
         # (same storage -- the recorded graph keeps their addresses) once the graph exists

@@ -154,3 +154,65 @@ def test_linear_and_head_random(case):
     (out * d3.to(DEV)).sum().backward()
     assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
     _cmp_grads(gl, cl)
+
+
+@pytest.mark.parametrize("n", [1, 7, 256, 1000, 70001])
+def test_mse_loss_matches_torch(n):
+    """rbr_mse_loss_fwd/_bwd vs nn.MSELoss (train_deepconn_pp.py:137,164): loss, d_pred, and a non-unit upstream gradient."""
+    from review_based_recommender_amd import functional as RF
+    g = torch.Generator().manual_seed(n)
+    pred, target = torch.randn(n, generator=g) * 2 + 3, torch.rand(n, generator=g) * 4 + 1
+    pc = _leaf(pred)
+    ref = F.mse_loss(pc, target)
+    (ref * 0.37).backward()
+    pg = _leaf(pred.to(DEV))
+    out = RF.mse_loss(pg, target.to(DEV))
+    (out * 0.37).backward()
+    assert out.shape == ref.shape
+    assert abs(float(out) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert max_err(pg.grad.cpu().numpy(), pc.grad.numpy()) <= 1e-6 * float(pc.grad.abs().max()) + 1e-12
+    with pytest.raises(RuntimeError):
+        RF.mse_loss(pg, target.to(DEV)[: max(n - 1, 0)])
+
+
+def test_stack_rows_is_a_view_for_adjacent_inputs():
+    """stack_rows == torch.cat; no copy for the two halves of one block (clone_adjacent), a copy otherwise."""
+    from review_based_recommender_amd import functional as RF
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randint(0, 99, (5, 7), generator=g).to(DEV), torch.randint(0, 99, (5, 7), generator=g).to(DEV)
+    m = torch.rand(5, generator=g).to(DEV)
+    assert torch.equal(RF.stack_rows(a, b), torch.cat([a, b]))
+    ca, cb, cm = RF.clone_adjacent((a, b, m))
+    assert torch.equal(ca, a) and torch.equal(cb, b) and torch.equal(cm, m)
+    st = RF.stack_rows(ca, cb)
+    assert st.data_ptr() == ca.data_ptr() and torch.equal(st, torch.cat([a, b]))
+    assert RF.stack_rows(cb, ca).data_ptr() not in (ca.data_ptr(), cb.data_ptr())          # wrong order: a real cat
+    ra = ca.view(5, 7)[:, :]            # reshaped views of the halves keep the adjacency (NARRE's [bz*R, T] view)
+    assert RF.stack_rows(ra.reshape(-1, 7), cb.reshape(-1, 7)).data_ptr() == ca.data_ptr()
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_pair_head_stacked_equals_separate(case):
+    """pair_head on the encoder's [2B,H] output == pair_head on its two halves: prediction and every gradient, bit for bit
+    on the dense ones (same kernels, same order)."""
+    from review_based_recommender_amd import functional as RF
+    rng = np.random.default_rng(900 + case)
+    B, H, K, NU, NI = int(rng.choice([1, 5, 64])), int(rng.choice([6, 150])), int(rng.choice([4, 32])), 23, 31
+    g = torch.Generator().manual_seed(case)
+    feat = torch.randn(2 * B, H, generator=g).to(DEV)
+    uid, iid = torch.randint(0, NU, (B,), generator=g).to(DEV), torch.randint(0, NI, (B,), generator=g).to(DEV)
+    shapes = [(H, K), (K,), (NU, K), (H, K), (K,), (NI, K), (K, 1), (1,), (NU, 1), (NI, 1)]
+    params = [(torch.randn(*s, generator=g) * 0.3).to(DEV) for s in shapes]
+    drop = (torch.rand(B, K, generator=g) > 0.3).float().div(0.7).to(DEV)
+    d = torch.randn(B, generator=g).to(DEV)
+    res = []
+    for stacked in (True, False):
+        f = _leaf(feat)
+        ps = [_leaf(t) for t in params]
+        pred = RF.pair_head(f, None, uid, iid, *ps, drop=drop) if stacked else RF.pair_head(f[:B], f[B:], uid, iid, *ps, drop=drop)
+        (pred * d).sum().backward()
+        res.append((pred.detach(), f.grad, [t.grad for t in ps]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert max_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6 * (float(b.abs().max()) + 1e-6)      # embedding rows: atomics

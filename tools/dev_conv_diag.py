@@ -51,6 +51,11 @@ host = np.zeros(8 * 1024, dtype=np.uint64)
 assert lib.rbr_diag_fetch(host.ctypes.data, host.size) == 0
 diag = host.reshape(1024, 8).astype(np.float64)
 diag = diag[diag.sum(1) > 0]
+if product and diag[:, 5].max() > 1e6:       # prod_gemm_kernel: slots 5 / 3 hold the absolute start / end stamps
+    t0, t1 = diag[:, 5], diag[:, 3]
+    print(f"launch span {t1.max() - t0.min():.0f} ticks; start skew {t0.max() - t0.min():.0f}; end skew {t1.max() - t1.min():.0f}; "
+          f"median WG lifetime {np.median(t1 - t0):.0f}")
+    diag[:, 5] = 0; diag[:, 3] = 0
 names = ["item pull", "item prologue", "row gather+barrier", "prefetch issue", "LDS reads + MFMA", "(unused)", "vmcnt + barrier", "epilogue"]
 tot = diag.sum(1).mean()
 print(f"workgroups {len(diag)}, mean cycles per WG {tot:.0f} (s_memtime ticks at 100 MHz)")
