@@ -15,17 +15,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// one wave per pair: lanes 0-31 run the user tower, lanes 32-63 the item tower (k = lane & 31, looped for K > 32);
-// the H-long dots are unrolled 4x so four independent L2 loads per tower are in flight
+// one workgroup per pair: threads [0,128) run the user tower, [128,256) the item tower; inside a tower 4 thread groups
+// split the H-long dots by h mod 4 and 32 lanes cover k (looped for K > 32).  A thread's loads are issued 8 at a time.
 __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
                                                        const float* __restrict__ itf, const long long* __restrict__ uid,
                                                        const long long* __restrict__ iid, const rbr_head_params p,
                                                        const float* __restrict__ drop, float* __restrict__ ul,
                                                        float* __restrict__ il, float* __restrict__ pred) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (b >= B) return;
-    const int side = lane >> 5, kk = lane & 31;
+    __shared__ float s_part[2][4][32];
+    __shared__ float s_l[2][32];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int side = t >> 7, hp = (t >> 5) & 3, kk = t & 31;
     const long id = side ? iid[b] : uid[b];
     const float* ft = (side ? itf : uf) + (long)b * H;
     const float* W = side ? p.Wi : p.Wu;
@@ -37,30 +37,39 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
         const int k = k0 + kk;
         float s = 0.f;
         if (k < K) {
-            float s0 = bias[k] + E[id * K + k], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int hh = 0;
-            for (; hh + 4 <= H; hh += 4) {
-                s0 = fmaf(ft[hh], W[(long)hh * K + k], s0);
-                s1 = fmaf(ft[hh + 1], W[(long)(hh + 1) * K + k], s1);
-                s2 = fmaf(ft[hh + 2], W[(long)(hh + 2) * K + k], s2);
-                s3 = fmaf(ft[hh + 3], W[(long)(hh + 3) * K + k], s3);
+            if (hp == 0) s = bias[k] + E[id * K + k];
+            int hh = hp;
+            for (; hh + 28 < H; hh += 32) {
+                float f[8], wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { f[u] = ft[hh + 4 * u]; wv[u] = W[(long)(hh + 4 * u) * K + k]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fmaf(f[u], wv[u], s);
             }
-            for (; hh < H; ++hh) s0 = fmaf(ft[hh], W[(long)hh * K + k], s0);
-            s = (s0 + s1) + (s2 + s3);
-            outl[k] = s;
+            for (; hh < H; hh += 4) s = fmaf(ft[hh], W[(long)hh * K + k], s);
         }
-        const float other = __shfl_xor(s, 32);      // user lanes get the item value and vice versa
-        if (side == 0 && k < K) {
-            float z = fmaxf(s * other, 0.f);
+        s_part[side][hp][kk] = s;
+        __syncthreads();
+        if (hp == 0) {
+            const float tot = (s_part[side][0][kk] + s_part[side][1][kk]) + (s_part[side][2][kk] + s_part[side][3][kk]);
+            if (k < K) outl[k] = tot;
+            s_l[side][kk] = tot;
+        }
+        __syncthreads();
+        if (t < 32 && k < K) {
+            float z = fmaxf(s_l[0][kk] * s_l[1][kk], 0.f);
             if (drop != nullptr) z *= drop[(long)b * K + k];
             part = fmaf(z, p.h[k], part);
         }
     }
-    part = wave_sum(part);
-    if (lane == 0) pred[b] = part + p.ub[uid[b]] + p.ib[iid[b]] + p.g[0];
+    if (t < 64) {
+        part = wave_sum(part);
+        if (t == 0) pred[b] = part + p.ub[uid[b]] + p.ib[iid[b]] + p.g[0];
+    }
 }
 
-// per-pair part of the backward: d_ul, d_il (to workspace), embedding-row grads, d_feat
+// per-pair part of the backward, one workgroup per pair: d_ul, d_il (to workspace), embedding-row grads, then d_feat with
+// all 256 threads over the 2*H outputs (rows of Wu / Wi read as float4 when K allows)
 __global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K, const long long* __restrict__ uid,
                                                             const long long* __restrict__ iid, const rbr_head_params p,
                                                             const float* __restrict__ drop, const float* __restrict__ ul,
@@ -69,15 +78,14 @@ __global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K,
                                                             float* __restrict__ d_uf, float* __restrict__ d_if,
                                                             float* __restrict__ ws_dul, float* __restrict__ ws_dil,
                                                             float* __restrict__ ws_zdp) {
-    extern __shared__ float sm[];   // [4 waves][2][K]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + wave;
-    if (b >= B) return;             // whole wave exits together; no block barrier below
-    float* s_dul = sm + wave * 2 * K;
-    float* s_dil = s_dul + K;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][K4]  (K4 = K rounded up to 4)
+    const int K4 = (K + 3) & ~3;
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* s_dul = sm;
+    float* s_dil = sm + K4;
     const long u = uid[b], it = iid[b];
     const float dp = d_pred[b];
-    for (int k = lane; k < K; k += 64) {
+    for (int k = t; k < K; k += 256) {
         const float su = ul[(long)b * K + k], si = il[(long)b * K + k];
         const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
         const float prod = su * si;
@@ -91,19 +99,27 @@ __global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K,
         if (u != pad_u) atomicAdd(g.dEu + u * K + k, dul);
         if (it != pad_i) atomicAdd(g.dEi + it * K + k, dil);
     }
-    if (lane == 0) {
+    if (t == 0) {
         if (u != pad_u) atomicAdd(g.dub + u, dp);
         if (it != pad_i) atomicAdd(g.dib + it, dp);
     }
-    __builtin_amdgcn_wave_barrier();   // LDS ops of one wave retire in order; keep the compiler from reordering
-    for (int hh = lane; hh < H; hh += 64) {
-        float a = 0.f, c = 0.f;
-        for (int k = 0; k < K; ++k) {
-            a = fmaf(s_dul[k], p.Wu[(long)hh * K + k], a);
-            c = fmaf(s_dil[k], p.Wi[(long)hh * K + k], c);
+    __syncthreads();
+    const bool vec = (K & 3) == 0 && ((((uintptr_t)p.Wu) | ((uintptr_t)p.Wi)) & 15) == 0;
+    for (int e = t; e < 2 * H; e += 256) {
+        const int side = e >= H, hh = side ? e - H : e;
+        const float* wrow = (side ? p.Wi : p.Wu) + (long)hh * K;
+        const float* sd = side ? s_dil : s_dul;
+        float a = 0.f;
+        if (vec) {
+            for (int k = 0; k < K; k += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+                const float4 dv = *reinterpret_cast<const float4*>(sd + k);
+                a = fmaf(dv.x, wv.x, a); a = fmaf(dv.y, wv.y, a); a = fmaf(dv.z, wv.z, a); a = fmaf(dv.w, wv.w, a);
+            }
+        } else {
+            for (int k = 0; k < K; ++k) a = fmaf(sd[k], wrow[k], a);
         }
-        d_uf[(long)b * H + hh] = a;
-        d_if[(long)b * H + hh] = c;
+        (side ? d_if : d_uf)[(long)b * H + hh] = a;
     }
 }
 
@@ -126,6 +142,7 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(int B, int H, int 
         float s = 0.f, hs = 0.f, gs = 0.f;
         if (k < K) {
             if (r < H) {
+#pragma unroll 8
                 for (int b = grp; b < B; b += 8) s = fmaf(ft[(long)b * H + r], dl[(long)b * K + k], s);
             } else {
                 for (int b = grp; b < B; b += 8) {
@@ -212,7 +229,7 @@ extern "C" int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u
                                  float* ul, float* il, float* pred, void* stream) {
     if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
     if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !pred) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, H, K, u_feat, i_feat,
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H, K, u_feat, i_feat,
                        reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
                        il, pred);
     RBR_CHECK_LAUNCH("pair_head_fwd launch");
@@ -234,7 +251,7 @@ extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u
     float* ws_dul = ws;
     float* ws_dil = ws + (size_t)B * K;
     float* ws_zdp = ws + (size_t)2 * B * K;
-    hipLaunchKernelGGL(head_bwd_pair_kernel, dim3((B + 3) / 4), dim3(256), (size_t)8 * K * sizeof(float), st, B, H, K,
+    hipLaunchKernelGGL(head_bwd_pair_kernel, dim3(B), dim3(256), (size_t)2 * ((K + 3) & ~3) * sizeof(float), st, B, H, K,
                        reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
                        il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, ws_dul, ws_dil, ws_zdp);
     RBR_CHECK_LAUNCH("pair_head_bwd pair launch");

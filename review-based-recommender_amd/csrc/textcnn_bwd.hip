@@ -341,25 +341,43 @@ __global__ __launch_bounds__(256) void dw_doc_kernel(const BwdArgs A, const long
     }
 }
 
+// One workgroup per (channel, 128 embedding columns): sums the NCH partial slabs in fixed order (reads coalesced along d,
+// the NCH loads of an element independent of each other), transposes through LDS and writes the [d][tap] block of the
+// torch layout as one contiguous run.
+constexpr int kRedCols = 128;
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const float* __restrict__ ws_w,
                                                         const float* __restrict__ ws_b, const MutPtrArray dW,
                                                         const MutPtrArray dbias) {
-    const long total = (long)A.C * A.KF * A.D;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int d = (int)(idx % A.D);
-        const int j = (int)((idx / A.D) % A.KF);
-        const int c = (int)(idx / ((long)A.D * A.KF));
-        const int w = bank_of(A, c);
-        const int kz = A.kz[w];
-        if (j >= kz) continue;
-        float s = 0.f;
-        for (int k = 0; k < A.NCH; ++k) s += ws_w[(((long)k * A.C + c) * A.KF + j) * A.D + d];
-        dW.p[w][((long)(c - A.ch_off[w]) * A.D + d) * kz + j] = s;
-        if (j == 0 && d == 0) {
-            float b = 0.f;
-            for (int k = 0; k < A.NCH; ++k) b += ws_b[(long)k * A.C + c];
-            dbias.p[w][c - A.ch_off[w]] = b;
+    __shared__ float s_out[kMaxKF * kRedCols];
+    const int c = blockIdx.x, d0 = blockIdx.y * kRedCols;
+    const int nd = min(kRedCols, A.D - d0);
+    const int w = bank_of(A, c);
+    const int kz = A.kz[w];
+    const long slab = (long)A.C * A.KF * A.D;
+    const float* src = ws_w + ((long)c * A.KF) * A.D + d0;
+    for (int e = threadIdx.x; e < kz * kRedCols; e += 256) {
+        const int j = e / kRedCols, dd = e % kRedCols;
+        if (dd >= nd) continue;
+        const float* q = src + (long)j * A.D + dd;
+        float sum = 0.f;
+        int k = 0;
+        for (; k + 8 <= A.NCH; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q[(long)(k + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
         }
+        for (; k < A.NCH; ++k) sum += q[(long)k * slab];
+        s_out[j * kRedCols + dd] = sum;
+    }
+    __syncthreads();
+    float* dst = dW.p[w] + ((long)(c - A.ch_off[w]) * A.D + d0) * kz;
+    for (int o = threadIdx.x; o < nd * kz; o += 256) dst[o] = s_out[(o % kz) * kRedCols + o / kz];
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        float b = 0.f;
+        for (int k = 0; k < A.NCH; ++k) b += ws_b[(long)k * A.C + c];
+        dbias.p[w][c - A.ch_off[w]] = b;
     }
 }
 
@@ -679,8 +697,7 @@ extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids,
     }
     MutPtrArray dWp{}, dbp{};
     for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
-    const long total = (long)A.C * A.KF * A.D;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, A,
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)A.C, (unsigned)((A.D + kRedCols - 1) / kRedCols)), dim3(256), 0, st, A,
                        ws_w, ws_b, dWp, dbp);
     RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
     return 0;

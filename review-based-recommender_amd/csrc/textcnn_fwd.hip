@@ -653,17 +653,32 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, co
         if (chan < 0) continue;
         const long base = (long)doc * P.wpd * P.nslots_total + (long)P.tile_base * kTile + ls;
         float best = -__builtin_huge_valf();
-        int bidx = 0;
+        int bw_tile = -1;        // tile holding the maximum; -2 - w for an all-masked tile w (index = its first position)
         const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
-        for (int w = 0; w < P.wpd; ++w) {
-            if (flags[doc * P.wpd + w]) {
-                const float v = pval[base + (long)w * P.nslots_total];
-                if (v > best) { best = v; bidx = pidx[base + (long)w * P.nslots_total]; }
-            } else if (w * kTile < Lv && 0.f > best) {      // all-masked tile: conv sum is exactly 0 everywhere
-                best = 0.f;
-                bidx = w * kTile;
+        // tiles in position order, first maximum wins.  The loads of a batch of 8 tiles are independent (issued together);
+        // the position index is fetched once, for the winning tile only.
+        for (int w0 = 0; w0 < P.wpd; w0 += 8) {
+            int fl[8];
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) fl[q] = (w0 + q < P.wpd) ? flags[doc * P.wpd + w0 + q] : 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fl[q] ? pval[base + (long)(w0 + q) * P.nslots_total] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int w = w0 + q;
+                if (w >= P.wpd) break;
+                if (fl[q]) {
+                    if (v[q] > best) { best = v[q]; bw_tile = w; }
+                } else if (w * kTile < Lv && 0.f > best) {      // all-masked tile: conv sum is exactly 0 everywhere
+                    best = 0.f;
+                    bw_tile = -2 - w;
+                }
             }
         }
+        int bidx = 0;
+        if (bw_tile >= 0) bidx = pidx[base + (long)bw_tile * P.nslots_total];
+        else if (bw_tile <= -2) bidx = (-2 - bw_tile) * kTile;
         const int bw = P.slot_w[ls];
         const float y = best + bias.p[bw][chan - P.ch_off[bw]];
         const float f = (P.act == RBR_ACT_RELU) ? fmaxf(y, 0.f) : tanhf(y);

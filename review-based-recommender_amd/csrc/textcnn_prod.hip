@@ -80,13 +80,26 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
     if ((int)blockIdx.x < nb_compact) {
         if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
             for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
-        const int v = blockIdx.x * 256 + threadIdx.x;
+        // dense row of token v = number of marked tokens below v: rows come out in token order, the same list for the
+        // same batch on every run (no atomics).  A block first counts the marks below its 256 tokens (<= V ints, L2).
+        __shared__ int s_cnt[4], s_wave[4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int below = blockIdx.x * 256;
+        int c = 0;
+        const int4* u4 = reinterpret_cast<const int4*>(used);
+        for (int q = threadIdx.x; q < below / 4; q += 256) {
+            const int4 m = u4[q];
+            c += m.x + m.y + m.z + m.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        const int v = below + threadIdx.x;
         const int u = (v < V) ? used[v] : 0;
         const unsigned long long b = __ballot(u);
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0 && b) base = atomicAdd(counter, __popcll(b));
-        base = __shfl(base, 0);
+        if (lane == 0) { s_cnt[wave] = c; s_wave[wave] = __popcll(b); }
+        __syncthreads();
+        int base = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        for (int k = 0; k < wave; ++k) base += s_wave[k];
         if (v < V) {
             int row = -1;
             if (u) {
@@ -95,6 +108,8 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
             }
             row_of_token[v] = row;
         }
+        if ((int)blockIdx.x == nb_compact - 1 && threadIdx.x == 0)
+            *counter = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]) + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         return;
     }
     const long nb = gridDim.x - nb_compact, b0 = blockIdx.x - nb_compact;
