@@ -138,8 +138,8 @@ int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, c
                                 float* dtable, float* dgate, void* stream);
 
 /* The same call on a workspace the caller KEEPS between calls: rbr_textcnn_bwd_prod_ws_reset zeroes the G region of
- * `bwd_ws` once after allocation; every _kept call then finds G all-zero and leaves it all-zero (each non-zero is cleared
- * as it is consumed), so the per-call zero-fill of G (65 MB at the DeepCoNN cfg2 shape) disappears.  The workspace must
+ * `bwd_ws` once after allocation; every _kept call then finds G all-zero and leaves it all-zero (the rows it consumed are
+ * cleared by the workgroup that consumed them, behind its product), so the per-call zero-fill of G (65 MB at the DeepCoNN cfg2 shape) disappears.  The workspace must
  * not be used by anything else, one stream at a time; after a failed call reset it again.  G is NOT available to
  * rbr_textcnn_bwd_dw_from_g after a _kept call. */
 int rbr_textcnn_bwd_prod_ws_reset(const rbr_textcnn_desc* d, void* bwd_ws, void* stream);
@@ -201,7 +201,7 @@ int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
 
 /* d_ufeat/d_ifeat [B,H] overwritten; dense grads overwritten; embedding grads accumulated
  * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx).
- * ws: rbr_pair_head_bwd_ws_floats(B, K) floats. */
+ * ws: rbr_pair_head_bwd_ws_floats(B, K) floats (may be 0 / NULL: the current kernel needs no scratch). */
 size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K);
 int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,

@@ -58,6 +58,14 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const OptTable T, long
         const long n = min((long)kOptChunk, T.n[k] - e0);
         const float* g = T.g[k] + e0;
         if ((((uintptr_t)g) & 15) == 0) {
+            if (n == kOptChunk) {            // whole chunk: the four loads of a thread are issued together
+                float4 x[kOptChunk / 1024];
+#pragma unroll
+                for (int u = 0; u < kOptChunk / 1024; ++u) x[u] = reinterpret_cast<const float4*>(g)[threadIdx.x + 256 * u];
+#pragma unroll
+                for (int u = 0; u < kOptChunk / 1024; ++u) acc += x[u].x * x[u].x + x[u].y * x[u].y + x[u].z * x[u].z + x[u].w * x[u].w;
+                continue;
+            }
             const long n4 = n >> 2;
             for (long i = threadIdx.x; i < n4; i += 256) {
                 const float4 x = reinterpret_cast<const float4*>(g)[i];
@@ -101,21 +109,42 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
         float* v = T.v[k] + e0;
         const bool al = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
         const long n4 = al ? (n >> 2) : 0;
-        for (long i = threadIdx.x; i < n4; i += 256) {
-            float4 G = reinterpret_cast<float4*>(g)[i], M = reinterpret_cast<float4*>(m)[i];
-            float4 V = reinterpret_cast<float4*>(v)[i], P = reinterpret_cast<float4*>(p)[i];
-#define RBR_ADAM1(c)                                                   \
+#define RBR_ADAM1(G, M, V, P, c)                                       \
             G.c *= coef;                                               \
             M.c = M.c + w1 * (G.c - M.c);                              \
             V.c = beta2 * V.c + w2 * G.c * G.c;                        \
             P.c -= step_size * M.c / (sqrtf(V.c) / bc2_sqrt + eps);
-            RBR_ADAM1(x) RBR_ADAM1(y) RBR_ADAM1(z) RBR_ADAM1(w)
-#undef RBR_ADAM1
+        if (al && n == kOptChunk) {          // whole chunk: all 16 loads of a thread in flight before the first use
+            constexpr int U = kOptChunk / 1024;
+            float4 G[U], M[U], V[U], P[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                G[u] = reinterpret_cast<float4*>(g)[i]; M[u] = reinterpret_cast<float4*>(m)[i];
+                V[u] = reinterpret_cast<float4*>(v)[i]; P[u] = reinterpret_cast<float4*>(p)[i];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
+                RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
+                if (clipped) reinterpret_cast<float4*>(g)[i] = G[u];
+                reinterpret_cast<float4*>(m)[i] = M[u];
+                reinterpret_cast<float4*>(v)[i] = V[u];
+                reinterpret_cast<float4*>(p)[i] = P[u];
+            }
+            continue;
+        }
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            float4 G = reinterpret_cast<float4*>(g)[i], M = reinterpret_cast<float4*>(m)[i];
+            float4 V = reinterpret_cast<float4*>(v)[i], P = reinterpret_cast<float4*>(p)[i];
+            RBR_ADAM1(G, M, V, P, x) RBR_ADAM1(G, M, V, P, y) RBR_ADAM1(G, M, V, P, z) RBR_ADAM1(G, M, V, P, w)
             if (clipped) reinterpret_cast<float4*>(g)[i] = G;       // coef == 1: .grad already holds the "clipped" gradient
             reinterpret_cast<float4*>(m)[i] = M;
             reinterpret_cast<float4*>(v)[i] = V;
             reinterpret_cast<float4*>(p)[i] = P;
         }
+#undef RBR_ADAM1
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
             const float gg = g[i] * coef;
             const float mm = m[i] + w1 * (gg - m[i]);

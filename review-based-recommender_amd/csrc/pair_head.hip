@@ -7,6 +7,8 @@
 // runs one wave per (user,item) pair with shuffle reductions -- no MFMA.
 #include "rbr_common.h"
 
+#include <algorithm>
+
 namespace rbr {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -68,88 +70,93 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
     }
 }
 
-// per-pair part of the backward, one workgroup per pair: d_ul, d_il (to workspace), embedding-row grads, then d_feat with
-// all 256 threads over the 2*H outputs (rows of Wu / Wi read as float4 when K allows)
-__global__ __launch_bounds__(256) void head_bwd_pair_kernel(int B, int H, int K, const long long* __restrict__ uid,
-                                                            const long long* __restrict__ iid, const rbr_head_params p,
-                                                            const float* __restrict__ drop, const float* __restrict__ ul,
-                                                            const float* __restrict__ il, const float* __restrict__ d_pred,
-                                                            int pad_u, int pad_i, const rbr_head_grads g,
-                                                            float* __restrict__ d_uf, float* __restrict__ d_if,
-                                                            float* __restrict__ ws_dul, float* __restrict__ ws_dil,
-                                                            float* __restrict__ ws_zdp) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][K4]  (K4 = K rounded up to 4)
-    const int K4 = (K + 3) & ~3;
-    const int b = blockIdx.x, t = threadIdx.x;
-    float* s_dul = sm;
-    float* s_dil = sm + K4;
-    const long u = uid[b], it = iid[b];
-    const float dp = d_pred[b];
-    for (int k = t; k < K; k += 256) {
-        const float su = ul[(long)b * K + k], si = il[(long)b * K + k];
-        const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
-        const float prod = su * si;
-        const float dz = (prod > 0.f) ? dp * p.h[k] * dr : 0.f;
-        const float dul = dz * si, dil = dz * su;
-        s_dul[k] = dul;
-        s_dil[k] = dil;
-        ws_dul[(long)b * K + k] = dul;
-        ws_dil[(long)b * K + k] = dil;
-        ws_zdp[(long)b * K + k] = fmaxf(prod, 0.f) * dr * dp;
-        if (u != pad_u) atomicAdd(g.dEu + u * K + k, dul);
-        if (it != pad_i) atomicAdd(g.dEi + it * K + k, dil);
-    }
-    if (t == 0) {
-        if (u != pad_u) atomicAdd(g.dub + u, dp);
-        if (it != pad_i) atomicAdd(g.dib + it, dp);
-    }
-    __syncthreads();
-    const bool vec = (K & 3) == 0 && ((((uintptr_t)p.Wu) | ((uintptr_t)p.Wi)) & 15) == 0;
-    for (int e = t; e < 2 * H; e += 256) {
-        const int side = e >= H, hh = side ? e - H : e;
-        const float* wrow = (side ? p.Wi : p.Wu) + (long)hh * K;
-        const float* sd = side ? s_dil : s_dul;
-        float a = 0.f;
-        if (vec) {
-            for (int k = 0; k < K; k += 4) {
-                const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
-                const float4 dv = *reinterpret_cast<const float4*>(sd + k);
-                a = fmaf(dv.x, wv.x, a); a = fmaf(dv.y, wv.y, a); a = fmaf(dv.z, wv.z, a); a = fmaf(dv.w, wv.w, a);
-            }
-        } else {
-            for (int k = 0; k < K; ++k) a = fmaf(sd[k], wrow[k], a);
-        }
-        (side ? d_if : d_uf)[(long)b * H + hh] = a;
-    }
+// The backward in ONE launch.  Blocks [0, B): one workgroup per pair -- embedding-row grads (atomics), then d_feat with all
+// 256 threads over the 2*H outputs (rows of Wu / Wi read as float4 when K allows).  Blocks [B, B + 2(H+1)): the batch
+// reductions dW = feat^T @ d_l, db, dh, dg, one workgroup per output row (side, r), 8 thread groups striding the batch in a
+// fixed partition and order (bitwise reproducible); they recompute d_l from ul / il / drop / d_pred (a few flops) instead
+// of waiting for the pair blocks to publish it, so both halves run side by side.
+__device__ __forceinline__ void head_dl(float su, float si, float dr, float dp, float hk, float& dul, float& dil, float& zdp) {
+    const float prod = su * si;
+    const float dz = (prod > 0.f) ? dp * hk * dr : 0.f;
+    dul = dz * si;
+    dil = dz * su;
+    zdp = fmaxf(prod, 0.f) * dr * dp;
 }
 
-// batch reductions (bitwise reproducible: fixed partition and order): dW = feat^T @ d_l, db, dh, dg.
-// One workgroup per output row (side, r): 8 thread groups stride the batch, 32 lanes cover k.
-__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(int B, int H, int K, const float* __restrict__ uf,
-                                                              const float* __restrict__ itf,
-                                                              const float* __restrict__ d_pred,
-                                                              const float* __restrict__ ws_dul,
-                                                              const float* __restrict__ ws_dil,
-                                                              const float* __restrict__ ws_zdp, const rbr_head_grads g) {
-    __shared__ float red[3][8][32];
+__global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int K, const float* __restrict__ uf,
+                                                       const float* __restrict__ itf, const long long* __restrict__ uid,
+                                                       const long long* __restrict__ iid, const rbr_head_params p,
+                                                       const float* __restrict__ drop, const float* __restrict__ ul,
+                                                       const float* __restrict__ il, const float* __restrict__ d_pred,
+                                                       int pad_u, int pad_i, const rbr_head_grads g,
+                                                       float* __restrict__ d_uf, float* __restrict__ d_if) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // pair role: [2][K4]; reduce role: [3][8][32]
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x < B) {
+        const int K4 = (K + 3) & ~3;
+        const int b = blockIdx.x;
+        float* s_dul = sm;
+        float* s_dil = sm + K4;
+        const long u = uid[b], it = iid[b];
+        const float dp = d_pred[b];
+        for (int k = t; k < K; k += 256) {
+            const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
+            float dul, dil, zdp;
+            head_dl(ul[(long)b * K + k], il[(long)b * K + k], dr, dp, p.h[k], dul, dil, zdp);
+            s_dul[k] = dul;
+            s_dil[k] = dil;
+            if (u != pad_u) atomicAdd(g.dEu + u * K + k, dul);
+            if (it != pad_i) atomicAdd(g.dEi + it * K + k, dil);
+        }
+        if (t == 0) {
+            if (u != pad_u) atomicAdd(g.dub + u, dp);
+            if (it != pad_i) atomicAdd(g.dib + it, dp);
+        }
+        __syncthreads();
+        const bool vec = (K & 3) == 0 && ((((uintptr_t)p.Wu) | ((uintptr_t)p.Wi)) & 15) == 0;
+        for (int e = t; e < 2 * H; e += 256) {
+            const int side = e >= H, hh = side ? e - H : e;
+            const float* wrow = (side ? p.Wi : p.Wu) + (long)hh * K;
+            const float* sd = side ? s_dil : s_dul;
+            float a = 0.f;
+            if (vec) {
+                for (int k = 0; k < K; k += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(wrow + k);
+                    const float4 dv = *reinterpret_cast<const float4*>(sd + k);
+                    a = fmaf(dv.x, wv.x, a); a = fmaf(dv.y, wv.y, a); a = fmaf(dv.z, wv.z, a); a = fmaf(dv.w, wv.w, a);
+                }
+            } else {
+                for (int k = 0; k < K; ++k) a = fmaf(sd[k], wrow[k], a);
+            }
+            (side ? d_if : d_uf)[(long)b * H + hh] = a;
+        }
+        return;
+    }
+    float (*red)[8][32] = reinterpret_cast<float (*)[8][32]>(sm);
     const int rows = H + 1;                 // row H holds the bias / h / g reductions
-    const int side = blockIdx.x / rows, r = blockIdx.x % rows;
-    const int kk = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const float* dl = side ? ws_dil : ws_dul;
+    const int rb = blockIdx.x - B;
+    const int side = rb / rows, r = rb % rows;
+    const int kk = t & 31, grp = t >> 5;
     const float* ft = side ? itf : uf;
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int k = k0 + kk;
         float s = 0.f, hs = 0.f, gs = 0.f;
         if (k < K) {
-            if (r < H) {
-#pragma unroll 8
-                for (int b = grp; b < B; b += 8) s = fmaf(ft[(long)b * H + r], dl[(long)b * K + k], s);
-            } else {
-                for (int b = grp; b < B; b += 8) {
-                    s += dl[(long)b * K + k];
+            const float hk = p.h[k];
+#pragma unroll 4
+            for (int b = grp; b < B; b += 8) {
+                const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
+                const float dp = d_pred[b];
+                float dul, dil, zdp;
+                head_dl(ul[(long)b * K + k], il[(long)b * K + k], dr, dp, hk, dul, dil, zdp);
+                const float dl = side ? dil : dul;
+                if (r < H) {
+                    s = fmaf(ft[(long)b * H + r], dl, s);
+                } else {
+                    s += dl;
                     if (side == 0) {
-                        hs += ws_zdp[(long)b * K + k];
-                        if (k == 0) gs += d_pred[b];
+                        hs += zdp;
+                        if (k == 0) gs += dp;
                     }
                 }
             }
@@ -236,27 +243,22 @@ extern "C" int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u
     return 0;
 }
 
-extern "C" size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K) { return (size_t)3 * B * K; }
+extern "C" size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K) { (void)B; (void)K; return 0; }
 
 extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
                                  const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                                  const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
                                  const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
     if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
-    if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !d_pred || !g || !d_ufeat || !d_ifeat || !ws) {
+    if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !d_pred || !g || !d_ufeat || !d_ifeat) {
         set_error("null pointer");
         return RBR_ERR_BAD_ARG;
     }
-    hipStream_t st = (hipStream_t)stream;
-    float* ws_dul = ws;
-    float* ws_dil = ws + (size_t)B * K;
-    float* ws_zdp = ws + (size_t)2 * B * K;
-    hipLaunchKernelGGL(head_bwd_pair_kernel, dim3(B), dim3(256), (size_t)2 * ((K + 3) & ~3) * sizeof(float), st, B, H, K,
-                       reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
-                       il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, ws_dul, ws_dil, ws_zdp);
-    RBR_CHECK_LAUNCH("pair_head_bwd pair launch");
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((unsigned)(2 * (H + 1))), dim3(256), 0, st, B, H, K, u_feat,
-                       i_feat, d_pred, ws_dul, ws_dil, ws_zdp, *g);
-    RBR_CHECK_LAUNCH("pair_head_bwd reduce launch");
+    (void)ws;      // no longer needed: the reduction blocks recompute d_l instead of reading it back
+    const size_t lds = std::max((size_t)2 * ((K + 3) & ~3), (size_t)3 * 8 * 32) * sizeof(float);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(B + 2 * (H + 1))), dim3(256), lds, (hipStream_t)stream, B, H, K, u_feat,
+                       i_feat, reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop,
+                       ul, il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat);
+    RBR_CHECK_LAUNCH("pair_head_bwd launch");
     return 0;
 }

@@ -294,7 +294,7 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
-// REZERO: every non-zero of G is overwritten with 0 as it is consumed, so a G that was all-zero before build_g is all-zero
+// REZERO: every consumed row of G is overwritten with zeros, so a G that was all-zero before build_g is all-zero
 // again afterwards (rbr_textcnn_bwd_dtable_prod_kept: no 65 MB zero-fill per step at the cfg2 shape).
 template <bool REZERO>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
@@ -314,9 +314,6 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
         if (tok_of_row[row] == A.padding_idx) {             // nn.Embedding(padding_idx): that row gets no gradient
             float* dst = dtable + (long)A.padding_idx * D;
             for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (REZERO)
-                for (int k4 = threadIdx.x; k4 < A.KG / 4; k4 += 256)
-                    *reinterpret_cast<f32x4*>(G + (long)row * A.KG + 4 * k4) = f32x4{0.f, 0.f, 0.f, 0.f};
             continue;                                        // workgroup-uniform
         }
         // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
@@ -324,11 +321,7 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
         for (int k0 = kbeg; k0 < kend; k0 += 256) {
             const int k = k0 + 4 * lane;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < kend) {
-                v = *reinterpret_cast<const f32x4*>(G + (long)row * A.KG + k);
-                if (REZERO && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f))
-                    *reinterpret_cast<f32x4*>(G + (long)row * A.KG + k) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            if (k < kend) v = *reinterpret_cast<const f32x4*>(G + (long)row * A.KG + k);
 #pragma unroll
             for (int cpt = 0; cpt < 4; ++cpt) {
                 const bool nz = v[cpt] != 0.f;
@@ -384,6 +377,13 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
         }
         __syncthreads();      // lists and partial rows are rewritten for the next row
+    }
+    // kept workspace: the G rows this workgroup consumed go back to zero, as whole-row stores behind its last product (a
+    // store right after the load would sit in front of every later load of the wave in the in-order memory counter)
+    if (REZERO) {
+        for (int row = blockIdx.x; row < n; row += gridDim.x)
+            for (int k4 = threadIdx.x; k4 < A.KG / 4; k4 += 256)
+                *reinterpret_cast<f32x4*>(G + (long)row * A.KG + 4 * k4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // rows of tokens the batch does not contain: zero (the caller need not pre-fill dtable); one wave per row
     if (row_of_token != nullptr) {

@@ -315,7 +315,8 @@ class _PairHead(torch.autograd.Function):
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
         d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
         d_uf, d_if = d_pair[:B], d_pair[B:]
-        ws = torch.empty(L_.rbr_pair_head_bwd_ws_floats(B, K), dtype=F32, device=dev)
+        wsn = L_.rbr_pair_head_bwd_ws_floats(B, K)
+        ws = torch.empty(wsn, dtype=F32, device=dev) if wsn else None
         d_pred = d_pred.contiguous()
         check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
                                    dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
