@@ -136,16 +136,6 @@ size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                 const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                 float* dtable, float* dgate, void* stream);
-
-/* The same call on a workspace the caller KEEPS between calls: rbr_textcnn_bwd_prod_ws_reset zeroes the G region of
- * `bwd_ws` once after allocation; every _kept call then finds G all-zero and leaves it all-zero (the rows it consumed are
- * cleared by the workgroup that consumed them, behind its product), so the per-call zero-fill of G (65 MB at the DeepCoNN cfg2 shape) disappears.  The workspace must
- * not be used by anything else, one stream at a time; after a failed call reset it again.  G is NOT available to
- * rbr_textcnn_bwd_dw_from_g after a _kept call. */
-int rbr_textcnn_bwd_prod_ws_reset(const rbr_textcnn_desc* d, void* bwd_ws, void* stream);
-int rbr_textcnn_bwd_dtable_prod_kept(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                                float* dtable, float* dgate, void* stream);
 /* Conv weight / bias gradients from the G the call above left in `bwd_ws` (dW = G^T @ table[distinct tokens] on the f32
  * MFMA pipe, split over token ranges, fixed-order reduce).  For many short documents (NARRE's reviews) this replaces
  * rbr_textcnn_bwd_dw; rbr_textcnn_bwd_dw_from_g_ws_floats(d) == 0 means "use rbr_textcnn_bwd_dw".  Needs the SAME fwd_ws /

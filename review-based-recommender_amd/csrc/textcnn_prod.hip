@@ -294,11 +294,8 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
-// REZERO: every consumed row of G is overwritten with zeros, so a G that was all-zero before build_g is all-zero
-// again afterwards (rbr_textcnn_bwd_dtable_prod_kept: no 65 MB zero-fill per step at the cfg2 shape).
-template <bool REZERO>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
-                                                        float* __restrict__ G, const float* __restrict__ WT,
+                                                        const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
                                                         const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
@@ -377,13 +374,6 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
         }
         __syncthreads();      // lists and partial rows are rewritten for the next row
-    }
-    // kept workspace: the G rows this workgroup consumed go back to zero, as whole-row stores behind its last product (a
-    // store right after the load would sit in front of every later load of the wave in the in-order memory counter)
-    if (REZERO) {
-        for (int row = blockIdx.x; row < n; row += gridDim.x)
-            for (int k4 = threadIdx.x; k4 < A.KG / 4; k4 += 256)
-                *reinterpret_cast<f32x4*>(G + (long)row * A.KG + 4 * k4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // rows of tokens the batch does not contain: zero (the caller need not pre-fill dtable); one wave per row
     if (row_of_token != nullptr) {
@@ -802,9 +792,9 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
-static int bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                           const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
-                           void* bwd_ws, float* dtable, float* dgate, void* stream, bool kept) {
+extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                           const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
+                                           void* bwd_ws, float* dtable, float* dgate, void* stream) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
     if (dgate != nullptr && gate == nullptr) dgate = nullptr;
@@ -836,7 +826,7 @@ static int bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const 
         A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
         A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
     }
-    if (dtable != nullptr && !kept) {
+    if (dtable != nullptr) {
         hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
         RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
     }
@@ -847,37 +837,10 @@ static int bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const 
     RBR_CHECK_LAUNCH("textcnn build_g launch");
     if (dtable == nullptr) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    if (kept)
-        hipLaunchKernelGGL(g_times_w_kernel<true>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G,
-                           WT, tok_of_row, row_of_token, d->V, dtable);
-    else
-        hipLaunchKernelGGL(g_times_w_kernel<false>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G,
-                           WT, tok_of_row, row_of_token, d->V, dtable);
+    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
+                       tok_of_row, row_of_token, d->V, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
-}
-
-extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                           const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
-                                           void* bwd_ws, float* dtable, float* dgate, void* stream) {
-    return bwd_dtable_prod(d, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, stream, false);
-}
-
-// A workspace the caller keeps between calls: _reset zeroes its G region once; every _kept call finds G all-zero and
-// leaves it all-zero (G is not available to rbr_textcnn_bwd_dw_from_g afterwards).
-extern "C" int rbr_textcnn_bwd_prod_ws_reset(const rbr_textcnn_desc* d, void* bwd_ws, void* stream) {
-    if (!bwd_ws) { set_error("null workspace"); return RBR_ERR_BAD_ARG; }
-    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
-    ProdLayout Lo;
-    ProdBwdLayout B;
-    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
-    return zero_words(bwd_ws, B.total, (hipStream_t)stream);      // G and the alignment slack around it
-}
-
-extern "C" int rbr_textcnn_bwd_dtable_prod_kept(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
-                                                const float* gate, const float* feat, const int32_t* argmax, const float* d_feat,
-                                                void* fwd_ws, void* bwd_ws, float* dtable, float* dgate, void* stream) {
-    return bwd_dtable_prod(d, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, stream, true);
 }
 
 namespace {

@@ -2,8 +2,6 @@
 from __future__ import annotations
 
 import ctypes as C
-import os
-from collections import OrderedDict
 from typing import Optional, Sequence
 
 import torch
@@ -185,19 +183,12 @@ class _TextCNN(torch.autograd.Function):
         if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
             # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
-            key, bws = None, None
-            if need_table and not dwg_floats:       # (dW-from-G reads G after this call: it needs the per-call form)
-                key, bws = _kept_bwd_ws(L_, desc, bws_bytes, dev, st)
-            fn = L_.rbr_textcnn_bwd_dtable_prod_kept if bws is not None else L_.rbr_textcnn_bwd_dtable_prod
-            if bws is None:
-                key = None
-                bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
-            rc = fn(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(gate, F32, "gate"),
-                    dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                    ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st)
-            if rc and key is not None:
-                _KEPT_WS.pop(key, None)             # its G may be half-consumed: never reuse it
-            check(rc, "rbr_textcnn_bwd_dtable_prod")
+            bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+            check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                 dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"),
+                                                 dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
             if dwg_floats:
@@ -219,33 +210,6 @@ class _TextCNN(torch.autograd.Function):
         if ev is not None:
             ev.record()
         return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-
-
-# Table-gradient workspaces kept between steps (rbr_textcnn_bwd_dtable_prod_kept): the G region is zeroed once, and every
-# call leaves it all-zero again, instead of a zero-fill of the rows of all distinct tokens per step (65 MB at cfg2).
-_KEPT_WS: "OrderedDict" = OrderedDict()
-_KEPT_WS_MAX = 4            # distinct (shape, device) entries; the oldest is dropped.  Steps that share an entry must be
-                            # stream-ordered (they also share the parameters, so they are)
-
-
-def _kept_bwd_ws(L_, desc, nbytes: int, dev, st):
-    """(key, workspace) or (None, None) when a new one would have to be created inside a stream capture."""
-    if os.environ.get("RBR_KEEP_BWD_WS", "1") == "0":
-        return None, None
-    key = (dev.index, nbytes, desc.n_docs, desc.L, desc.D, desc.V, desc.n_widths,
-           tuple(desc.kz[:desc.n_widths]), tuple(desc.ch[:desc.n_widths]), desc.pad_mode, desc.act, desc.padding_idx)
-    ws = _KEPT_WS.get(key)
-    if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None, None          # memory from a graph's private pool is recycled by the graph: not keepable
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(L_.rbr_textcnn_bwd_prod_ws_reset(C.byref(desc), ws.data_ptr(), st), "rbr_textcnn_bwd_prod_ws_reset")
-        _KEPT_WS[key] = ws
-        while len(_KEPT_WS) > _KEPT_WS_MAX:
-            _KEPT_WS.popitem(last=False)
-    else:
-        _KEPT_WS.move_to_end(key)
-    return key, ws
 
 
 def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor], weights: Sequence[torch.Tensor],
