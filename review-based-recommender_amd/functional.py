@@ -1,7 +1,9 @@
 """torch.autograd.Functions over the C ABI (include/rbr_hip.h).  HIP tensors only."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -162,13 +164,27 @@ class _TextCNN(torch.autograd.Function):
         # many short documents (NARRE's reviews): dW = G^T @ table[distinct tokens] on the MFMA pipe, from the G the
         # table-gradient call builds anyway (0 floats of workspace = not this shape: the window-row kernels below)
         dwg_floats = L_.rbr_textcnn_bwd_dw_from_g_ws_floats(C.byref(desc)) if (need_table and bws_bytes) else 0
+        join = None
         if not dwg_floats:
-            ev = TIMER.record("textcnn_bwd_dw")
-            check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                        dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
-                                        dev_ptr(wsb, F32, "ws"), st), "rbr_textcnn_bwd_dw")
-            if ev is not None:
-                ev.record()
+            # the weight-gradient kernels and the table-gradient kernels below both start from d_feat and share nothing
+            # else: the former go to a second stream (fork here, join before returning), so the two chains overlap --
+            # also inside a captured graph, where the fork becomes two parallel branches
+            side = _side_stream(dev) if (need_table or need_gate or use_taps) else None
+            if side is not None:
+                fork = torch.cuda.Event()
+                fork.record()
+                side.wait_event(fork)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ev = TIMER.record("textcnn_bwd_dw")
+                check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                            dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
+                                            ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"), current_stream()),
+                      "rbr_textcnn_bwd_dw")
+                if ev is not None:
+                    ev.record()
+                if side is not None:
+                    join = torch.cuda.Event()
+                    join.record()
         ev = TIMER.record("textcnn_bwd_dtable")
         if use_taps:
             tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
@@ -179,6 +195,7 @@ class _TextCNN(torch.autograd.Function):
             sink.record(desc, list(ws))
             if ev is not None:
                 ev.record()
+            _join(join)
             return (None, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
@@ -200,6 +217,7 @@ class _TextCNN(torch.autograd.Function):
                                                    dev_ptr(dwg_ws, F32, "ws"), st), "rbr_textcnn_bwd_dw_from_g")
                 if ev is not None:
                     ev.record()
+            _join(join)
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if packed is None:
             packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
@@ -209,7 +227,26 @@ class _TextCNN(torch.autograd.Function):
               "rbr_textcnn_bwd_dtable")
         if ev is not None:
             ev.record()
+        _join(join)
         return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev):
+    """The second stream of `dev` for the weight-gradient chain (None: RBR_BWD_OVERLAP=0)."""
+    if os.environ.get("RBR_BWD_OVERLAP", "1") == "0":
+        return None
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def _join(event) -> None:
+    if event is not None:
+        torch.cuda.current_stream().wait_event(event)
 
 
 def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor], weights: Sequence[torch.Tensor],
