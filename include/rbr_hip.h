@@ -198,6 +198,12 @@ int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
                       const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream);
 
+/* ---- nn.Dropout multiplier (deepconn/layers.py:202, narre.py:73, dual_att/dual_att.py:33, simple_siamese/layers.py:7-68):
+ *   out[i] = 0 with probability p, else 1/(1-p), i < n.  Philox4x32-10 keyed by `seed`, counter (i/4, call number).
+ *   state: 2 x uint64 in device memory, zero-initialised by the caller once; state[0] is the call number, advanced by
+ *   the kernel itself (graph-replay safe: every replay draws a new mask), state[1] a workgroup ticket.      ---- */
+int rbr_dropout_multiplier(int64_t n, float p, uint64_t seed, uint64_t* state, float* out, void* stream);
+
 /* ---- nn.MSELoss(reduction="mean") of the trainers (trainer/train_deepconn_pp.py:137,164):
  *   loss[0] = sum_i (pred[i]-target[i])^2 / n   (one workgroup, fixed summation order)
  *   d_pred[i] = 2 (pred[i]-target[i]) / n * d_loss[0]       (d_loss is a device scalar)          ---- */

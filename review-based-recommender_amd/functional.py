@@ -119,6 +119,7 @@ class _TextCNN(torch.autograd.Function):
         ctx.save_for_backward(table_c, ids, packed, feat, argmax, *([mask8] if mask8 is not None else []),
                               *([gate] if gate is not None else []), *ws)
         ctx.mark_non_differentiable(argmax)
+        ctx.set_materialize_grads(False)        # no zero-filled "gradient" tensor for argmax (a fill launch per step)
         return feat, argmax
 
     @staticmethod
@@ -132,6 +133,8 @@ class _TextCNN(torch.autograd.Function):
     def backward(ctx, d_feat, _d_argmax):
         saved = list(ctx.saved_tensors)
         table, ids, packed, feat, argmax = saved[:5]
+        if d_feat is None:
+            d_feat = torch.zeros_like(feat)
         k = 5
         mask8 = None
         gate = None
@@ -368,20 +371,29 @@ def clone_adjacent(tensors):
 
 
 def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torch.Tensor]:
-    """The multiplier F.dropout would apply (0 or 1/(1-p)), drawn from torch's HIP generator."""
+    """The multiplier F.dropout would apply (0 or 1/(1-p)): rbr_dropout_multiplier, keyed by the device generator's seed
+    (torch.manual_seed) and a per-device call counter that lives on the device."""
     if not training or p <= 0.0:
         return None
     if p >= 1.0:
         return torch.zeros(shape, dtype=F32, device=device)
-    # native_dropout(ones) = mask / (1-p): one launch instead of bernoulli_ + div_
-    key = (tuple(shape), str(device))
-    ones = _ONES.get(key)
-    if ones is None:
-        ones = _ONES[key] = torch.ones(shape, dtype=F32, device=device)
-    return torch.native_dropout(ones, p, True)[0]
+    # own Philox kernel with the call counter in device memory: one launch, and -- unlike a torch RNG op -- nothing for the
+    # host to patch before every replay of a captured step (the generator's seed / offset fills)
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"dropout_multiplier: device must be a HIP device (got {dev}); there is no CPU path")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    state = _DROP_STATE.get(idx)
+    if state is None:
+        state = _DROP_STATE[idx] = torch.zeros(2, dtype=torch.int64, device=dev)
+    out = torch.empty(shape, dtype=F32, device=dev)
+    seed = torch.cuda.default_generators[idx].initial_seed() & 0xFFFFFFFFFFFFFFFF
+    check(_lib.lib().rbr_dropout_multiplier(out.numel(), float(p), seed, state.data_ptr(), dev_ptr(out, F32, "out"),
+                                            current_stream()), "rbr_dropout_multiplier")
+    return out
 
 
-_ONES: dict = {}
+_DROP_STATE: dict = {}       # per device: [call number, workgroup ticket] (uint64 x 2), advanced on the device
 
 
 

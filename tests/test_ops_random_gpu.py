@@ -216,3 +216,44 @@ def test_pair_head_stacked_equals_separate(case):
     assert torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):
         assert max_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6 * (float(b.abs().max()) + 1e-6)      # embedding rows: atomics
+
+
+def test_dropout_multiplier_statistics_and_replay():
+    """rbr_dropout_multiplier: values in {0, 1/(1-p)}, drop rate ~ p, a new mask per call (device-side call counter), also on
+    every replay of a captured graph; the same seed and call number reproduce the same mask."""
+    from review_based_recommender_amd import functional as RF
+    dev = torch.device(DEV)
+    for p in (0.1, 0.5, 0.8):
+        m = RF.dropout_multiplier((1000, 333), p, True, dev)
+        vals = torch.unique(m)
+        assert set(np.round(vals.cpu().numpy(), 5)) == {0.0, np.round(np.float32(1.0 / (1.0 - p)), 5)}
+        rate = float((m == 0).float().mean())
+        assert abs(rate - p) < 4 * np.sqrt(p * (1 - p) / m.numel()) + 1e-3
+        assert abs(float(m.mean()) - 1.0) < 0.02            # E[multiplier] = 1
+    assert RF.dropout_multiplier((4, 4), 0.5, False, dev) is None and RF.dropout_multiplier((4, 4), 0.0, True, dev) is None
+    assert float(RF.dropout_multiplier((4, 4), 1.0, True, dev).abs().sum()) == 0.0
+    a, b = RF.dropout_multiplier((64, 32), 0.5, True, dev), RF.dropout_multiplier((64, 32), 0.5, True, dev)
+    assert not torch.equal(a, b)
+    # same (seed, call number) -> same mask: rewind the device counter
+    state = RF._DROP_STATE[dev.index]
+    torch.cuda.synchronize()
+    call = int(state[0])
+    c1 = RF.dropout_multiplier((777,), 0.3, True, dev)
+    state[0] = call
+    c2 = RF.dropout_multiplier((777,), 0.3, True, dev)
+    assert torch.equal(c1, c2) and int(state[0]) == call + 1 and int(state[1]) == 0
+    # a captured launch draws a new mask on every replay
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        RF.dropout_multiplier((256, 32), 0.5, True, dev)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = RF.dropout_multiplier((256, 32), 0.5, True, dev)
+    masks = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        masks.append(out.clone())
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
