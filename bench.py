@@ -392,7 +392,7 @@ def main():
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             conv_ms = sum(ksum[k][1] for k in ("textcnn_prod_prepare", "textcnn_prod_table", "textcnn_prod_pool"))
             out["roofline"] = {
-                "bound": "mfma", "kernel": "conv_store_kernel<8,60>: T = table[distinct tokens] @ Wprod "
+                "bound": "mfma", "kernel": "prod_gemm_kernel<60>: T = table[distinct tokens] @ Wprod "
                                            "(v_mfma_f32_32x32x2_f32, rows gathered by LDS-DMA)",
                 "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic("r01_prod_table_pmc.json"),

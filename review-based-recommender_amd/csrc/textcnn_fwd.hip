@@ -545,7 +545,11 @@ void prod_gemm_kernel(const ConvPlan P, const long long* __restrict__ ids, const
                     f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
+#if defined(RBR_DIAG_VARIANT) && RBR_DIAG_VARIANT == 2
+                        if (false) {
+#else
                         if (q + 2 < Q) {
+#endif
                             w0[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(w0p + 8 * (q + 2));
                             w1[(q + 2) % 3] = *reinterpret_cast<const f32x4*>(w1p + 8 * (q + 2));
                         } else if (q + 2 == Q && DC % 8 == 4) {
@@ -563,7 +567,9 @@ void prod_gemm_kernel(const ConvPlan P, const long long* __restrict__ ids, const
                         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].z, x1.z, c1, 0, 0, 0);
                         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, x0.w, c0, 0, 0, 0);
                         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[q].w, x1.w, c1, 0, 0, 0);
+#if !defined(RBR_DIAG_VARIANT) || RBR_DIAG_VARIANT != 1
                         if (!last && q < NLD) issue_round(q, nxt_dst, nxt_src);
+#endif
                     }
                     if (DC % 8 == 4) {
                         f32x16& c0 = acc[2 * pair];
@@ -582,7 +588,9 @@ void prod_gemm_kernel(const ConvPlan P, const long long* __restrict__ ids, const
                 }
                 RBR_STAMP(4);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !defined(RBR_DIAG_VARIANT) || RBR_DIAG_VARIANT != 3
                 __syncthreads();
+#endif
                 RBR_STAMP(6);
                 cur ^= 1;
             }

@@ -10,11 +10,12 @@ import numpy as np, torch, synth
 from review_based_recommender_amd import _lib
 
 csrc = os.path.join(ROOT, "review-based-recommender_amd", "csrc")
-out = os.path.join(ROOT, "tools", "diag", "librbr_diag.so")
+variant = os.environ.get("RBR_DIAG_VARIANT", "")      # 1: no weight DMA in the loop, 2: no LDS weight reads, 3: no barriers (results wrong)
+out = os.path.join(ROOT, "tools", "diag", f"librbr_diag{variant}.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = sorted(glob.glob(os.path.join(csrc, "*.hip")))
 if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs + glob.glob(os.path.join(csrc, "*.h"))):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRBR_DIAG",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DRBR_DIAG", *([f"-DRBR_DIAG_VARIANT={variant}"] if variant else []),
                            "-o", out] + srcs)
 lib = C.CDLL(out)
 for n in ("rbr_textcnn_pack", "rbr_textcnn_conv_fwd", "rbr_textcnn_packed_floats", "rbr_textcnn_partial_elems",
