@@ -68,8 +68,8 @@ class NARRE(nn.Module):
         ids = RF.stack_rows(u_text.reshape(-1, T), i_text.reshape(-1, T))
         masks = RF.stack_rows(u_text_masks.reshape(-1, T), i_text_masks.reshape(-1, T))
         feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
-        u_feat = feats[:bz * R].view(bz, R, self.hiddem_dim)
-        i_feat = feats[bz * R:].view(bz, R, self.hiddem_dim)
+        # unbind, not two slices: its backward is ONE stack of the two gradients (a slice pair costs two fills, two copies, an add)
+        u_feat, i_feat = feats.view(2, bz, R, self.hiddem_dim).unbind(0)
 
         u_feat, u_att_scores = self.user_att(u_feat, reuid)
         i_feat, i_att_scores = self.item_att(i_feat, reiid)
