@@ -189,6 +189,16 @@ int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                       float* ul, float* il, float* pred, void* stream);
 
+/* Training forward in one launch: the same computation with the dropout multiplier drawn inside the kernel -- element
+ * (b, k) gets exactly the value rbr_dropout_multiplier(B*K, p_drop, seed, rng_state, ...) would write at b*K + k for the
+ * same call number, and the call number advances once -- and written to drop_out [B,K] for the backward (p_drop == 0: no
+ * dropout, rng_state / drop_out may be NULL).  zero_buf / zero_n (optional): a float buffer cleared by spare workgroups of
+ * the same launch; the module passes the embedding-style gradients rbr_pair_head_bwd accumulates into. */
+int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                            const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, float p_drop,
+                            uint64_t seed, uint64_t* rng_state, float* drop_out, float* zero_buf, int64_t zero_n,
+                            float* ul, float* il, float* pred, void* stream);
+
 /* d_ufeat/d_ifeat [B,H] overwritten; dense grads overwritten; embedding grads accumulated
  * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx).
  * ws: rbr_pair_head_bwd_ws_floats(B, K) floats (may be 0 / NULL: the current kernel needs no scratch). */
@@ -206,8 +216,11 @@ int rbr_dropout_multiplier(int64_t n, float p, uint64_t seed, uint64_t* state, f
 
 /* ---- nn.MSELoss(reduction="mean") of the trainers (trainer/train_deepconn_pp.py:137,164):
  *   loss[0] = sum_i (pred[i]-target[i])^2 / n   (one workgroup, fixed summation order)
- *   d_pred[i] = 2 (pred[i]-target[i]) / n * d_loss[0]       (d_loss is a device scalar)          ---- */
-int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, void* stream);
+ *   d_pred[i] = 2 (pred[i]-target[i]) / n * d_loss[0]       (d_loss is a device scalar)
+ *   d_pred_unit (optional, [n]): d loss / d pred for an upstream gradient of exactly 1, written by the forward launch, so
+ *   that a backward called with that gradient (loss.backward()) needs no launch of its own.
+ */
+int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, float* d_pred_unit, void* stream);
 int rbr_mse_loss_bwd(int64_t n, const float* pred, const float* target, const float* d_loss, float* d_pred,
                      void* stream);
 

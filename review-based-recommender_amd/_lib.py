@@ -105,12 +105,14 @@ SIGNATURES = {
                                      C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_pair_head_fwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
                                     c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_pair_head_fwd_train": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), C.c_float,
+                                          C.c_uint64, C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_pair_head_bwd_ws_floats": (C.c_size_t, [i32, i32]),
     "rbr_pair_head_bwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
                                     c_f32p, c_f32p, c_f32p, i32, i32, C.POINTER(HeadGrads), c_f32p, c_f32p, c_f32p,
                                     c_stream]),
     "rbr_dropout_multiplier": (C.c_int, [C.c_int64, C.c_float, C.c_uint64, C.c_void_p, c_f32p, c_stream]),
-    "rbr_mse_loss_fwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_mse_loss_fwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_mse_loss_bwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_review_attn_fwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p,
                                       c_f32p, c_stream]),

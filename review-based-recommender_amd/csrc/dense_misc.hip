@@ -303,31 +303,19 @@ extern "C" int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k
 // bookkeeping (two fill launches per replay) a torch RNG op costs inside a captured step.
 namespace rbr {
 
-__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-
 __global__ __launch_bounds__(256) void dropout_mult_kernel(long n, float p, unsigned long long seed,
                                                            unsigned long long* __restrict__ state, float* __restrict__ out) {
     const unsigned long long call = state[0];
     const float keep = 1.f / (1.f - p);
     const long nquads = (n + 3) >> 2;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (long)gridDim.x * 256) {
-        unsigned c0 = (unsigned)q, c1 = (unsigned)((unsigned long long)q >> 32), c2 = (unsigned)call, c3 = (unsigned)(call >> 32);
-        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
+        unsigned c0, c1, c2, c3;
+        philox4x32_10((unsigned long long)q, call, seed, c0, c1, c2, c3);
         const unsigned w[4] = {c0, c1, c2, c3};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const long i = 4 * q + e;
-            if (i < n) out[i] = ((float)(w[e] >> 8) * (1.f / 16777216.f) >= p) ? keep : 0.f;     // u in [0,1), 24 bits
+            if (i < n) out[i] = dropout_keep(w[e], p) ? keep : 0.f;
         }
     }
     __syncthreads();

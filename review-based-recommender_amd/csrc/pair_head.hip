@@ -17,16 +17,43 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+struct HeadTrain {               // rbr_pair_head_fwd_train extras; all zero for the plain forward
+    float p_drop;
+    unsigned long long seed;
+    unsigned long long* rng_state;      // [call number, ticket], as rbr_dropout_multiplier
+    float* drop_out;                    // [B,K] multiplier, written for the backward
+    float* zero_buf;
+    long zero_n;
+};
+
+// the last workgroup of the launch advances the call number (every pair block has read it by then)
+__device__ __forceinline__ void head_rng_ticket(const HeadTrain& tr, unsigned long long call) {
+    if (tr.rng_state == nullptr) return;
+    __threadfence();
+    if (atomicAdd(tr.rng_state + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
+        tr.rng_state[1] = 0;
+        tr.rng_state[0] = tr.rng_state[0] + 1;
+    }
+    (void)call;
+}
+
 // one workgroup per pair: threads [0,128) run the user tower, [128,256) the item tower; inside a tower 4 thread groups
 // split the H-long dots by h mod 4 and 32 lanes cover k (looped for K > 32).  A thread's loads are issued 8 at a time.
 __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
                                                        const float* __restrict__ itf, const long long* __restrict__ uid,
                                                        const long long* __restrict__ iid, const rbr_head_params p,
                                                        const float* __restrict__ drop, float* __restrict__ ul,
-                                                       float* __restrict__ il, float* __restrict__ pred) {
+                                                       float* __restrict__ il, float* __restrict__ pred,
+                                                       const HeadTrain tr) {
     __shared__ float s_part[2][4][32];
     __shared__ float s_l[2][32];
     const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= B) {                 // training launch only: blocks past the pairs clear the buffer the backward accumulates into
+        for (long k = (long)(b - B) * 256 + t; k < tr.zero_n; k += (long)(gridDim.x - B) * 256) tr.zero_buf[k] = 0.f;
+        if (t == 0) head_rng_ticket(tr, 0);
+        return;
+    }
+    const unsigned long long call = (tr.p_drop > 0.f) ? tr.rng_state[0] : 0;
     const int side = t >> 7, hp = (t >> 5) & 3, kk = t & 31;
     const long id = side ? iid[b] : uid[b];
     const float* ft = (side ? itf : uf) + (long)b * H;
@@ -60,7 +87,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
         __syncthreads();
         if (t < 32 && k < K) {
             float z = fmaxf(s_l[0][kk] * s_l[1][kk], 0.f);
-            if (drop != nullptr) z *= drop[(long)b * K + k];
+            if (tr.p_drop > 0.f) {       // the draw rbr_dropout_multiplier would make for element (b, k) of this call
+                const unsigned long long e = (unsigned long long)b * K + k;
+                unsigned w[4];
+                philox4x32_10(e >> 2, call, tr.seed, w[0], w[1], w[2], w[3]);
+                const float m = dropout_keep(w[e & 3], tr.p_drop) ? 1.f / (1.f - tr.p_drop) : 0.f;
+                tr.drop_out[e] = m;
+                z *= m;
+            } else if (drop != nullptr) {
+                z *= drop[(long)b * K + k];
+            }
             part = fmaf(z, p.h[k], part);
         }
     }
@@ -68,6 +104,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
         part = wave_sum(part);
         if (t == 0) pred[b] = part + p.ub[uid[b]] + p.ib[iid[b]] + p.g[0];
     }
+    if (t == 0 && tr.rng_state != nullptr) head_rng_ticket(tr, call);
 }
 
 // The backward in ONE launch.  Blocks [0, B): one workgroup per pair -- embedding-row grads (atomics), then d_feat with all
@@ -193,12 +230,13 @@ static bool head_args_ok(int B, int H, int K) {
 namespace rbr {
 // ---- nn.MSELoss (mean) of the trainers.  One workgroup, fixed summation order: the loss is bitwise reproducible.
 __global__ __launch_bounds__(256) void mse_fwd_kernel(long n, const float* __restrict__ pred, const float* __restrict__ target,
-                                                      float* __restrict__ loss) {
+                                                      float* __restrict__ loss, float* __restrict__ d_unit) {
     __shared__ float s_red[4];
     float acc = 0.f;
     for (long i = threadIdx.x; i < n; i += 256) {
         const float d = pred[i] - target[i];
         acc += d * d;
+        if (d_unit != nullptr) d_unit[i] = d * (2.f / (float)n);       // d loss / d pred for an upstream gradient of 1
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -215,9 +253,9 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(long n, const float* __res
 
 }  // namespace rbr
 
-extern "C" int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, void* stream) {
+extern "C" int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, float* d_pred_unit, void* stream) {
     if (n <= 0 || !pred || !target || !loss) { rbr::set_error("mse_loss_fwd: n=%lld or null pointer", (long long)n); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(rbr::mse_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long)n, pred, target, loss);
+    hipLaunchKernelGGL(rbr::mse_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long)n, pred, target, loss, d_pred_unit);
     RBR_CHECK_LAUNCH("mse_fwd launch");
     return 0;
 }
@@ -238,8 +276,29 @@ extern "C" int rbr_pair_head_fwd(int32_t B, int32_t H, int32_t K, const float* u
     if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !pred) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H, K, u_feat, i_feat,
                        reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop, ul,
-                       il, pred);
+                       il, pred, HeadTrain{});
     RBR_CHECK_LAUNCH("pair_head_fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, float p_drop,
+                                       uint64_t seed, uint64_t* rng_state, float* drop_out, float* zero_buf, int64_t zero_n,
+                                       float* ul, float* il, float* pred, void* stream) {
+    if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
+    if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !pred) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("pair_head_fwd_train: p_drop=%f outside [0,1)", (double)p_drop); return RBR_ERR_BAD_ARG; }
+    if (p_drop > 0.f && (!rng_state || !drop_out)) { set_error("pair_head_fwd_train: dropout needs rng_state and drop_out"); return RBR_ERR_BAD_ARG; }
+    if (zero_n < 0 || (zero_n > 0 && !zero_buf)) { set_error("pair_head_fwd_train: bad zero buffer"); return RBR_ERR_BAD_ARG; }
+    HeadTrain tr{};
+    tr.p_drop = p_drop; tr.seed = seed;
+    tr.rng_state = (p_drop > 0.f) ? reinterpret_cast<unsigned long long*>(rng_state) : nullptr;
+    tr.drop_out = drop_out; tr.zero_buf = zero_buf; tr.zero_n = zero_n;
+    const int zblocks = zero_n > 0 ? (int)std::min<long>((zero_n + 1023) / 1024, 256) : 0;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B + zblocks), dim3(256), 0, (hipStream_t)stream, B, H, K, u_feat, i_feat,
+                       reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p,
+                       static_cast<const float*>(nullptr), ul, il, pred, tr);
+    RBR_CHECK_LAUNCH("pair_head_fwd_train launch");
     return 0;
 }
 

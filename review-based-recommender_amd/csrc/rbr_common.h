@@ -132,6 +132,30 @@ inline int choose_dc(int D) {
     return 20;
 }
 
+
+// ---- Philox4x32-10 for the dropout draws (dense_misc.hip: rbr_dropout_multiplier; pair_head.hip: the fused head forward).
+// Element i of call number `call` under `seed` is word (i & 3) of the block with counter (i >> 2, call).
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned long long quad, unsigned long long call, unsigned long long seed,
+                                              unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3) {
+    c0 = (unsigned)quad; c1 = (unsigned)(quad >> 32); c2 = (unsigned)call; c3 = (unsigned)(call >> 32);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ bool dropout_keep(unsigned word, float p) {      // u in [0,1) from the top 24 bits; keep iff u >= p
+    return (float)(word >> 8) * (1.f / 16777216.f) >= p;
+}
+
 }  // namespace rbr
 
 #define RBR_CHECK_LAUNCH(what)                                   \

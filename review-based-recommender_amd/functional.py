@@ -264,6 +264,10 @@ def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor]
     return (feat, argmax) if return_argmax else feat
 
 
+_HEAD_NAMES = ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib")
+_HEAD_ACC = ("Eu", "Ei", "ub", "ib")       # gradients accumulated with atomics (rows addressed by id)
+
+
 class _PairHead(torch.autograd.Function):
     """pred[B] = FM(LastFeat_u(u_feat, u_id), LastFeat_i(i_feat, i_id))  -- rbr_pair_head_* in rbr_hip.h."""
 
@@ -285,15 +289,34 @@ class _PairHead(torch.autograd.Function):
         u_id, i_id = u_id.contiguous(), i_id.contiguous()
         params = [t.contiguous() for t in (Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)]
         hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(params, ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib"))])
-        if drop is not None:
-            drop = drop.contiguous()
         ul = torch.empty(B, K, dtype=F32, device=dev)
         il = torch.empty(B, K, dtype=F32, device=dev)
         pred = torch.empty(B, dtype=F32, device=dev)
-        check(L_.rbr_pair_head_fwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
-                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
-                                   dev_ptr(drop, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
-                                   dev_ptr(pred, F32, "pred"), current_stream()), "rbr_pair_head_fwd")
+        ctx.flat = None
+        if isinstance(drop, float):
+            # training forward in one launch: the kernel draws the dropout multiplier itself (same stream of draws as
+            # dropout_multiplier) and its spare workgroups clear the buffer the backward accumulates the embedding-style
+            # gradients into
+            p_drop = drop
+            if p_drop >= 1.0:
+                raise RuntimeError("pair_head: drop probability must be < 1 on the fused path")
+            acc_n = sum(t.numel() for t, n in zip(params, _HEAD_NAMES) if n in _HEAD_ACC) if any(ctx.needs_input_grad[7:]) else 0
+            flat = torch.empty(acc_n, dtype=F32, device=dev) if acc_n else None
+            seed, state = _drop_rng(dev)
+            drop = torch.empty(B, K, dtype=F32, device=dev) if p_drop > 0.0 else None
+            check(L_.rbr_pair_head_fwd_train(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
+                                             dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp), float(p_drop),
+                                             seed, state.data_ptr(), dev_ptr(drop, F32, "drop"), dev_ptr(flat, F32, "zero_buf"),
+                                             acc_n, dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"), dev_ptr(pred, F32, "pred"),
+                                             current_stream()), "rbr_pair_head_fwd_train")
+            ctx.flat = flat
+        else:
+            if drop is not None:
+                drop = drop.contiguous()
+            check(L_.rbr_pair_head_fwd(B, H, K, dev_ptr(u_feat, F32, "u_feat"), dev_ptr(i_feat, F32, "i_feat"),
+                                       dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                       dev_ptr(drop, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                       dev_ptr(pred, F32, "pred"), current_stream()), "rbr_pair_head_fwd")
         ctx.dims = (B, H, K, int(pad_u), int(pad_i))
         ctx.has_drop = drop is not None
         ctx.save_for_backward(u_feat, i_feat, u_id, i_id, ul, il, *params, *([drop] if drop is not None else []))
@@ -312,8 +335,10 @@ class _PairHead(torch.autograd.Function):
         hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(params, names)])
         # embedding-style grads are accumulated with atomics -> start from zero (one fill for the four of them);
         # the rest is overwritten
-        acc = [t for t, n in zip(params, names) if n in ("Eu", "Ei", "ub", "ib")]
-        flat = torch.zeros(sum(t.numel() for t in acc), dtype=F32, device=dev)
+        acc = [t for t, n in zip(params, names) if n in _HEAD_ACC]
+        flat, ctx.flat = ctx.flat, None         # cleared by the training forward; a second backward gets a fresh one
+        if flat is None:
+            flat = torch.zeros(sum(t.numel() for t in acc), dtype=F32, device=dev)
         zeroed = iter(v.view_as(t) for v, t in zip(flat.split([t.numel() for t in acc]), acc))
         grads = [next(zeroed) if n in ("Eu", "Ei", "ub", "ib") else torch.empty_like(t) for t, n in zip(params, names)]
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
@@ -335,7 +360,8 @@ class _PairHead(torch.autograd.Function):
 
 def pair_head(u_feat, i_feat, u_id, i_id, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib, *, drop=None, pad_u=0, pad_i=0):
     """LastFeat x2 + FM.  u_feat/i_feat [B,H] (or u_feat [2B,H] = user rows then item rows, i_feat None);
-    ids [B] int64; returns pred [B]."""
+    ids [B] int64; returns pred [B].  drop: None, a [B,K] multiplier tensor, or a float = dropout probability of a
+    TRAINING forward (the kernel draws the multiplier itself: one launch less than dropout_multiplier + pair_head)."""
     return _PairHead.apply(u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)
 
 
@@ -380,17 +406,24 @@ def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torc
     # own Philox kernel with the call counter in device memory: one launch, and -- unlike a torch RNG op -- nothing for the
     # host to patch before every replay of a captured step (the generator's seed / offset fills)
     dev = torch.device(device)
+    seed, state = _drop_rng(dev)
+    out = torch.empty(shape, dtype=F32, device=dev)
+    check(_lib.lib().rbr_dropout_multiplier(out.numel(), float(p), seed, state.data_ptr(), dev_ptr(out, F32, "out"),
+                                            current_stream()), "rbr_dropout_multiplier")
+    return out
+
+
+def _drop_rng(dev):
+    """(seed, device state) of the dropout draws on `dev`: the device generator's seed (torch.manual_seed) and the
+    [call number, ticket] pair that lives on the device."""
+    dev = torch.device(dev)
     if dev.type != "cuda":
-        raise RuntimeError(f"dropout_multiplier: device must be a HIP device (got {dev}); there is no CPU path")
+        raise RuntimeError(f"dropout: device must be a HIP device (got {dev}); there is no CPU path")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     state = _DROP_STATE.get(idx)
     if state is None:
         state = _DROP_STATE[idx] = torch.zeros(2, dtype=torch.int64, device=dev)
-    out = torch.empty(shape, dtype=F32, device=dev)
-    seed = torch.cuda.default_generators[idx].initial_seed() & 0xFFFFFFFFFFFFFFFF
-    check(_lib.lib().rbr_dropout_multiplier(out.numel(), float(p), seed, state.data_ptr(), dev_ptr(out, F32, "out"),
-                                            current_stream()), "rbr_dropout_multiplier")
-    return out
+    return torch.cuda.default_generators[idx].initial_seed() & 0xFFFFFFFFFFFFFFFF, state
 
 
 _DROP_STATE: dict = {}       # per device: [call number, workgroup ticket] (uint64 x 2), advanced on the device
@@ -398,7 +431,9 @@ _DROP_STATE: dict = {}       # per device: [call number, workgroup ticket] (uint
 
 
 class _MseLoss(torch.autograd.Function):
-    """mean((pred - target)^2) -- the trainers' nn.MSELoss (train_deepconn_pp.py:137,164) as one launch each way."""
+    """mean((pred - target)^2) -- the trainers' nn.MSELoss (train_deepconn_pp.py:137,164).  The forward launch also writes
+    d loss / d pred for an upstream gradient of 1; a backward that is handed unit_scalar() (train_step does that) returns it
+    without a launch, any other upstream gradient costs one launch."""
 
     @staticmethod
     def forward(ctx, pred, target):
@@ -406,20 +441,38 @@ class _MseLoss(torch.autograd.Function):
         if pred.shape != target.shape:
             raise RuntimeError(f"mse_loss: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
         loss = torch.empty((), dtype=F32, device=pred.device)
+        d_unit = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
         check(_lib.lib().rbr_mse_loss_fwd(pred.numel(), dev_ptr(pred, F32, "pred"), dev_ptr(target, F32, "target"),
-                                          dev_ptr(loss, F32, "loss"), current_stream()), "rbr_mse_loss_fwd")
-        ctx.save_for_backward(pred, target)
+                                          dev_ptr(loss, F32, "loss"), dev_ptr(d_unit, F32, "d_pred_unit"), current_stream()),
+              "rbr_mse_loss_fwd")
+        ctx.save_for_backward(pred, target, *([d_unit] if d_unit is not None else []))
         return loss
 
     @staticmethod
     def backward(ctx, d_loss):
-        pred, target = ctx.saved_tensors
+        pred, target = ctx.saved_tensors[:2]
+        unit = _UNIT.get(pred.device)
+        if unit is not None and len(ctx.saved_tensors) == 3 and d_loss.data_ptr() == unit.data_ptr():
+            return ctx.saved_tensors[2], None
         d_pred = torch.empty_like(pred)
         d_loss = d_loss.contiguous()
         check(_lib.lib().rbr_mse_loss_bwd(pred.numel(), dev_ptr(pred, F32, "pred"), dev_ptr(target, F32, "target"),
                                           dev_ptr(d_loss, F32, "d_loss"), dev_ptr(d_pred, F32, "d_pred"), current_stream()),
               "rbr_mse_loss_bwd")
         return d_pred, None
+
+
+_UNIT: dict = {}
+
+
+def unit_scalar(device) -> torch.Tensor:
+    """The constant 1.0 on `device` (one tensor per device, never written): pass it to loss.backward() as the root gradient
+    to spare the per-step fill, and mse_loss's backward recognises it."""
+    device = torch.device(device)
+    t = _UNIT.get(device)
+    if t is None:
+        t = _UNIT[device] = torch.ones((), dtype=F32, device=device)
+    return t
 
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

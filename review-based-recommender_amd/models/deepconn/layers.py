@@ -178,7 +178,10 @@ class FM(nn.Module):
 def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm: FM, u_text_feat, i_text_feat, u_ids, i_ids):
     """LastFeat(user) + LastFeat(item) + FM in one HIP kernel pair (layers.py:156-165,189-209).
     i_text_feat None: u_text_feat holds both towers, [2*bz, H] with the user rows first."""
-    drop = RF.dropout_multiplier((u_ids.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
+    if fm.training and fm.dropout.p < 1.0 and torch.is_grad_enabled():
+        drop = float(fm.dropout.p)       # training forward: the head kernel draws the mask (and clears its gradient buffer) itself
+    else:
+        drop = RF.dropout_multiplier((u_ids.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
     return RF.pair_head(u_text_feat, i_text_feat, u_ids, i_ids,
                         user_feat.W, user_feat.b, user_feat.ebd.weight,
                         item_feat.W, item_feat.b, item_feat.ebd.weight,

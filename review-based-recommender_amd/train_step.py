@@ -141,7 +141,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     if pred.is_cuda and pred.dtype == torch.float32 and ratings.dtype == torch.float32 and pred.shape == ratings.shape:
         # one launch each way, and the root gradient is a cached device scalar (no fill per step)
         loss = RF.mse_loss(pred, ratings)
-        loss.backward(_unit(pred.device))
+        loss.backward(RF.unit_scalar(pred.device))
     else:
         loss = F.mse_loss(pred, ratings)
         loss.backward()
@@ -149,16 +149,6 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
         grad_sync(model)
     gnorm = clip_and_step(model, optimizer, max_grad_norm)
     return loss.detach(), gnorm, pred.detach()
-
-
-_UNIT: dict = {}
-
-
-def _unit(device) -> torch.Tensor:
-    t = _UNIT.get(device)
-    if t is None:
-        t = _UNIT[device] = torch.ones((), dtype=torch.float32, device=device)
-    return t
 
 
 def clip_and_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_grad_norm: float) -> torch.Tensor:
