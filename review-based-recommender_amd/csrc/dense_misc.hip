@@ -319,8 +319,7 @@ __global__ __launch_bounds__(256) void dropout_mult_kernel(long n, float p, unsi
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
+    if (threadIdx.x == 0) {       // (no fence needed: the call number was consumed before this atomic is issued)
         if (atomicAdd(state + 1, 1ull) == (unsigned long long)gridDim.x - 1) {      // every workgroup has read state[0]
             state[1] = 0;
             state[0] = call + 1;

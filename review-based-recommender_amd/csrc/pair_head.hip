@@ -29,7 +29,7 @@ struct HeadTrain {               // rbr_pair_head_fwd_train extras; all zero for
 // the last workgroup of the launch advances the call number (every pair block has read it by then)
 __device__ __forceinline__ void head_rng_ticket(const HeadTrain& tr, unsigned long long call) {
     if (tr.rng_state == nullptr) return;
-    __threadfence();
+    // no fence: the call number was consumed (its value used) before this atomic is issued, and nothing else is published
     if (atomicAdd(tr.rng_state + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
         tr.rng_state[1] = 0;
         tr.rng_state[0] = tr.rng_state[0] + 1;
