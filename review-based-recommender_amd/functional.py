@@ -396,7 +396,7 @@ def clone_adjacent(tensors):
     return tuple(out)
 
 
-def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torch.Tensor]:
+def dropout_multiplier(shape, p: float, training: bool, device, lane: int = 0) -> Optional[torch.Tensor]:
     """The multiplier F.dropout would apply (0 or 1/(1-p)): rbr_dropout_multiplier, keyed by the device generator's seed
     (torch.manual_seed) and a per-device call counter that lives on the device."""
     if not training or p <= 0.0:
@@ -406,24 +406,59 @@ def dropout_multiplier(shape, p: float, training: bool, device) -> Optional[torc
     # own Philox kernel with the call counter in device memory: one launch, and -- unlike a torch RNG op -- nothing for the
     # host to patch before every replay of a captured step (the generator's seed / offset fills)
     dev = torch.device(device)
-    seed, state = _drop_rng(dev)
+    seed, state = _drop_rng(dev, lane)
     out = torch.empty(shape, dtype=F32, device=dev)
     check(_lib.lib().rbr_dropout_multiplier(out.numel(), float(p), seed, state.data_ptr(), dev_ptr(out, F32, "out"),
                                             current_stream()), "rbr_dropout_multiplier")
     return out
 
 
-def _drop_rng(dev):
+def _drop_rng(dev, lane: int = 0):
     """(seed, device state) of the dropout draws on `dev`: the device generator's seed (torch.manual_seed) and the
-    [call number, ticket] pair that lives on the device."""
+    [call number, ticket] pair that lives on the device.  `lane` selects an independent stream of draws: launches that may
+    run concurrently (the second tower on its own HIP stream, second_tower()) must not share a call counter."""
     dev = torch.device(dev)
     if dev.type != "cuda":
         raise RuntimeError(f"dropout: device must be a HIP device (got {dev}); there is no CPU path")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    state = _DROP_STATE.get(idx)
+    state = _DROP_STATE.get((idx, lane))
     if state is None:
-        state = _DROP_STATE[idx] = torch.zeros(2, dtype=torch.int64, device=dev)
-    return torch.cuda.default_generators[idx].initial_seed() & 0xFFFFFFFFFFFFFFFF, state
+        state = _DROP_STATE[(idx, lane)] = torch.zeros(2, dtype=torch.int64, device=dev)
+    seed = (torch.cuda.default_generators[idx].initial_seed() + 0x9E3779B97F4A7C15 * lane) & 0xFFFFFFFFFFFFFFFF
+    return seed, state
+
+
+_TOWER_STREAMS: dict = {}
+
+
+def fork_tower(dev):
+    """A second HIP stream, made to wait for the current one: run the item tower of a two-tower model under
+    `with torch.cuda.stream(side):`, enqueue the user tower on the current stream, then join_tower(side, outputs).  autograd
+    replays each op's backward on its forward stream, so the towers overlap in both directions, and a captured step gets two
+    parallel branches.  Returns None with RBR_TOWER_OVERLAP=0 (torch.cuda.stream(None) is a no-op: plain sequential code).
+    Only for sub-networks that share NO parameter with the rest of the step (NARRE's two attention pools): a parameter used
+    on both streams gets its gradient accumulated across streams, which torch warns about and which crashed graph capture
+    for D-ATT's shared word table and fc."""
+    if os.environ.get("RBR_TOWER_OVERLAP", "1") == "0":
+        return None
+    dev = torch.device(dev)
+    s = _TOWER_STREAMS.get(dev)
+    if s is None:
+        s = _TOWER_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    return s
+
+
+def join_tower(side, *tensors) -> None:
+    """The current stream waits for `side`; `tensors` (made on `side`, used from here on) are marked as used by the current
+    stream for the caching allocator."""
+    if side is None:
+        return
+    cur = torch.cuda.current_stream(side.device)
+    cur.wait_stream(side)
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            t.record_stream(cur)
 
 
 _DROP_STATE: dict = {}       # per device: [call number, workgroup ticket] (uint64 x 2), advanced on the device

@@ -27,11 +27,13 @@ class LinearAttention(nn.Module):
         self.ebd_vals = nn.Embedding(vocab_size, hidden_dim, padding_idx=padding_idx)
         self.dropout = nn.Dropout(p=dropout)
 
+    rng_lane = 0      # NARRE.forward runs the item side on a second stream and gives it its own stream of dropout draws
+
     def forward(self, feat, other_id):
         """feat [bz, dnum, hidden], other_id [bz, dnum] -> (out [bz, hidden], att_scores [bz, dnum, 1])."""
         out, att = RF.review_attention(feat, other_id, self.W_rv, self.W_id, self.h, self.b_1, self.b_2,
                                        self.ebd_vals.weight, pad_idx=self.padding_idx)
-        drop = RF.dropout_multiplier(out.shape, self.dropout.p, self.training, out.device)
+        drop = RF.dropout_multiplier(out.shape, self.dropout.p, self.training, out.device, lane=self.rng_lane)
         if drop is not None:
             out = out * drop
         return out, att
@@ -71,8 +73,14 @@ class NARRE(nn.Module):
         # unbind, not two slices: its backward is ONE stack of the two gradients (a slice pair costs two fills, two copies, an add)
         u_feat, i_feat = feats.view(2, bz, R, self.hiddem_dim).unbind(0)
 
+        # the two attention pools share nothing: the item side runs on a second stream (forward and, through autograd's
+        # stream bookkeeping, backward)
+        side = RF.fork_tower(feats.device)
+        self.item_att.rng_lane = 1 if side is not None else 0
+        with torch.cuda.stream(side):
+            i_feat, i_att_scores = self.item_att(i_feat, reiid)
         u_feat, u_att_scores = self.user_att(u_feat, reuid)
-        i_feat, i_att_scores = self.item_att(i_feat, reiid)
+        RF.join_tower(side, i_feat, i_att_scores)
 
         pred = rating_head(self.user_feat, self.item_feat, self.fm, u_feat, i_feat, u_id, i_id)
         return pred.view(-1), u_att_scores, i_att_scores

@@ -235,7 +235,7 @@ def test_dropout_multiplier_statistics_and_replay():
     a, b = RF.dropout_multiplier((64, 32), 0.5, True, dev), RF.dropout_multiplier((64, 32), 0.5, True, dev)
     assert not torch.equal(a, b)
     # same (seed, call number) -> same mask: rewind the device counter
-    state = RF._DROP_STATE[dev.index]
+    state = RF._DROP_STATE[(dev.index, 0)]
     torch.cuda.synchronize()
     call = int(state[0])
     c1 = RF.dropout_multiplier((777,), 0.3, True, dev)
