@@ -75,7 +75,7 @@ class NARRE(nn.Module):
 
         # the two attention pools share nothing: the item side runs on a second stream (forward and, through autograd's
         # stream bookkeeping, backward)
-        side = RF.fork_tower(feats.device)
+        side = RF.fork_tower(feats.device) if torch.is_grad_enabled() else None     # (eval: two 12-us kernels, not worth the host work)
         self.item_att.rng_lane = 1 if side is not None else 0
         with torch.cuda.stream(side):
             i_feat, i_att_scores = self.item_att(i_feat, reiid)
