@@ -138,17 +138,23 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     optimizer.zero_grad()
     out = model(*batch)
     pred = out[0] if isinstance(out, tuple) else out
+    loss = _loss_and_backward(pred, ratings)
+    if grad_sync is not None:
+        grad_sync(model)
+    gnorm = clip_and_step(model, optimizer, max_grad_norm)
+    return loss.detach(), gnorm, pred.detach()
+
+
+def _loss_and_backward(pred: torch.Tensor, ratings: torch.Tensor) -> torch.Tensor:
+    """loss = MSELoss()(pred, ratings); loss.backward()  (train_deepconn_pp.py:164-165)."""
     if pred.is_cuda and pred.dtype == torch.float32 and ratings.dtype == torch.float32 and pred.shape == ratings.shape:
-        # one launch each way, and the root gradient is a cached device scalar (no fill per step)
+        # one launch for the loss AND its gradient; the root gradient is a cached device scalar (no fill per step)
         loss = RF.mse_loss(pred, ratings)
         loss.backward(RF.unit_scalar(pred.device))
     else:
         loss = F.mse_loss(pred, ratings)
         loss.backward()
-    if grad_sync is not None:
-        grad_sync(model)
-    gnorm = clip_and_step(model, optimizer, max_grad_norm)
-    return loss.detach(), gnorm, pred.detach()
+    return loss
 
 
 def clip_and_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_grad_norm: float) -> torch.Tensor:
@@ -208,8 +214,7 @@ class GraphedTrainStep:
                 optimizer.zero_grad()
                 out = model(*self.batch)
                 pred = out[0] if isinstance(out, tuple) else out
-                loss = F.mse_loss(pred, self.ratings)
-                loss.backward()
+                loss = _loss_and_backward(pred, self.ratings)
                 self.loss, self.pred = loss.detach(), pred.detach()
             grad_sync(model)
             self._static_grads = [(p, p.grad) for p in model.parameters()]
