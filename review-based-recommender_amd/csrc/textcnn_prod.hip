@@ -43,14 +43,14 @@ struct ProdArgs {
 // hold an unmasked token), the remaining blocks mark the tokens that occur.  Independent jobs, one launch.
 __global__ __launch_bounds__(256) void mark_scan_kernel(const ConvPlan P, int nb_scan, long n_tok, const long long* __restrict__ ids,
                                                         const unsigned char* __restrict__ mask, int* __restrict__ sched,
-                                                        int* __restrict__ used) {
+                                                        unsigned char* __restrict__ used) {
     if ((int)blockIdx.x < nb_scan) {
         tile_scan_block(P, mask, sched, blockIdx.x);
         return;
     }
     const long nb = gridDim.x - nb_scan;
     for (long k = (long)(blockIdx.x - nb_scan) * 256 + threadIdx.x; k < n_tok; k += nb * 256)
-        if (mask == nullptr || mask[k]) used[ids[k]] = 1;      // benign race: everyone stores 1
+        if (mask == nullptr || mask[k]) used[ids[k]] = 1;      // benign race: everyone stores 1 (one byte per token id)
 }
 
 struct PackJob {        // weight images of the product formulation, both derived from the torch-layout conv weights
@@ -73,7 +73,7 @@ __device__ __forceinline__ float prod_weight(const PackJob& J, const PtrArray& W
 // tok_of_row / row_mask describe the pseudo-document, *counter = rows); the remaining blocks write the product weight
 // image of the forward GEMM and the row-major Wprod^T the backward's sparse product reads.
 __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int nb_compact, int V, int cap,
-                                                           const int* __restrict__ used, int* __restrict__ row_of_token,
+                                                           const unsigned char* __restrict__ used, int* __restrict__ row_of_token,
                                                            long long* __restrict__ tok_of_row, unsigned char* __restrict__ row_mask,
                                                            int* __restrict__ counter, float* __restrict__ zero_row, int pitch,
                                                            const PtrArray W, float* __restrict__ packed, float* __restrict__ WT) {
@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int below = blockIdx.x * 256;
         int c = 0;
-        const int4* u4 = reinterpret_cast<const int4*>(used);
-        for (int q = threadIdx.x; q < below / 4; q += 256) {
+        const int4* u4 = reinterpret_cast<const int4*>(used);          // 16 marks (bytes of value 0 / 1) per load
+        for (int q = threadIdx.x; q < below / 16; q += 256) {
             const int4 m = u4[q];
-            c += m.x + m.y + m.z + m.w;
+            c += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
@@ -716,7 +716,7 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     const ConvPlan& p = plans[0];
     size_t o = 0;
     // [used | row_mask] are contiguous and re-zeroed every call together with the counters of `sched`
-    Lo.used = o;         o += align256((size_t)d->V * sizeof(int));
+    Lo.used = o;         o += align256((size_t)d->V);                    // one byte per token id
     Lo.row_mask = o;     o += align256((size_t)Lo.cap);
     Lo.row_of_token = o; o += align256((size_t)d->V * sizeof(int));
     Lo.tok_of_row = o;   o += align256((size_t)Lo.cap * sizeof(long long));
@@ -849,7 +849,8 @@ struct ProdState {       // everything the three forward stages share, derived f
     ProdLayout Lo;
     ConvPlan pp[kMaxGroups];
     ProdArgs A;
-    int *used, *row_of_token, *counter, *sched_p;
+    unsigned char* used;
+    int *row_of_token, *counter, *sched_p;
     long long* tok_of_row;
     unsigned char* row_mask;
     float *packed_p, *WT, *T;
@@ -862,7 +863,7 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
     if (!prod_layout(d, S.Lo)) return RBR_ERR_BAD_ARG;
     const ProdLayout& Lo = S.Lo;
     S.base = static_cast<char*>(ws);
-    S.used = reinterpret_cast<int*>(S.base + Lo.used);
+    S.used = reinterpret_cast<unsigned char*>(S.base + Lo.used);
     S.row_of_token = reinterpret_cast<int*>(S.base + Lo.row_of_token);
     S.tok_of_row = reinterpret_cast<long long*>(S.base + Lo.tok_of_row);
     S.row_mask = reinterpret_cast<unsigned char*>(S.base + Lo.row_mask);
