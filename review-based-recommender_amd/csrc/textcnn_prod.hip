@@ -582,7 +582,6 @@ __global__ __launch_bounds__(256) void dw_from_g_kernel(int KG, int D, int cap, 
                                                         const float* __restrict__ table, float* __restrict__ part) {
     __shared__ float As[32][68];          // [k][col]
     __shared__ float Bs[32][68];          // [k][d]
-    __shared__ long s_off[32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int col0 = blockIdx.x * 64, d0 = blockIdx.y * 64, z = blockIdx.z;
@@ -594,19 +593,43 @@ __global__ __launch_bounds__(256) void dw_from_g_kernel(int KG, int D, int cap, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int c = tid & 63, kq = tid >> 6;                                // element (k = kq + 4 q, c)
-    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
-        __syncthreads();
-        if (tid < 32) s_off[tid] = (r0 + tid < r_end) ? tok_of_row[r0 + tid] * (long)D : -1;
-        __syncthreads();
+    const bool col_ok = col0 + c < KG, d_ok = d0 + c < D;
+    // software pipeline: the table-row offsets run two tiles ahead of the MFMAs, the operand loads one tile ahead (in
+    // registers), so a tile's 16 MFMAs per wave cover the next tile's two dependent round trips
+    long off[8];
+    float ga[8], gb[8];
+    auto load_offs = [&](int r0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int k = kq + 4 * q;
-            const int row = r0 + k;
-            As[k][c] = (row < r_end && col0 + c < KG) ? G[(long)row * KG + col0 + c] : 0.f;
-            const long off = s_off[k];
-            Bs[k][c] = (off >= 0 && d0 + c < D) ? table[off + d0 + c] : 0.f;
+            const int row = r0 + kq + 4 * q;                              // wave-uniform: one broadcast load
+            off[q] = (row < r_end) ? tok_of_row[row] * (long)D : -1;
+        }
+    };
+    auto load_tile = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = r0 + kq + 4 * q;
+            ga[q] = (row < r_end && col_ok) ? G[(long)row * KG + col0 + c] : 0.f;
+            gb[q] = (off[q] >= 0 && d_ok) ? table[off[q] + d0 + c] : 0.f;
+        }
+    };
+    if (r_begin < r_end) {
+        load_offs(r_begin);
+        load_tile(r_begin);
+        load_offs(r_begin + 32);
+    }
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();                    // the previous tile's MFMAs have read LDS
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            As[kq + 4 * q][c] = ga[q];
+            Bs[kq + 4 * q][c] = gb[q];
         }
         __syncthreads();
+        if (r0 + 32 < r_end) {
+            load_tile(r0 + 32);             // uses the offsets fetched one iteration ago
+            load_offs(r0 + 64);
+        }
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + h][wm * 32 + i], Bs[kk + h][wn * 32 + i], acc, 0, 0, 0);
