@@ -180,20 +180,34 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int K, cons
         float s = 0.f, hs = 0.f, gs = 0.f;
         if (k < K) {
             const float hk = p.h[k];
-#pragma unroll 4
-            for (int b = grp; b < B; b += 8) {
-                const float dr = (drop != nullptr) ? drop[(long)b * K + k] : 1.f;
-                const float dp = d_pred[b];
-                float dul, dil, zdp;
-                head_dl(ul[(long)b * K + k], il[(long)b * K + k], dr, dp, hk, dul, dil, zdp);
-                const float dl = side ? dil : dul;
-                if (r < H) {
-                    s = fmaf(ft[(long)b * H + r], dl, s);
-                } else {
-                    s += dl;
-                    if (side == 0) {
-                        hs += zdp;
-                        if (k == 0) gs += dp;
+            // 8 batch rows per round: their 40 loads are issued together (a row past the batch repeats row `grp` with
+            // d_pred = 0, which contributes exact zeros)
+            for (int b0 = grp; b0 < B; b0 += 64) {
+                float vu[8], vi[8], vd[8], vp[8], vf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + 8 * u;
+                    const bool ok = b < B;
+                    const long bb = ok ? b : grp;
+                    vu[u] = ul[bb * K + k];
+                    vi[u] = il[bb * K + k];
+                    vd[u] = (drop != nullptr) ? drop[bb * K + k] : 1.f;
+                    vp[u] = ok ? d_pred[bb] : 0.f;
+                    vf[u] = (r < H) ? ft[bb * H + r] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float dul, dil, zdp;
+                    head_dl(vu[u], vi[u], vd[u], vp[u], hk, dul, dil, zdp);
+                    const float dl = side ? dil : dul;
+                    if (r < H) {
+                        s = fmaf(vf[u], dl, s);
+                    } else {
+                        s += dl;
+                        if (side == 0) {
+                            hs += zdp;
+                            if (k == 0) gs += vp[u];
+                        }
                     }
                 }
             }
