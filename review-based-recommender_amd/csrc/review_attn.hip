@@ -117,10 +117,10 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
 }
 
 // reductions over the N = B*R rows in two stages, fixed partition and order (bitwise reproducible):
-//   stage 1: one workgroup per chunk of 64 rows stages d_pre / feat / embedding rows / hid / d_logit in LDS and writes the
+//   stage 1: one workgroup per chunk of kRedRows rows stages d_pre / feat / embedding rows / hid / d_logit in LDS and writes the
 //            chunk's partial of every output;   stage 2: one thread per output sums the chunks in order.
 // output index: [0, H*A) dW_rv | [H*A, H*A + A*A) dW_id | + A db1 | + A dh | + 1 db2
-constexpr int kRedRows = 64;
+constexpr int kRedRows = 16;      // rows per chunk: B*R = 2560 rows give 160 workgroups (64-row chunks left 5/6 of the CUs idle)
 
 __device__ __forceinline__ int attn_n_out(int H, int A) { return H * A + A * A + 2 * A + 1; }
 
@@ -172,7 +172,15 @@ __global__ __launch_bounds__(256) void attn_bwd_final_kernel(int n_chunks, int H
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
     float t = 0.f;
-    for (int c = 0; c < n_chunks; ++c) t += part[(long)c * n_out + o];
+    int c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {        // 8 independent loads in flight, summed in chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + u) * n_out + o];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; c < n_chunks; ++c) t += part[(long)c * n_out + o];
     if (o < H * A) g.dW_rv[o] = t;
     else if (o < H * A + A * A) g.dW_id[o - H * A] = t;
     else if (o < H * A + A * A + A) g.db1[o - H * A - A * A] = t;
