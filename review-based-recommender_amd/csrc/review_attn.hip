@@ -77,10 +77,16 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* fb = feat + (long)b * R * H;
     const float* ab = att + (long)b * R;
-    for (int r = tid; r < R; r += 256) {
-        float s = (d_att != nullptr) ? d_att[(long)b * R + r] : 0.f;
-        for (int hh = 0; hh < H; ++hh) s = fmaf(d_out[(long)b * H + hh], fb[(long)r * H + hh], s);
-        s_da[r] = s;
+    {   // d att_r = d_att_r + <d_out, feat_r>: one wave per review, lanes over the hidden dim (R is ~10: a thread per review
+        // left 246 threads idle behind ten H-long chains of dependent loads)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int r = wave; r < R; r += 4) {
+            float s = 0.f;
+            for (int hh = lane; hh < H; hh += 64) s = fmaf(d_out[(long)b * H + hh], fb[(long)r * H + hh], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) s_da[r] = s + ((d_att != nullptr) ? d_att[(long)b * R + r] : 0.f);
+        }
     }
     __syncthreads();
     float S = 0.f;
@@ -100,10 +106,20 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         ws_dpre[((long)b * R + r) * A + a] = v;
     }
     __syncthreads();
+    const bool vec = (A & 3) == 0 && ((((uintptr_t)p.W_rv) | ((uintptr_t)p.W_id)) & 15) == 0;     // rows of A floats as float4
     for (int idx = tid; idx < R * H; idx += 256) {
         const int r = idx / H, hh = idx - r * H;
         float s = ab[r] * d_out[(long)b * H + hh];
-        for (int a = 0; a < A; ++a) s = fmaf(s_dpre[r * A + a], p.W_rv[(long)hh * A + a], s);
+        const float* wrow = p.W_rv + (long)hh * A;
+        if (vec) {
+            for (int a = 0; a < A; a += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + a);
+                s = fmaf(s_dpre[r * A + a], wv.x, s); s = fmaf(s_dpre[r * A + a + 1], wv.y, s);
+                s = fmaf(s_dpre[r * A + a + 2], wv.z, s); s = fmaf(s_dpre[r * A + a + 3], wv.w, s);
+            }
+        } else {
+            for (int a = 0; a < A; ++a) s = fmaf(s_dpre[r * A + a], wrow[a], s);
+        }
         d_feat[((long)b * R + r) * H + hh] = s;
     }
     for (int idx = tid; idx < R * A; idx += 256) {
@@ -111,7 +127,16 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         const long id = oid[(long)b * R + r];
         if (id == pad_idx) continue;                 // nn.Embedding(padding_idx): no gradient for the pad row
         float s = 0.f;
-        for (int a = 0; a < A; ++a) s = fmaf(s_dpre[r * A + a], p.W_id[(long)a2 * A + a], s);
+        const float* wrow = p.W_id + (long)a2 * A;
+        if (vec) {
+            for (int a = 0; a < A; a += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + a);
+                s = fmaf(s_dpre[r * A + a], wv.x, s); s = fmaf(s_dpre[r * A + a + 1], wv.y, s);
+                s = fmaf(s_dpre[r * A + a + 2], wv.z, s); s = fmaf(s_dpre[r * A + a + 3], wv.w, s);
+            }
+        } else {
+            for (int a = 0; a < A; ++a) s = fmaf(s_dpre[r * A + a], wrow[a], s);
+        }
         atomicAdd(debd + id * A + a2, s);
     }
 }

@@ -70,7 +70,7 @@ def test_review_attention_random(case):
     (go * d.to(DEV)).sum().backward()
     assert max_err(go.detach().cpu().numpy(), ro.detach().numpy()) <= 1e-5
     assert max_err(ga.detach().cpu().numpy(), ra.detach().numpy()) <= 1e-6
-    _cmp_grads(gl, cl)
+    _cmp_grads(gl, cl, atol=1e-5)      # R = 1 makes d(logit) = att * (d att - sum att * d att) an exact-zero cancellation: rounding noise of the dot order
 
 
 @pytest.mark.parametrize("case", range(8))
