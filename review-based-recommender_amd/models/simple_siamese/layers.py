@@ -93,11 +93,12 @@ class FMWithoutUIBias(_FM):
 
 
 def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm, u_text_feat, i_text_feat, u_ids, i_ids):
-    """LastFeat(user) + LastFeat(item) + FM / FMWithoutUIBias in one HIP kernel pair."""
+    """LastFeat(user) + LastFeat(item) + FM / FMWithoutUIBias in one HIP kernel pair.
+    i_text_feat None: u_text_feat holds both towers, [2*bz, F] with the user rows first."""
     if fm.training and fm.dropout.p < 1.0 and torch.is_grad_enabled():
         drop = float(fm.dropout.p)       # training forward: the head kernel draws the mask (and clears its gradient buffer) itself
     else:
-        drop = RF.dropout_multiplier((u_text_feat.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
+        drop = RF.dropout_multiplier((u_ids.shape[0], fm.h.shape[0]), fm.dropout.p, fm.training, u_text_feat.device)
     ub = fm.user_bias.weight if fm.WITH_ID_BIASES else fm._zero_user_bias
     ib = fm.item_bias.weight if fm.WITH_ID_BIASES else fm._zero_item_bias
     return RF.pair_head(u_text_feat, i_text_feat, u_ids, i_ids,

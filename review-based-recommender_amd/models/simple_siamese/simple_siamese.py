@@ -50,8 +50,15 @@ class SimpleSiamese(nn.Module):
         """u_revs / i_revs [bz, rv_num, rv_len] int64, word masks [bz, rv_num, rv_len], review masks [bz, rv_num], ids [bz]
         -> (out_logits [bz], None, None), as the reference returns."""
         bz = u_revs.shape[0]
-        u_rev_feat = self._tower(u_revs, u_rev_word_masks, u_rev_masks)
-        i_rev_feat = self._tower(i_revs, i_rev_word_masks, i_rev_masks)
+        if u_revs.shape == i_revs.shape and u_rev_word_masks.shape == i_rev_word_masks.shape and u_rev_masks.shape == i_rev_masks.shape:
+            # the towers share every layer (simple_siamese.py:58-77: one word_embedding, latent_transform_layer, review_att_layer): both sides go through each kernel as ONE batch of
+            # 2*bz rows, user rows first, and the head takes the stacked features whole
+            u_rev_feat = self._tower(RF.stack_rows(u_revs, i_revs), RF.stack_rows(u_rev_word_masks, i_rev_word_masks),
+                                     RF.stack_rows(u_rev_masks, i_rev_masks))
+            i_rev_feat = None
+        else:
+            u_rev_feat = self._tower(u_revs, u_rev_word_masks, u_rev_masks)
+            i_rev_feat = self._tower(i_revs, i_rev_word_masks, i_rev_masks)
         out_logits = rating_head(self.user_last_feat_layer, self.item_last_feat_layer, self.fm, u_rev_feat, i_rev_feat,
                                  u_ids, i_ids)
         return out_logits.view(bz), None, None

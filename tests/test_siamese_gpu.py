@@ -67,9 +67,10 @@ def test_attention_scores_and_state_dict(golden_dir):
     with torch.no_grad():
         model(*_batch(b)[0])
     h.remove()
-    assert seen[0].shape == (cfg["B"], cfg["R"], 1)
-    assert max_err(seen[0].view(cfg["B"], cfg["R"]).cpu().numpy(), g["u_rev_scores"]) <= 1e-5
-    assert max_err(seen[1].view(cfg["B"], cfg["R"]).cpu().numpy(), g["i_rev_scores"]) <= 1e-5
+    scores = torch.cat(seen, 0)          # one call on the 2*B stacked rows (user rows first), or one call per tower
+    assert scores.shape == (2 * cfg["B"], cfg["R"], 1)
+    assert max_err(scores[:cfg["B"]].view(cfg["B"], cfg["R"]).cpu().numpy(), g["u_rev_scores"]) <= 1e-5
+    assert max_err(scores[cfg["B"]:].view(cfg["B"], cfg["R"]).cpu().numpy(), g["i_rev_scores"]) <= 1e-5
 
 
 def test_standalone_layers_match_oracle():
