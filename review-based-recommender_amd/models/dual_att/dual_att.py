@@ -25,10 +25,12 @@ class DualAtt(nn.Module):
         self.fc = nn.Sequential(nn.Linear(self.fc_input, hidden_size_1), nn.ReLU(), nn.Dropout(dropout),
                                 nn.Linear(hidden_size_1, hidden_size_2))
 
-    def _tower(self, docs, local, glob):
+    def _encode(self, docs, local, glob):
         table = self.word_embeddings.weight
         pad = self.word_embeddings.padding_idx
-        feat = torch.cat((local.encode(table, docs, pad), glob.encode(table, docs, pad)), dim=1)   # [bz, fc_input]
+        return torch.cat((local.encode(table, docs, pad), glob.encode(table, docs, pad)), dim=1)   # [bz, fc_input]
+
+    def _fc(self, feat):
         p = self.fc[2].p
         drop = RF.dropout_multiplier((feat.shape[0], self.fc[0].out_features), p, self.training, feat.device)
         hid = RF.linear(feat, self.fc[0].weight, self.fc[0].bias, relu=True, drop=drop)
@@ -36,7 +38,11 @@ class DualAtt(nn.Module):
 
     def forward(self, u_docs, i_docs):
         """u_docs / i_docs [bz, doc_len] int64 -> ratings [bz]."""
-        u_feat = self._tower(u_docs, self.u_local_atten, self.u_global_atten)
-        i_feat = self._tower(i_docs, self.i_local_atten, self.i_global_atten)
+        bz = u_docs.shape[0]
+        u_enc = self._encode(u_docs, self.u_local_atten, self.u_global_atten)
+        i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten)
+        # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
+        # backward) as a single 2*bz batch, user rows first
+        u_feat, i_feat = self._fc(torch.cat((u_enc, i_enc), dim=0)).view(2, bz, -1).unbind(0)
         ratings = torch.sum(torch.mul(u_feat, i_feat), 1)
         return ratings.view(-1)
