@@ -104,7 +104,17 @@ __device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigne
             const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
             const int lo = max(0, l0 - P.P), hi = min(P.L, l0 + kTile + P.KF - 1 - P.P);
             act = 0;
-            for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
+            const unsigned char* row = mask + (long)doc * P.L;
+            if (l0 + kTile <= P.L && ((((uintptr_t)(row + l0)) & 15) == 0)) {
+                // the 32 tokens of the slab as two 16-byte loads, the halo bytes beside them: one round of independent loads
+                const uint4 a = *reinterpret_cast<const uint4*>(row + l0), c = *reinterpret_cast<const uint4*>(row + l0 + 16);
+                unsigned halo = 0;
+                for (int p = lo; p < l0; ++p) halo |= row[p];
+                for (int p = l0 + kTile; p < hi; ++p) halo |= row[p];
+                act = (a.x | a.y | a.z | a.w | c.x | c.y | c.z | c.w | halo) != 0;
+            } else {
+                for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
+            }
             act = act ? 1 : 0;
         }
         sched[wt] = act;
