@@ -310,7 +310,21 @@ __global__ __launch_bounds__(256) void global_gate_fwd_kernel(int B, int L, int 
         const float* row = table + ids[(long)b * L + l] * (long)E;
         float s = 0.f;
         if (vec) {      // the thread's own row in 16-byte pieces (a quarter of the cache-line touches); w coalesced across threads
-            for (int e = 0; e < E; e += 4) {
+            int e = 0;
+            for (; e + 16 <= E; e += 16) {      // 4 row quads and their 16 weight scalars requested before the first use
+                f32x4g x[4];
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4g*>(row + e + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = w[(long)(e + u) * L + l];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = fmaf(x[u].x, wv[4 * u], s); s = fmaf(x[u].y, wv[4 * u + 1], s);
+                    s = fmaf(x[u].z, wv[4 * u + 2], s); s = fmaf(x[u].w, wv[4 * u + 3], s);
+                }
+            }
+            for (; e < E; e += 4) {
                 const f32x4g x = *reinterpret_cast<const f32x4g*>(row + e);
                 s = fmaf(x.x, w[(long)e * L + l], s);
                 s = fmaf(x.y, w[(long)(e + 1) * L + l], s);
