@@ -369,6 +369,9 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, i
                                                                  const float* __restrict__ table, const float* __restrict__ dpre,
                                                                  float* __restrict__ dw, float* __restrict__ db0) {
     __shared__ float s_part[256];
+    constexpr int kStage = 2048;                      // documents whose row offsets and dpre are staged per pass
+    __shared__ long s_off[kStage];
+    __shared__ float s_dp[kStage];
     const int l = blockIdx.x, tid = threadIdx.x;
     if (l == L) {
         if (tid == 0) { float s = 0.f; for (int b = 0; b < B; ++b) s += dpre[b]; db0[0] = s; }
@@ -379,18 +382,29 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, i
         const int cls = (E >= 256) ? 0 : tid / E, e = e0 + ((E >= 256) ? tid : tid - cls * E);
         const bool live = cls < ncls && e < E;
         float s = 0.f;
-        if (live) {
-            for (int b0i = cls; b0i < B; b0i += 8 * ncls) {
-                float x[8], dp[8];
+        // the token ids of this position (one per document, a strided column of `ids`) are fetched once per pass into LDS, all
+        // at the same time: the row reads below then depend on nothing but LDS (they were a chain id -> row, 8 at a time)
+        for (int bs = 0; bs < B; bs += kStage) {
+            const int nb = min(kStage, B - bs);
+            __syncthreads();
+            for (int k = tid; k < nb; k += 256) {
+                s_off[k] = ids[(long)(bs + k) * L + l] * (long)E;
+                s_dp[k] = dpre[bs + k];
+            }
+            __syncthreads();
+            if (live) {
+                for (int b0i = cls; b0i < nb; b0i += 8 * ncls) {
+                    float x[8], dp[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int b = b0i + u * ncls;
-                    const bool ok = b < B;
-                    dp[u] = ok ? dpre[b] : 0.f;
-                    x[u] = ok ? table[ids[(long)b * L + l] * (long)E + e] : 0.f;
+                    for (int u = 0; u < 8; ++u) {
+                        const int b = b0i + u * ncls;
+                        const bool ok = b < nb;
+                        dp[u] = ok ? s_dp[b] : 0.f;
+                        x[u] = ok ? table[s_off[b] + e] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s = fmaf(dp[u], x[u], s);
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) s = fmaf(dp[u], x[u], s);
             }
         }
         __syncthreads();
