@@ -38,18 +38,27 @@ __global__ __launch_bounds__(256) void bag_fwd_kernel(int n_rev, int T, int D, c
         const int nq4 = D >> 2;
         for (int q0 = 0; q0 < nq4; q0 += 64) {
             const int q4 = q0 + lane;
+            const bool lane_ok = q4 < nq4;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (q4 < nq4) {
-                for (int l0 = 0; l0 < T; l0 += 4) {          // 4 independent row reads in flight
-                    f32x4 v[4];
+            // the review's token rows: every lane fetches ONE row offset (-1 = masked) of a 64-token stretch, then the rows
+            // are read 8 at a time with the offsets broadcast from the lanes -- the row reads no longer wait for an id load each
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int lt = t0 + lane;
+                long my_off = -1;
+                if (lt < T && (rm == nullptr || rm[lt])) my_off = rid[lt] * (long)D;
+                const int nt = min(64, T - t0);
+                for (int l0 = 0; l0 < nt; l0 += 8) {
+                    f32x4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int l = l0 + u;
-                        const bool ok = l < T && (rm == nullptr || rm[l]);
-                        v[u] = ok ? *reinterpret_cast<const f32x4*>(table + rid[l] * (long)D + 4 * q4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int u = 0; u < 8; ++u) {
+                        const long off = __shfl(my_off, (l0 + u) & 63);      // (lanes past nt hold -1)
+                        v[u] = (lane_ok && l0 + u < nt && off >= 0) ? *reinterpret_cast<const f32x4*>(table + off + 4 * q4)
+                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    acc += (v[0] + v[1]) + (v[2] + v[3]);
+                    acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
+            }
+            if (lane_ok) {
                 f32x4 o = acc * inv;
                 if (drop != nullptr) o = o * *reinterpret_cast<const f32x4*>(drop + (long)r * D + 4 * q4);
                 *reinterpret_cast<f32x4*>(out + (long)r * D + 4 * q4) = o;
