@@ -183,8 +183,7 @@ def gen_datt(name, edge=False, seed=0):
     model.eval()
     with torch.no_grad():
         out["pred_eval"] = _np(model(b["u_docs"], b["i_docs"]))
-    if not big:
-        run_train_steps(model, lambda: model(b["u_docs"], b["i_docs"]), b["ratings"], out, big)
+    run_train_steps(model, lambda: model(b["u_docs"], b["i_docs"]), b["ratings"], out, big)
     return out
 
 

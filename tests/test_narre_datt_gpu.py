@@ -97,16 +97,36 @@ def test_datt_matches_reference(golden_dir, name, cfgname, conv_mode):
             check_params_after(model, g, f"after{step + 1}")
 
 
-def test_datt_cfg4_forward(golden_dir, conv_mode):
-    """BASELINE configs[3]: B=512, 2x1024 tokens, E=100 -- forward against the reference's predictions."""
+def test_datt_cfg4_full_step(golden_dir, conv_mode):
+    """BASELINE configs[3]: B=512, 2x1024 tokens, E=100 -- eval predictions, then the trainer step against the reference's
+    loss, every gradient (gated global convs and both gates included: models/dual_att/layers.py:43-53,81-89), the clipped
+    norm and the parameters after 1 and 3 Adam steps (fixture: tests/golden/make_golden.py:gen_datt, big=True)."""
+    from review_based_recommender_amd.train_step import make_optimizer, train_step
     g = golden(golden_dir, "datt_cfg4")
     cfg = synth.DATT_CFGS["cfg4"]
     model = _datt(cfg, scale=0.3)
     b = synth.datt_batch(cfg, 1)
+    args, ratings = (b["u_docs"].to(DEV), b["i_docs"].to(DEV)), b["ratings"].to(DEV)
     model.eval()
     with torch.no_grad():
-        pred = model(b["u_docs"].to(DEV), b["i_docs"].to(DEV))
+        pred = model(*args)
     assert max_err(pred.cpu().numpy(), g["pred_eval"]) <= FWD_TOL
+
+    model.train()
+    pred = model(*args)
+    assert max_err(pred.detach().cpu().numpy(), g["pred"]) <= FWD_TOL
+    loss = torch.nn.functional.mse_loss(pred, ratings)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * max(1.0, float(g["loss"]))
+    loss.backward()
+    check_grads({k: p.grad for k, p in model.named_parameters()}, g)
+    model.zero_grad()
+    opt = make_optimizer(model)
+    for step in range(3):
+        loss, gnorm, pred = train_step(model, opt, args, ratings)
+        if step == 0:
+            assert abs(float(gnorm) - float(g["gnorm"])) <= 2e-4 * float(g["gnorm"])
+        if step in (0, 2):
+            check_params_after(model, g, f"after{step + 1}")
 
 
 def test_datt_state_dict_keys():
