@@ -84,6 +84,23 @@ int rbr_textcnn_pack(const rbr_textcnn_desc* d, const float* const* W, float* pa
  * rbr_set_conv_mode: 0 auto (default; env RBR_CONV_MODE=dense|product overrides), 1 dense, 2 product. */
 size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d);
 void rbr_set_conv_mode(int32_t mode);
+/* Arithmetic of the product formulation's GEMM (the contraction of MyConv1d.forward, deepconn/layers.py:46-60, as
+ * called from narre.py:175-176), all with f32 accumulation and an f32 product table:
+ *   RBR_PROD_F32    v_mfma_f32_32x32x2_f32 on f32 operands (an f32 fma chain, bit for bit)
+ *   RBR_PROD_BF16X3 default: each f32 operand split exactly into three bf16 planes, 6 plane products per f32
+ *                   product on v_mfma_f32_32x32x16_bf16 (neglected terms < 2^-25 |a b|: f32-class accuracy)
+ *   RBR_PROD_BF16X2 two planes, 3 plane products (~2^-17 relative per product)
+ *   RBR_PROD_BF16   operands rounded to bf16, one MFMA per 16 products: the reduced-precision row of
+ *                   BASELINE configs 3 and 5 (tolerance class of its own, see tests/test_precision_gpu.py)
+ * The word table and the conv weights stay f32 in memory in every mode.  Set once, before the first forward of a step
+ * (the workspace layout depends on it); -1 restores the default (env RBR_PROD_PRECISION=f32|bf16x3|bf16x2|bf16).
+ * D % 4 != 0 always takes the f32 kernel. */
+#define RBR_PROD_F32 0
+#define RBR_PROD_BF16X3 1
+#define RBR_PROD_BF16X2 2
+#define RBR_PROD_BF16 3
+void rbr_set_prod_precision(int32_t mode);
+int32_t rbr_get_prod_precision(void);
 int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                          const float* table, const float* const* W, const float* packed, float* pval, int32_t* pidx,
                          void* ws, void* stream);

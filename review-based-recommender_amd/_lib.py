@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(HERE, "csrc", "librbr_hip.so")
 RBR_MAX_WIDTHS = 8
 PAD_SAME, PAD_VALID = 0, 1
 ACT_RELU, ACT_TANH = 0, 1
+PROD_F32, PROD_BF16X3, PROD_BF16X2, PROD_BF16 = 0, 1, 2, 3     # rbr_set_prod_precision (RBR_PROD_* of rbr_hip.h)
+PROD_PRECISIONS = {"f32": PROD_F32, "bf16x3": PROD_BF16X3, "bf16x2": PROD_BF16X2, "bf16": PROD_BF16}
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p
@@ -64,6 +66,8 @@ SIGNATURES = {
     "rbr_textcnn_pack": (C.c_int, [_DESC, _PP, c_f32p, c_stream]),
     "rbr_textcnn_fwd_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_set_conv_mode": (None, [i32]),
+    "rbr_set_prod_precision": (None, [i32]),
+    "rbr_get_prod_precision": (i32, []),
     "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, _PP, c_f32p, c_f32p, c_i32p, C.c_void_p,
                                        c_stream]),
     "rbr_textcnn_prod_prepare": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p, c_stream]),

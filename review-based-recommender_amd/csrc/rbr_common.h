@@ -79,6 +79,15 @@ int run_token_product(const rbr_textcnn_desc* d, const long long* ids, const uns
                       const float* table, const float* const* W, float* pval, int* pidx, void* ws, hipStream_t st);
 // 0 auto, 1 dense forced, 2 token-product forced (rbr_set_conv_mode / RBR_CONV_MODE)
 int forced_conv_mode();
+// bf16-plane form of the token-product GEMM (textcnn_prod_b16.hip): RBR_PROD_* in force, whether it serves `d`, the
+// bytes of its weight-plane image, the pack launch and the GEMM launch (T pitch must be >= 128 * prod_b16_groups)
+int prod_precision();
+bool prod_b16_applicable(const rbr_textcnn_desc* d);
+int prod_b16_groups(int cp_real);
+size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real);
+int prod_b16_pack(const rbr_textcnn_desc* d, const float* const* W, void* bimg, hipStream_t st);
+int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
+                  const float* table, const void* bimg, float* T, hipStream_t st);
 // Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not
 // hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and stays a chain of
 // plain kernel nodes (memset nodes of these shapes faulted on replay with ROCm 7.2).

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
     const long nb = gridDim.x - nb_compact, b0 = blockIdx.x - nb_compact;
     const ConvPlan& P = J.P;
     const int DC = P.DC;
-    const long n_img = (long)P.nchunks * P.tiles_total * kTile * DC;
+    const long n_img = packed != nullptr ? (long)P.nchunks * P.tiles_total * kTile * DC : 0;     // bf16-plane GEMM: no f32 image
     const long n_wt = (long)J.cp_real * J.D;
     for (long idx = b0 * 256 + threadIdx.x; idx < n_img + n_wt; idx += nb * 256) {
         if (idx < n_img) {
@@ -695,7 +695,7 @@ using namespace rbr;
 namespace {
 
 struct ProdLayout {      // byte offsets inside the workspace
-    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, table_T, total;
+    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, bimg, table_T, total;
     int cap, Cp, tiles_p;
     rbr_textcnn_desc dp;
 };
@@ -726,7 +726,8 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     // zero-weight padding channels make all work-item groups identical: 8 tiles each (750 -> 768 = 3 x 8 tiles at cfg2:
     // 167 row blocks x 3 groups = 501 items for 512 resident workgroups), fewer when the whole bank is smaller
     const int group_tiles = (int)std::min<long>(kProdGroupTiles, (Cp + kTile - 1) / kTile);
-    const int kGroupSlots = group_tiles * kTile;
+    // the bf16-plane GEMM works on items of 128 product channels
+    const int kGroupSlots = prod_b16_applicable(d) ? 128 : group_tiles * kTile;
     Cp = ((Cp + kGroupSlots - 1) / kGroupSlots) * kGroupSlots;
     Lo.Cp = (int)Cp;
     Lo.tiles_p = (int)(Cp / kTile);
@@ -751,6 +752,7 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     long cp_real = 0;
     for (int w = 0; w < d->n_widths; ++w) cp_real += (long)d->kz[w] * d->ch[w];
     Lo.wt = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
+    Lo.bimg = o;         o += prod_b16_applicable(d) ? align256(prod_b16_image_bytes(d, (int)cp_real)) : 0;
     Lo.table_T = o;      o += align256((((size_t)Lo.cap + 1) * p.nslots_total + 4) * sizeof(float));   // + one float4 of slack: quads read whole
     Lo.total = o;
     return true;
@@ -942,12 +944,14 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
     const int nb_compact = (d->V + 255) / 256;
-    const long n_pack = (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC + (long)S.A.cp_real * d->D;
+    const bool b16 = prod_b16_applicable(d);
+    const long n_pack = (b16 ? 0 : (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC) + (long)S.A.cp_real * d->D;
     const int nb_pack = (int)std::min<long>((n_pack + 255) / 256, 2048);
     hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, S.Lo.cap, S.used,
                        S.row_of_token, S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch, wp,
-                       S.packed_p, S.WT);
+                       b16 ? nullptr : S.packed_p, S.WT);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
+    if (b16) return prod_b16_pack(d, W, S.base + S.Lo.bimg, st);      // weight planes in MFMA-fragment order
     return 0;
 }
 
@@ -956,6 +960,9 @@ extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* ta
     if (!table) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     ProdState S;
     if (int e = prod_state(d, ws, S)) return e;
+    if (prod_b16_applicable(d))
+        return prod_b16_gemm(d, S.A.cp_real, S.Lo.cap, S.A.pitch, S.counter, S.tok_of_row, table, S.base + S.Lo.bimg, S.T,
+                             (hipStream_t)stream);
     return run_conv_groups(S.pp, 1, S.tok_of_row, S.row_mask, nullptr, table, S.packed_p, S.T, nullptr, S.sched_p, (hipStream_t)stream);
 }
 

@@ -1,0 +1,338 @@
+// textcnn_prod_b16.hip -- the distinct-token GEMM  T = table[tok_of_row] @ Wprod  on the bf16 MFMA pipe.
+//
+// gfx950 has no reduced-precision f32 MFMA (no xf32): v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate.  An f32
+// value splits EXACTLY into three bf16 planes (x = hi + mid + lo up to < 2^-25 |x|: round-to-nearest residues, each
+// subtraction exact), so   a*b = a_hi*b_hi + (a_hi*b_mid + a_mid*b_hi) + (a_hi*b_lo + a_lo*b_hi + a_mid*b_mid) + O(2^-26 |a b|)
+// costs 6 v_mfma_f32_32x32x16_bf16 per 16 k (192 cycles) against 8 v_mfma_f32_32x32x2_f32 (512 cycles) for the same
+// products, accumulated in f32: the same error class as the f32 chain (products exact, one f32 rounding per add).
+//   precision 1 = "bf16x3": 6 plane products (f32-class accuracy; the headline)
+//   precision 2 = "bf16x2": 3 plane products (hi*hi, hi*mid, mid*hi: ~2^-17 relative per product)
+//   precision 3 = "bf16"  : 1 plane product  (operands rounded to bf16: the reduced-precision row of BASELINE configs 3/5)
+// The table stays f32 in HBM (Adam's master copy); rows are gathered by LDS-DMA and split in registers by the wave that
+// owns them, the weight planes are split once per step by the pack stage and stored in MFMA-fragment order.
+//
+// Work item = 128 token rows x 128 product channels (grid: every such pair, XCD-aware order).  4 waves, wave w owns the
+// 32-row tile w and 4 channel tiles (64 accumulator registers); two workgroups per CU.  K is walked in 16-deep MFMA steps
+// through a 4-stage LDS ring filled three steps ahead:
+// A stage [128 rows][4 x 16 B] (row segments XOR-swizzled so the 8-float fragment reads are conflict-free), B stage
+// [4 tiles][3 planes][64 lanes x 16 B] (fragment order: a straight copy).  One barrier per step.
+// Measured at cfg2 (21 344 rows x 300 x 768, 1002 items): 64 us (bf16x3) / 47 (bf16x2) / 39 (bf16) against 104 us for the
+// f32 MFMA kernel.  What bounds it is the CU's LDS-fill path, not the MFMA pipe and not L2: a stage is 20 one-KiB LDS-DMA
+// instructions per workgroup for 4 x 24 MFMAs, and a CU retires ~1 KiB per 35 cycles whatever the source (with every fill
+// reading one cached 16-byte line and no stores the bf16 kernel still takes 24 us = 381 k instructions / 256 CUs x 35
+// cycles).  The way below that is weights stationary in registers (one 32-column tile x all K per wave = 228 VGPRs at
+// D = 300) so that only token rows move: DESIGN.md section 8.
+#include "rbr_common.h"
+
+#include <cstdlib>
+
+namespace rbr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kB16Waves = 4, kB16Stages = 4;
+constexpr int kB16BM = 32 * kB16Waves, kB16BN = 128, kB16KC = 16, kB16Threads = 64 * kB16Waves;
+constexpr int kB16ABytes = kB16BM * kB16KC * 4;                 // 8 KiB
+constexpr int kB16BFrag = 1024;                                 // one (tile, plane) fragment: 64 lanes x 16 B
+constexpr int kB16BBytes = (kB16BN / 32) * 3 * kB16BFrag;       // 12 KiB
+constexpr int kB16Lds = kB16Stages * (kB16ABytes + kB16BBytes); // 80 KiB: two workgroups per CU
+static_assert(kB16Waves == 4 && kB16Stages == 4, "the fill schedule below (5 LDS-DMA instructions per wave and stage) assumes 4 x 4");
+
+__device__ float g_b16_zero[4];      // LDS-DMA source of rows / columns outside the problem (zero-initialised, never written)
+
+struct B16Gemm {
+    const int* counter;              // rows of the token list (device)
+    const long long* tok_of_row;
+    const float* table;
+    const unsigned char* bimg;       // [group][chunk][tile][step][plane][lane][8 bf16]
+    float* T;
+    int cap, D, pitch, ngroups, nchunks;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);       // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// (x0, x1) -> packed bf16 pairs of the three planes; the residues x - hi and (x - hi) - mid are exact in f32
+template <int NPLANES>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pack_bf16(x0, x1);
+    if (NPLANES >= 2) {
+        const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+        mid = pack_bf16(r0, r1);
+        if (NPLANES >= 3) {
+            const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+            lo = pack_bf16(s0, s1);
+        }
+    }
+}
+
+__device__ __forceinline__ void b16_dma16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// NPROD plane products per f32 product: 6 (bf16x3), 3 (bf16x2), 1 (bf16)
+template <int NPROD>
+__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16Gemm g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int NPLANES = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    const int n = min(*g.counter, g.cap);
+    // blocks b and b + 8 share an XCD (round-robin dispatch): the ngroups items of a row block sit on ONE XCD, so its rows
+    // are fetched into that L2 once; speed only
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int mblock = (jj / g.ngroups) * 8 + xcd, ng = jj - (jj / g.ngroups) * g.ngroups;
+    const int m0 = mblock * kB16BM;
+    if (m0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = g.D;
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + kB16Stages * kB16ABytes;
+
+    // gather role: instruction q of this wave moves rows wave*32 + q*16 .. +15, lane = (row in 16, 16-byte position)
+    long aoff[2];
+    int aseg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rl = wave * 32 + q * 16 + (lane >> 2);
+        const int row = m0 + rl;
+        aoff[q] = (row < n) ? g.tok_of_row[row] * (long)D : -1;
+        aseg[q] = ((lane & 3) ^ ((rl >> 2) & 3)) * 4;          // position p of the row holds segment p ^ swz(row)
+    }
+    // weight fragments of a stage: 12 x 1 KiB, three per wave.  Every wave issues 5 LDS-DMA instructions per stage, also
+    // past the last stage (source clamped, slot unused), so the counted waits below hold in every step
+    const unsigned char* bsrc = g.bimg + ((size_t)ng * g.nchunks) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
+    const int nch = g.nchunks;
+    auto issue_a = [&](int c) {
+        const int buf = c & (kB16Stages - 1), cs = min(c, nch - 1);
+        unsigned char* A = Abuf + buf * kB16ABytes + wave * 32 * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = cs * kB16KC + aseg[q];
+            const float* src = (aoff[q] >= 0 && col < D) ? g.table + aoff[q] + col : g_b16_zero;
+            b16_dma16(src, A + q * 16 * 64);
+        }
+    };
+    auto issue_b = [&](int c) {
+        const int buf = c & (kB16Stages - 1), cs = min(c, nch - 1);
+        unsigned char* B = Bbuf + buf * kB16BBytes + wave * 3 * kB16BFrag;
+        const unsigned char* s = bsrc + (size_t)cs * kB16BBytes;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b16_dma16(s + t * kB16BFrag, B + t * kB16BFrag);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int r32 = lane & 31, h = lane >> 5;
+    const int swz = (r32 >> 2) & 3;
+    const int arow = (wave * 32 + r32) * 64;
+    const int seg0 = ((2 * h) ^ swz) * 16, seg1 = ((2 * h + 1) ^ swz) * 16;
+
+    bf16x8 a_hi, a_mid, a_lo;
+    auto split_rows = [&](const f32x4 x0, const f32x4 x1) {      // this lane's 8 floats of a step -> bf16 planes
+        unsigned h4[4], m4[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0};
+        split_pair<NPLANES>(x0.x, x0.y, h4[0], m4[0], l4[0]);
+        split_pair<NPLANES>(x0.z, x0.w, h4[1], m4[1], l4[1]);
+        split_pair<NPLANES>(x1.x, x1.y, h4[2], m4[2], l4[2]);
+        split_pair<NPLANES>(x1.z, x1.w, h4[3], m4[3], l4[3]);
+        const u32x4 ah = {h4[0], h4[1], h4[2], h4[3]}, am = {m4[0], m4[1], m4[2], m4[3]}, al = {l4[0], l4[1], l4[2], l4[3]};
+        a_hi = __builtin_bit_cast(bf16x8, ah);
+        a_mid = a_lo = a_hi;
+        if (NPLANES >= 2) a_mid = __builtin_bit_cast(bf16x8, am);
+        if (NPLANES >= 3) a_lo = __builtin_bit_cast(bf16x8, al);
+    };
+    auto mma_tile = [&](const unsigned char* B, int t) {
+        const unsigned char* bf = B + (t * 3) * kB16BFrag;
+        const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(bf);
+        if (NPROD == 6) {       // small terms first
+            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+            const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(bf + 2 * kB16BFrag);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc[t], 0, 0, 0);
+        } else if (NPROD == 3) {
+            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+    };
+
+    // Software pipeline: the fills run three stages ahead; the wave's own token rows of stage c + 1 are read and split
+    // between the MFMAs of stage c (a wave gathers exactly the rows of its own tile: no barrier on that path), and the
+    // fill instructions of stage c + 3 are issued between the MFMA groups too -- in front of the chain they cost the wave
+    // ~100 cycles each with the matrix pipe idle.
+    for (int c = 0; c < 3; ++c) { issue_a(c); issue_b(c); }
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            // stage 0 (this wave's share)
+    {
+        const unsigned char* A = Abuf + arow;
+        split_rows(*reinterpret_cast<const f32x4*>(A + seg0), *reinterpret_cast<const f32x4*>(A + seg1));
+    }
+    for (int c = 0; c < nch; ++c) {
+        // stage c has landed once at most the two younger stages' fills (5 instructions each) are outstanding
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        // a bare s_barrier: __syncthreads() would add a fence that drains the fills meant to stay in flight
+        __builtin_amdgcn_s_barrier();         // weights of stage c landed for every wave; every wave is done with stage c - 1
+        asm volatile("" ::: "memory");
+        const unsigned char* B = Bbuf + (c & (kB16Stages - 1)) * kB16BBytes + lane * 16;
+        const unsigned char* An = Abuf + ((c + 1) & (kB16Stages - 1)) * kB16ABytes + arow;
+        mma_tile(B, 0);
+        issue_a(c + 3);                       // into the slot of stage c - 1
+        mma_tile(B, 1);
+        issue_b(c + 3);
+        mma_tile(B, 2);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // this wave's rows of stage c + 1
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(An + seg0), x1 = *reinterpret_cast<const f32x4*>(An + seg1);
+        mma_tile(B, 3);
+        split_rows(x0, x1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the surplus fills have drained before the LDS is released
+    // C/D map of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): one store
+    // instruction writes two whole 128-byte lines
+    float* out = g.T + (size_t)(m0 + wave * 32 + 4 * h) * g.pitch + ng * kB16BN + r32;
+    const int rows_left = n - (m0 + wave * 32 + 4 * h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (dr < rows_left) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) out[(size_t)dr * g.pitch + t * 32] = acc[t][r];
+        }
+    }
+}
+
+// Weight planes of the token-product GEMM in fragment order (see the header); element (lane l, j) of fragment
+// (group, step, tile, plane) is plane(Wprod[k = step*16 + 8*(l >> 5) + j][column = group*128 + tile*32 + (l & 31)]).
+struct B16Pack {
+    int n_widths, D, cp_real, ngroups, nchunks;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
+};
+
+__device__ __forceinline__ float b16_prod_weight(const B16Pack& J, const PtrArray& W, int pc, int d) {
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < J.n_widths && pc >= J.poff[k]) w = k;
+    const int rel = pc - J.poff[w];
+    const int j = rel / J.ch[w], cl = rel - j * J.ch[w];
+    return W.p[w][((long)cl * J.D + d) * J.kz[w] + j];
+}
+
+__global__ __launch_bounds__(256) void b16_pack_kernel(const B16Pack J, const PtrArray W, unsigned char* __restrict__ bimg) {
+    const long total = (long)J.ngroups * J.nchunks * 4 * 64;           // one thread per (fragment triple, lane)
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        long r = idx;
+        const int l = (int)(r & 63); r >>= 6;
+        const int t = (int)(r & 3); r >>= 2;
+        const int c = (int)(r % J.nchunks);
+        const int ng = (int)(r / J.nchunks);
+        const int col = ng * kB16BN + t * 32 + (l & 31);
+        const int k0 = c * kB16KC + 8 * (l >> 5);
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = k0 + 2 * q + e;
+                x[e] = (col < J.cp_real && k < J.D) ? b16_prod_weight(J, W, col, k) : 0.f;
+            }
+            unsigned a, b, cc;
+            split_pair<3>(x[0], x[1], a, b, cc);
+            ph[q] = a; pm[q] = b; pl[q] = cc;
+        }
+        unsigned char* dst = bimg + (((size_t)ng * J.nchunks + c) * 4 + t) * 3 * kB16BFrag + l * 16;
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        *reinterpret_cast<u32x4*>(dst + kB16BFrag) = pm;
+        *reinterpret_cast<u32x4*>(dst + 2 * kB16BFrag) = pl;
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+static int g_prod_precision = -1;        // -1: RBR_PROD_PRECISION env or the default (bf16x3)
+
+int prod_precision() {
+    if (g_prod_precision >= 0) return g_prod_precision;
+    static const char* env = getenv("RBR_PROD_PRECISION");
+    if (env) {
+        if (!strcmp(env, "f32")) return RBR_PROD_F32;
+        if (!strcmp(env, "bf16x3")) return RBR_PROD_BF16X3;
+        if (!strcmp(env, "bf16x2")) return RBR_PROD_BF16X2;
+        if (!strcmp(env, "bf16")) return RBR_PROD_BF16;
+    }
+    return RBR_PROD_BF16X3;
+}
+
+bool prod_b16_applicable(const rbr_textcnn_desc* d) { return prod_precision() != RBR_PROD_F32 && d->D % 4 == 0; }
+
+int prod_b16_groups(int cp_real) { return (cp_real + kB16BN - 1) / kB16BN; }
+size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real) {
+    return (size_t)prod_b16_groups(cp_real) * ((d->D + kB16KC - 1) / kB16KC) * kB16BBytes;
+}
+
+int prod_b16_pack(const rbr_textcnn_desc* d, const float* const* W, void* bimg, hipStream_t st) {
+    B16Pack J{};
+    J.n_widths = d->n_widths; J.D = d->D;
+    int o = 0;
+    for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = o; o += d->kz[w] * d->ch[w]; }
+    J.cp_real = o;
+    J.ngroups = prod_b16_groups(o);
+    J.nchunks = (d->D + kB16KC - 1) / kB16KC;
+    PtrArray wp{};
+    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
+    const long total = (long)J.ngroups * J.nchunks * 4 * 64;
+    hipLaunchKernelGGL(b16_pack_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, J, wp,
+                       static_cast<unsigned char*>(bimg));
+    RBR_CHECK_LAUNCH("textcnn b16 pack launch");
+    return 0;
+}
+
+int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
+                  const float* table, const void* bimg, float* T, hipStream_t st) {
+    if (((uintptr_t)table & 15) != 0) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
+    B16Gemm g{};
+    g.counter = counter; g.tok_of_row = tok_of_row; g.table = table; g.bimg = static_cast<const unsigned char*>(bimg); g.T = T;
+    g.cap = cap; g.D = d->D; g.pitch = pitch; g.ngroups = prod_b16_groups(cp_real); g.nchunks = (d->D + kB16KC - 1) / kB16KC;
+    if (pitch < g.ngroups * kB16BN) { set_error("product table pitch %d < %d", pitch, g.ngroups * kB16BN); return RBR_ERR_BAD_ARG; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        // dynamic LDS is declared to the runtime (needed above 64 KiB; harmless below)
+        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<6>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<6> LDS")) return e;
+        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<3>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<3> LDS")) return e;
+        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<1> LDS")) return e;
+        attr_set = true;
+    }
+    const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;           // whole XCD rounds
+    const dim3 grid((unsigned)(mblocks * g.ngroups)), block(kB16Threads);
+    switch (prod_precision()) {
+        case RBR_PROD_BF16X3: hipLaunchKernelGGL(prod_gemm_b16_kernel<6>, grid, block, kB16Lds, st, g); break;
+        case RBR_PROD_BF16X2: hipLaunchKernelGGL(prod_gemm_b16_kernel<3>, grid, block, kB16Lds, st, g); break;
+        case RBR_PROD_BF16: hipLaunchKernelGGL(prod_gemm_b16_kernel<1>, grid, block, kB16Lds, st, g); break;
+        default: set_error("prod_b16_gemm called in f32 mode"); return RBR_ERR_BAD_ARG;
+    }
+    RBR_CHECK_LAUNCH("textcnn prod_gemm_b16 launch");
+    return 0;
+}
+
+}  // namespace rbr
+
+extern "C" void rbr_set_prod_precision(int32_t mode) {
+    rbr::g_prod_precision = (mode >= RBR_PROD_F32 && mode <= RBR_PROD_BF16) ? mode : -1;
+}
+extern "C" int32_t rbr_get_prod_precision(void) { return rbr::prod_precision(); }

@@ -30,6 +30,21 @@ def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _TAP_SINK = None
 
 
+def set_prod_precision(name: Optional[str]) -> None:
+    """Arithmetic of the token-product conv's GEMM (rbr_set_prod_precision): "f32" (f32 MFMA, an fma chain bit for bit),
+    "bf16x3" (default: exact three-plane bf16 split, 6 plane products, f32 accumulation: f32-class accuracy), "bf16x2",
+    "bf16" (operands rounded to bf16: the reduced-precision row of BASELINE configs 3 and 5); None restores the default.
+    Set it between steps, never between a forward and its backward (the workspace layout depends on it)."""
+    if name is not None and name not in _lib.PROD_PRECISIONS:
+        raise ValueError(f"unknown product precision {name!r}; one of {sorted(_lib.PROD_PRECISIONS)}")
+    _lib.lib().rbr_set_prod_precision(-1 if name is None else _lib.PROD_PRECISIONS[name])
+
+
+def get_prod_precision() -> str:
+    mode = _lib.lib().rbr_get_prod_precision()
+    return {v: k for k, v in _lib.PROD_PRECISIONS.items()}[mode]
+
+
 def set_tap_sink(sink) -> None:
     global _TAP_SINK
     _TAP_SINK = sink

@@ -1,0 +1,142 @@
+"""The arithmetic classes of the token-product conv GEMM (rbr_set_prod_precision, csrc/textcnn_prod_b16.hip) against the
+reference-generated fixtures.  The contraction is MyConv1d.forward (reference models/deepconn/layers.py:46-60, called
+from narre.py:175-176); every class accumulates in f32 and keeps the word table and the conv weights f32 in memory.
+
+Tolerance classes (stated here, used below):
+  f32, bf16x3 : the north-star bar -- predictions and loss within 1e-4, gradients within 2e-4 relative (helpers.check_grads).
+                bf16x3 (three exact bf16 planes per operand, 6 plane products) is the default every other GPU test runs.
+  bf16x2      : two planes, 3 plane products, ~2^-17 relative per product: predictions 1e-4, gradients 1e-3 relative.
+  bf16        : operands rounded to bf16 (2^-9 relative): predictions within 3e-2 of the f32 reference, loss within
+                2e-2 relative, gradient norms within 5e-2 relative.  This is the reduced-precision row BASELINE configs
+                3 ("NARRE ... bf16") and 5 ("DeepCoNN ... bf16") name; its backward runs in f32 on the forward's argmax.
+"""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import check_grads, golden, max_err, quiet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def precision(request):
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd import functional as RF
+    _lib.lib().rbr_set_conv_mode(2)           # token-product formulation whatever the shape
+    RF.set_prod_precision(request.param)
+    yield request.param
+    RF.set_prod_precision(None)
+    _lib.lib().rbr_set_conv_mode(0)
+
+
+def _deepconn(cfg):
+    from review_based_recommender_amd.models.deepconn.deepconn import DeepCoNNpp
+    m = quiet(DeepCoNNpp, cfg["U"], cfg["I"], cfg["V"], cfg["kz"], cfg["D"], cfg["H"], cfg["K"], cfg["L"], None, 0.0)
+    m.load_state_dict(synth.deepconn_params(cfg, 0))
+    return m.to(DEV)
+
+
+def _deepconn_batch(cfg, edge):
+    b = synth.deepconn_batch(cfg, 1, edge_cases=edge)
+    return tuple(b[k].to(DEV) for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids")), b["ratings"].to(DEV)
+
+
+def _grad_norm_errs(model, g):
+    out = {}
+    for k, p in model.named_parameters():
+        ref = float(g[f"gradl2/{k}"])
+        if ref > 1e-6:
+            out[k] = abs(float(p.grad.double().norm()) - ref) / ref
+    return out
+
+
+def test_default_is_the_exact_split():
+    from review_based_recommender_amd import functional as RF
+    RF.set_prod_precision(None)
+    assert RF.get_prod_precision() == "bf16x3"
+    with pytest.raises(ValueError):
+        RF.set_prod_precision("fp8")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"], indirect=True)
+@pytest.mark.parametrize("name,cfgname,edge", [("deepconn_small", "small", True), ("deepconn_cfg1", "cfg1", False),
+                                               ("deepconn_cfg2", "cfg2", False)])
+def test_f32_class_meets_the_north_star_bar(golden_dir, precision, name, cfgname, edge):
+    g = golden(golden_dir, name)
+    cfg = synth.DEEPCONN_CFGS[cfgname]
+    model = _deepconn(cfg)
+    args, ratings = _deepconn_batch(cfg, edge)
+    model.eval()
+    with torch.no_grad():
+        pred = model(*args)
+        feats = model.ngram.encode(model.word_embeddings.weight, torch.cat([args[0], args[1]]), torch.cat([args[2], args[3]]))
+    assert max_err(pred.cpu().numpy(), g["pred_eval"]) <= 1e-4
+    ref = np.concatenate([g["u_rev_feats"], g["i_rev_feats"]])
+    assert max_err(feats.cpu().numpy(), ref) <= 2e-5           # TextCNN features themselves
+    model.train()
+    loss = torch.nn.functional.mse_loss(model(*args), ratings)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4
+    loss.backward()
+    check_grads({k: p.grad for k, p in model.named_parameters()}, g)
+
+
+@pytest.mark.parametrize("precision", ["bf16x2"], indirect=True)
+def test_bf16x2_class(golden_dir, precision):
+    g = golden(golden_dir, "deepconn_cfg2")
+    cfg = synth.DEEPCONN_CFGS["cfg2"]
+    model = _deepconn(cfg)
+    args, ratings = _deepconn_batch(cfg, False)
+    model.eval()
+    with torch.no_grad():
+        assert max_err(model(*args).cpu().numpy(), g["pred_eval"]) <= 1e-4
+    model.train()
+    loss = torch.nn.functional.mse_loss(model(*args), ratings)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4
+    loss.backward()
+    check_grads({k: p.grad for k, p in model.named_parameters()}, g, rtol=1e-3)
+
+
+@pytest.mark.parametrize("precision", ["bf16"], indirect=True)
+def test_bf16_class_deepconn_cfg2(golden_dir, precision):
+    """BASELINE configs[4]'s per-GPU shard (cfg2 shape) in the bf16 class."""
+    g = golden(golden_dir, "deepconn_cfg2")
+    cfg = synth.DEEPCONN_CFGS["cfg2"]
+    model = _deepconn(cfg)
+    args, ratings = _deepconn_batch(cfg, False)
+    model.eval()
+    with torch.no_grad():
+        err = max_err(model(*args).cpu().numpy(), g["pred_eval"])
+    assert 1e-6 < err <= 3e-2, err                # really reduced precision, and inside its class
+    model.train()
+    loss = torch.nn.functional.mse_loss(model(*args), ratings)
+    assert abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    loss.backward()
+    errs = _grad_norm_errs(model, g)
+    assert max(errs.values()) <= 5e-2, errs
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"], indirect=True)
+def test_narre_cfg3_precision_classes(golden_dir, precision):
+    """BASELINE configs[2] (NARRE, 10 reviews x 50 tokens per side): bf16 class and the default class."""
+    from review_based_recommender_amd.models.narre.narre import NARRE
+    g = golden(golden_dir, "narre_cfg3")
+    c = synth.NARRE_CFGS["cfg3"]
+    m = quiet(NARRE, c["U"], c["I"], c["V"], c["kz"], c["H"], c["D"], c["A"], c["K"], c["R"], c["T"], 0.0, 0, 0, 0, None, "CNN")
+    m.load_state_dict(synth.narre_params(c, 0))
+    m.to(DEV)
+    b = synth.narre_batch(c, 1)
+    args = tuple(b[k].to(DEV) for k in ("u_text", "i_text", "u_masks", "i_masks", "u_id", "i_id", "reuid", "reiid"))
+    m.eval()
+    with torch.no_grad():
+        pred, ua, _ = m(*args)
+    tol_pred, tol_att, tol_g = (3e-2, 2e-3, 5e-2) if precision == "bf16" else (1e-4, 1e-5, 2e-4)
+    assert max_err(pred.cpu().numpy(), g["pred_eval"]) <= tol_pred
+    assert max_err(ua.cpu().numpy(), g["u_att"]) <= tol_att
+    m.train()
+    loss = torch.nn.functional.mse_loss(m(*args)[0], b["ratings"].to(DEV))
+    loss.backward()
+    errs = _grad_norm_errs(m, g)
+    assert max(errs.values()) <= tol_g, errs
