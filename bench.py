@@ -2,32 +2,42 @@
 """bench.py -- (user,item) pairs/s of the DeepCoNN review-encoder train step on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment, bench.py starts its own ranks BEFORE touching the GPU: a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(the same command a launcher would use; under such a launcher bench.py simply runs as one rank), relays rank 0's JSON
+line and exits with the child's code.
 
 Workload = BASELINE.json configs[1] ("cfg2"): DeepCoNN, batch 256 pairs per GPU, 2 x 512-token
 documents per pair, 300-d embeddings, conv widths 3/5/7 x 50 channels, latent 32, V = 50 002,
 fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the reference trainer's step
 (trainer/train_deepconn_pp.py:161-168): zero_grad -> forward -> MSELoss -> backward ->
-[N>1: RCCL gradient all-reduce] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
+[N>1: RCCL gradient exchange] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
 HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
 
-The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed on the batch resident in the
-graph's input buffers.  `--no-graph` launches the kernels one by one from Python instead.
+Timing.  The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed.  Every step takes
+the next of --batches (default 4) DISTINCT resident batches: one device-to-device copy into the graph's input block,
+inside the timed region (what a loader's hand-over costs).  A timed block is EXACTLY --steps steps between
+barrier + synchronize on both sides, max over ranks; the block is repeated until >= 0.5 s of timed region and
+`ms_per_step` / `value` are the MEDIAN block (`ms_per_step_min`, `repeats` beside them).  Secondary results, same step:
+`single_batch_replay` (one batch resident in the input block, no copy: round 1's number), `uniform_ids` (token ids
+uniform over the vocabulary) and `all_distinct` (every vocabulary entry occurs: distinct tokens = min(V, positions)),
+each with its distinct-token count -- the token-product conv's cost follows that count.
 
-Rank 0 prints ONE JSON line.  `value` = pairs/s over all ranks of the full train step;
-`roofline` prices the longest kernel of the step -- by default the distinct-token GEMM of the token-product
-conv (csrc/textcnn_prod.hip) on the f32 MFMA pipe; with RBR_CONV_MODE=dense the fused gather+conv+max-pool
-kernel -- with HIP events recorded around its launches on the launch stream.  Events cannot be read inside a
-replayed graph, so the event pass re-runs the same K steps eagerly right after the timed region (with
---no-graph the events sit in the timed region itself).  `cpu_baseline` times the CPU oracle
-(oracle/ref_cpu.py, torch CPU ops) on the same workload on this host's cores.
+Rank 0 prints ONE JSON line.  `roofline` prices the longest kernel of the step, measured live with HIP events around
+its C-ABI launches (events cannot be read inside a replayed graph: the same K steps are launched eagerly right after the
+timed region for them); `roofline_gemm` prices the distinct-token GEMM of the conv (the kernel round 1 priced) on the
+MFMA pipe it runs on.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py, torch CPU ops) on the same workload on
+this host's cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -41,6 +51,9 @@ import synth  # noqa: E402
 
 WORKLOAD = "cfg2"
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0 # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBPS = 8000.0         # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured with a float4 copy)
+MIN_TIMED_S = 0.5
 
 
 def conv_fwd_flops(cfg) -> float:
@@ -87,8 +100,22 @@ def build_model(cfg, device):
     return m.to(device)
 
 
-def batch_on(cfg, seed, device):
+def batch_on(cfg, seed, device, ids="zipf"):
+    """A resident batch.  ids: "zipf" (synth.py: the headline), "uniform" (token ids uniform over [2, V)) or
+    "all_distinct" (the unmasked positions walk the whole vocabulary: distinct tokens = min(V - 2, unmasked positions))."""
     b = synth.deepconn_batch(cfg, seed)
+    if ids != "zipf":
+        import numpy as np
+        rng = np.random.default_rng(1000 + seed)
+        for k in ("u_docs", "i_docs"):
+            keep = b[k] != 0
+            n = int(keep.sum())
+            if ids == "uniform":
+                new = rng.integers(2, cfg["V"], size=n)
+            else:
+                new = 2 + (rng.permutation(n) + (0 if k == "u_docs" else n)) % (cfg["V"] - 2)
+            b[k] = b[k].clone()
+            b[k][keep] = torch.from_numpy(new.astype("int64"))
     args = tuple(b[k].to(device) for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids"))
     return args, b["ratings"].to(device)
 
@@ -229,37 +256,111 @@ def verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=Fa
     return note or f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {err})"
 
 
+def time_gemm_launches(model, args, reps=50):
+    """HIP events on the launch stream around `reps` back-to-back launches of the conv's distinct-token GEMM
+    (rbr_textcnn_prod_table) on a workspace prepared for this batch: the queue stays full, so the interval holds kernel
+    time only.  Returns ms per launch."""
+    import ctypes as C
+    from review_based_recommender_amd import _lib
+    L_ = _lib.lib()
+    conv = model.ngram.feature_layer[0]
+    table = model.word_embeddings.weight.detach()
+    ids = torch.cat([args[0], args[1]]).contiguous()
+    mask = torch.cat([args[2], args[3]]).contiguous().view(torch.uint8)
+    ws_ = [w.detach().contiguous() for w in conv.weights()]
+    V, D = table.shape
+    desc = _lib.make_desc(ids.shape[0], ids.shape[1], D, V, [w.shape[2] for w in ws_], [w.shape[0] for w in ws_],
+                          _lib.PAD_SAME, _lib.ACT_RELU, 0)
+    nbytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))
+    if not nbytes:
+        return None
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+    pidx = torch.empty(L_.rbr_textcnn_partial_elems(C.byref(desc)), dtype=torch.int32, device=table.device)
+    st = _lib.current_stream()
+    _lib.check(L_.rbr_textcnn_prod_prepare(C.byref(desc), ids.data_ptr(), mask.data_ptr(), _lib.ptr_array(ws_, torch.float32, "W"),
+                                           pidx.data_ptr(), ws.data_ptr(), st), "prod_prepare")
+    for _ in range(3):
+        _lib.check(L_.rbr_textcnn_prod_table(C.byref(desc), table.data_ptr(), ws.data_ptr(), st), "prod_table")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(L_.rbr_textcnn_prod_table(C.byref(desc), table.data_ptr(), ws.data_ptr(), st), "prod_table")
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def time_optimizer_launches(opt, reps=50):
+    """The same for rbr_clip_adam_step (its two kernels: gradient norm, clip + Adam) on the gradients the last backward
+    left in place.  The parameters keep moving: run it after everything else.  Returns ms per call."""
+    for _ in range(3):
+        opt.clip_and_step(5.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        opt.clip_and_step(5.0)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def dense_mode_env() -> bool:
+    return os.environ.get("RBR_CONV_MODE") == "dense"
+
+
+def self_launch(a) -> int:
+    """--gpus N > 1 from a plain invocation: start the N ranks as a child torch.distributed.run (this process has
+    not touched the GPU, and never does), relay its output and return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["RBR_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches rotated through the step's input block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the single-batch / uniform-id / all-distinct secondary results")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16x2", "bf16"], default=None,
+                    help="arithmetic of the token-product GEMM (default bf16x3: exact three-plane split, f32-class accuracy)")
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
     ap.add_argument("--exchange", choices=["auto", "taps", "dense"], default="auto",
-                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank: 0.16 / 0.23 / "
-                         "0.37 ms at 2 / 4 / 8 ranks) or all-reduce the dense 60 MB gradient; auto times both on the job's own "
-                         "ranks at start-up and keeps the faster one")
+                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank) or all-reduce "
+                         "the dense 60 MB gradient; auto times both on the job's own ranks at start-up and keeps the faster one")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))          # nothing above this line has initialised HIP
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     from review_based_recommender_amd import _lib
+    from review_based_recommender_amd import functional as RF
     from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
     _lib.lib()   # fail loudly now if librbr_hip.so is missing
+    if a.precision is not None:
+        RF.set_prod_precision(a.precision)
+    precision = RF.get_prod_precision()
 
     # rehearsal aids for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
     if os.environ.get("RBR_BENCH_SINGLE_DEVICE") == "1":
@@ -271,6 +372,7 @@ def main():
 
     grad_sync = None
     exchange_note = None
+    dist = None
     if world > 1:
         import torch.distributed as dist
         from review_based_recommender_amd.distributed import GradAllReduce, init_process_group_from_env
@@ -280,7 +382,10 @@ def main():
     model.train()
     use_graph = not a.no_graph
     opt = make_optimizer(model, capturable=use_graph, hip_clip_adam=not a.torch_optim)
-    args, ratings = batch_on(cfg, 1 + rank, device)   # each rank owns a different shard
+    nb = max(1, a.batches)
+    seeds = [1 + rank * 64 + j for j in range(nb)]      # each rank owns different shards
+    batches = [batch_on(cfg, sd, device) for sd in seeds]
+    args, ratings = batches[0]
     if world > 1:
         use_taps = a.comm_dtype == "fp32" and a.exchange in ("taps", "auto")
         grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None,
@@ -293,7 +398,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     launch_note = None
+    stepper = None
     if use_graph:
         try:
             stepper = GraphedTrainStep(model, opt, args, ratings, grad_sync=grad_sync)
@@ -301,31 +414,75 @@ def main():
             use_graph = False
             launch_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches"
             torch.cuda.synchronize()
-    if use_graph:
-        def step():
-            stepper()      # the batch is resident in the graph's input buffers (where a loader's H2D copy lands)
-    else:
-        def step():
-            train_step(model, opt, args, ratings, grad_sync=grad_sync)
 
-    for _ in range(a.warmup):
-        step()
+    def make_runner(bs):
+        """step(i) over the resident batches `bs`: len(bs) == 1 replays the batch already in the input block."""
+        if use_graph:
+            if len(bs) == 1:
+                stepper(*bs[0])               # resident from here on
+                return lambda i: stepper()
+            blobs = [stepper.pack(*b) for b in bs]
+            return lambda i: stepper(packed=blobs[i % len(blobs)])
+        return lambda i: train_step(model, opt, bs[i % len(bs)][0], bs[i % len(bs)][1], grad_sync=grad_sync)
+
+    def timed_blocks(step, min_s=MIN_TIMED_S, max_repeats=400):
+        """Blocks of exactly a.steps steps, barrier + synchronize on both sides, max over ranks; repeated until the timed
+        region adds up to min_s.  Returns the per-block seconds."""
+        for i in range(a.warmup):
+            step(i)
+        out = []
+        k = 0
+        target = None
+        while True:
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(k + i)
+            barrier()
+            out.append(max_over_ranks(time.perf_counter() - t0))
+            k += a.steps
+            if target is None:      # the same count on every rank: derived from the all-reduced first block
+                target = min(max_repeats, max(3, int(min_s / max(out[0], 1e-6)) + 1))
+            if len(out) >= target:
+                return out
+
+    headline = timed_blocks(make_runner(batches))
+    med, best = statistics.median(headline), min(headline)
+
+    variants = {}
+    if not a.no_variants:
+        one = timed_blocks(make_runner(batches[:1]), min_s=0.25)
+        variants["single_batch_replay"] = {"ms_per_step": round(1e3 * statistics.median(one) / a.steps, 4),
+                                           "ms_per_step_min": round(1e3 * min(one) / a.steps, 4), "repeats": len(one),
+                                           "note": "one batch resident in the step's input block, no per-step copy (round 1's line)"}
+        for kind in ("uniform_ids", "all_distinct"):
+            vb = [batch_on(cfg, sd, device, ids=kind.replace("_ids", "")) for sd in seeds]
+            blk = timed_blocks(make_runner(vb), min_s=0.25)
+            ids_all = torch.cat([vb[0][0][0], vb[0][0][1]])
+            msk = torch.cat([vb[0][0][2], vb[0][0][3]])
+            variants[kind] = {"ms_per_step": round(1e3 * statistics.median(blk) / a.steps, 4),
+                              "pairs_per_s": round(cfg["B"] * world * a.steps / statistics.median(blk), 1),
+                              "repeats": len(blk), "distinct_tokens": int(torch.unique(ids_all[msk]).numel()),
+                              "positions": int(msk.numel())}
+            del vb
+
+    # HIP-event pass over the same K steps of the headline batches, launched eagerly
+    run_eager = lambda i: train_step(model, opt, batches[i % nb][0], batches[i % nb][1], grad_sync=grad_sync)
+    for i in range(3):
+        run_eager(i)
     barrier()
-    if not use_graph:
-        _lib.TIMER.start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    _lib.TIMER.start()
+    for i in range(a.steps):
+        run_eager(i)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if use_graph:
-        # HIP-event pass over the same K steps, launched eagerly (events cannot be read inside a replayed graph)
-        _lib.TIMER.start()
-        for _ in range(a.steps):
-            train_step(model, opt, args, ratings, grad_sync=grad_sync)
-        barrier()
     _lib.TIMER.stop()
     ksum = _lib.TIMER.summary()
+
+    gemm_ms = opt_ms = None
+    if rank == 0 and not dense_mode_env():
+        gemm_ms = time_gemm_launches(model, args)
+        if not a.torch_optim:
+            opt_ms = time_optimizer_launches(opt)
 
     # forward-only (eval) rate, reported beside the headline
     model.eval()
@@ -339,33 +496,37 @@ def main():
         torch.cuda.synchronize()
         fwd_s = (time.perf_counter() - f0) / 20
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     if rank == 0:
-        pairs = cfg["B"] * a.steps * world
         flops = conv_fwd_flops(cfg)
         masks = torch.cat([args[2], args[3]])
         dense_mode = "textcnn_conv_fwd" in ksum
         out = {
             "metric": "(user,item) pairs/sec, DeepCoNN train step (fwd+MSE+bwd+clip+Adam), bsz256 2x512tok",
-            "value": round(pairs / elapsed, 1), "unit": "pairs/s",
+            "value": round(cfg["B"] * world * a.steps / med, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * elapsed / a.steps, 4),
+            "ms_per_step": round(1e3 * med / a.steps, 4), "ms_per_step_min": round(1e3 * best / a.steps, 4),
+            "repeats": len(headline), "timed_region_s": round(sum(headline), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
                        "parallelism": f"dp{world}", "launch": launch_note or ("hipGraph replay" if use_graph else "eager"),
+                       "resident_batches": nb,
+                       "conv_arithmetic": {"f32": "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+                                           "bf16x3": "f32 operands split exactly into 3 bf16 planes, 6 plane products per product on "
+                                                     "v_mfma_f32_32x32x16_bf16, f32 accumulate (f32-class accuracy: parity tests at 1e-4)",
+                                           "bf16x2": "2 bf16 planes, 3 plane products, f32 accumulate",
+                                           "bf16": "operands rounded to bf16, f32 accumulate (reduced precision)"}[precision],
                        "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)",
                        "grad_exchange": None if world == 1 else (exchange_note or f"RCCL all-reduce, {a.comm_dtype} wire format, before the clip")},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
-            "kernel_timing": ("HIP events around the C-ABI launches, eager pass over the same steps after the timed region"
-                              if use_graph else "HIP events around the C-ABI launches inside the timed region"),
+            "kernel_timing": "HIP events around the C-ABI launches, eager pass over the same steps after the timed region",
         }
+        out.update(variants)
+        ids_all = torch.cat([args[0], args[1]])
+        n_distinct = int(torch.unique(ids_all[masks]).numel())
         if dense_mode:
             conv_calls, conv_ms = ksum["textcnn_conv_fwd"]
             act_frac = active_tile_fraction(cfg, masks)
@@ -381,30 +542,58 @@ def main():
                 "executed_tile_fraction": round(act_frac, 4), "executed_achieved": round(ach * act_frac, 2),
                 "executed_frac": round(ach * act_frac / PEAK_F32_MFMA_TFLOPS, 4)}
         else:
-            # default build: the conv runs in its token-product form.  Its contraction -- one launch of the MFMA
-            # kernel over the DISTINCT tokens of the batch -- is the longest kernel of the step.  Algorithmic FLOPs of
-            # that formulation: 2 * distinct tokens * D * sum(kz * channels)  (DESIGN.md section 4).
-            gemm_calls, gemm_ms = ksum["textcnn_prod_table"]
-            ids_all = torch.cat([args[0], args[1]])
-            n_distinct = int(torch.unique(ids_all[masks]).numel())
+            # The conv runs in its token-product form; its contraction is ONE launch of the MFMA kernel over the distinct
+            # tokens of the batch.  Algorithmic FLOPs of that formulation: 2 * distinct tokens * D * sum(kz * channels)
+            # (DESIGN.md section 4); the bf16-plane arithmetics execute 6 / 3 / 1 bf16 MFMA products per f32 product.
+            gemm_calls = 50
+            if gemm_ms is None:
+                gemm_calls, gemm_ms = ksum["textcnn_prod_table"]
             cp = sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"])
             gemm_flops = 2.0 * n_distinct * cfg["D"] * cp
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-            conv_ms = sum(ksum[k][1] for k in ("textcnn_prod_prepare", "textcnn_prod_table", "textcnn_prod_pool"))
-            out["roofline"] = {
-                "bound": "mfma", "kernel": "prod_gemm_kernel<60>: T = table[distinct tokens] @ Wprod "
-                                           "(v_mfma_f32_32x32x2_f32, rows gathered by LDS-DMA)",
-                "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic("r01_prod_table_pmc.json"),
-                "traffic_source": "profiles/r01_prod_table_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                "flops_per_launch": gemm_flops, "avg_launch_ms": round(gemm_ms, 4), "launches_timed": gemm_calls,
+            nprod = {"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1}[precision]
+            peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+            # the prepare stage of the b16 arithmetics adds the weight-plane pack launch in front of the GEMM; the events
+            # bracket rbr_textcnn_prod_table alone
+            ach = nprod * gemm_flops / (gemm_ms * 1e-3) / 1e12
+            gemm_pmc = "r02_prod_gemm_b16_pmc.json" if precision != "f32" else "r01_prod_table_pmc.json"
+            out["roofline_gemm"] = {
+                "bound": "mfma",
+                "kernel": ("prod_gemm_kernel<60> (v_mfma_f32_32x32x2_f32)" if precision == "f32" else
+                           f"prod_gemm_b16_kernel<{nprod}> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product)")
+                          + ": T = table[distinct tokens] @ Wprod, rows gathered by LDS-DMA",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": measured_traffic(gemm_pmc), "traffic_source": f"profiles/{gemm_pmc}",
+                "algorithmic_flops_per_launch": gemm_flops, "executed_mfma_flops_per_launch": nprod * gemm_flops,
+                "avg_launch_ms": round(gemm_ms, 4), "launches_timed": gemm_calls,
+                "algorithmic_vs_f32_mfma_peak": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "distinct_tokens": n_distinct, "positions": int(masks.numel()),
-                "note": "longest kernel of the default (token-product) step; the dense conv it replaces is "
-                        f"{flops / 1e9:.1f} GFLOP per launch (RBR_CONV_MODE=dense prices that kernel)"}
+                "timing": "HIP events on the launch stream around 50 back-to-back launches on a workspace prepared for this batch",
+                "note": "achieved = plane-product FLOPs the kernel executes on the bf16 pipe / HIP-event time; "
+                        "algorithmic_vs_f32_mfma_peak = the f32 products it stands for / time / 157.3 TF (the pipe round 1 used)"}
+            conv_ms = sum(ksum[k][1] for k in ("textcnn_prod_prepare", "textcnn_prod_table", "textcnn_prod_pool"))
             out["conv_stage"] = {
-                "formulation": "token-product: T = table[distinct tokens] @ W (f32 MFMA), then gather-add + max-pool",
-                "ms": round(conv_ms, 4), "dense_conv_flops_replaced": flops,
-                "dense_equivalent_TFLOPs": round(flops / (conv_ms * 1e-3) / 1e12, 1)}
+                "formulation": "token-product: T = table[distinct tokens] @ W on the MFMA pipe, then gather-add + max-pool",
+                "ms": round(conv_ms, 4), "dense_conv_flops_it_replaces": flops}
+            if opt_ms is not None:
+                # longest kernel pair of the step: clip_grad_norm_ + Adam over all 17 tensors.  Algorithmic bytes per
+                # launch: the norm pass reads every gradient (4 B/param); the update reads p, g, m, v
+                # and writes p, g (clipped, as clip_grad_norm_ leaves it), m, v (32 B/param).
+                n_par = sum(p.numel() for p in model.parameters())
+                oc, oms = 50, opt_ms
+                obytes = 36.0 * n_par
+                gbps = obytes / (oms * 1e-3) / 1e9
+                out["roofline"] = {
+                    "bound": "hbm", "kernel": "grad_sqnorm_kernel + clip_adam_kernel (rbr_clip_adam_step: clip_grad_norm_ + Adam, "
+                                              "all 17 parameter tensors, 61.2 MB of f32 parameters)",
+                    "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                    "traffic": measured_traffic("r02_clip_adam_pmc.json") or measured_traffic("r01_clip_adam_pmc.json"),
+                    "traffic_source": "profiles/r02_clip_adam_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)",
+                    "bytes_per_launch": obytes, "avg_launch_ms": round(oms, 4), "launches_timed": oc,
+                    "timing": "HIP events on the launch stream around 50 back-to-back rbr_clip_adam_step calls (two kernels each)",
+                    "note": "longest kernel of the step (rocprofv3: clip_adam_kernel 78 us + grad_sqnorm_kernel 14 us); "
+                            "36 B per parameter x 15.3 M parameters; per pair: 36 * 15 301 513 / 256 = 2.15 MB of optimizer traffic"}
+            else:
+                out["roofline"] = out["roofline_gemm"]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
         print(json.dumps(out), flush=True)

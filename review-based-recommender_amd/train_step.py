@@ -101,6 +101,7 @@ class HipClipAdam(torch.optim.Optimizer):
                     raise RuntimeError("HipClipAdam needs contiguous parameters and gradients")
             numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
             b1, b2 = g["betas"]
+            ev = _lib.TIMER.record("clip_adam_step")
             _lib.check(L_.rbr_clip_adam_step(len(ps), _lib.ptr_array(ps, torch.float32, "param"),
                                              _lib.ptr_array(grads, torch.float32, "grad"),
                                              _lib.ptr_array([s_["exp_avg"] for s_ in states], torch.float32, "exp_avg"),
@@ -110,6 +111,8 @@ class HipClipAdam(torch.optim.Optimizer):
                                              _lib.dev_ptr(step, torch.float32, "step"),
                                              _lib.dev_ptr(self._gnorm, torch.float32, "gnorm"),
                                              _lib.dev_ptr(self._ws, torch.float32, "ws"), st), "rbr_clip_adam_step")
+            if ev is not None:
+                ev.record()
         return self._gnorm
 
     @torch.no_grad()
@@ -167,6 +170,31 @@ def clip_and_step(model: nn.Module, optimizer: torch.optim.Optimizer, max_grad_n
     return gnorm
 
 
+def _flat_layout(tensors, align: int = 256):
+    """Byte offsets of `tensors` laid out one after another in one block; neighbours (2k, 2k+1) of equal shape and dtype
+    are packed back to back (no padding between them) so functional.stack_rows() sees one [2n, ...] tensor.  Last entry:
+    total bytes."""
+    offs, o, k = [], 0, 0
+    while k < len(tensors):
+        a = tensors[k]
+        b = tensors[k + 1] if k + 1 < len(tensors) else None
+        o = (o + align - 1) // align * align
+        offs.append(o)
+        o += a.numel() * a.element_size()
+        if b is not None and a.shape == b.shape and a.dtype == b.dtype and a.dim() >= 1:
+            offs.append(o)
+            o += b.numel() * b.element_size()
+            k += 2
+        else:
+            k += 1
+    offs.append((o + align - 1) // align * align)
+    return offs
+
+
+def _flat_views(flat: torch.Tensor, layout, like):
+    return [flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(layout, like)]
+
+
 class GraphedTrainStep:
     """train_step() recorded once into a hipGraph and replayed: the step is ~70 short kernels (0.8 ms of GPU
     work at the cfg2 shape), so launching them one by one from Python leaves the GPU waiting on the host.
@@ -184,8 +212,14 @@ class GraphedTrainStep:
         if not ratings.is_cuda:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         self.model, self.optimizer, self.grad_sync, self.max_grad_norm = model, optimizer, grad_sync, max_grad_norm
-        self.batch = RF.clone_adjacent(batch)       # both towers' inputs in one block: the models stack them as a view
-        self.ratings = ratings.clone()
+        # every input of the step lives in ONE block (`_flat`): a loader hands over a batch with a single device-to-device
+        # (or host-to-device) copy, and the two towers' inputs are neighbours, so the models stack them as a view
+        self._layout = _flat_layout(list(batch) + [ratings])
+        self._flat = torch.empty(self._layout[-1], dtype=torch.uint8, device=ratings.device)
+        views = _flat_views(self._flat, self._layout, list(batch) + [ratings])
+        for v, src in zip(views, list(batch) + [ratings]):
+            v.copy_(src)
+        self.batch, self.ratings = tuple(views[:-1]), views[-1]
         # the warm-up steps below must not count as training: parameters and Adam state are put back in place
         # (same storage -- the recorded graph keeps their addresses) once the graph exists
         saved_params = [p.detach().clone() for p in model.parameters()]
@@ -231,9 +265,21 @@ class GraphedTrainStep:
                             old = saved_state.get(p, {}).get(k)
                             v.copy_(old) if old is not None else v.zero_()
 
-    def __call__(self, batch=None, ratings: torch.Tensor | None = None):
-        """Runs one step on `batch` (None: the batch already in the static buffers).  Returns the graph's
+    def pack(self, batch, ratings: torch.Tensor) -> torch.Tensor:
+        """`batch` + `ratings` as one block in the layout of the step's input buffers (what a loader would stage on the
+        device); hand it to __call__(packed=...)."""
+        blob = torch.empty_like(self._flat)
+        for v, src in zip(_flat_views(blob, self._layout, list(batch) + [ratings]), list(batch) + [ratings]):
+            v.copy_(src)
+        return blob
+
+    def __call__(self, batch=None, ratings: torch.Tensor | None = None, packed: torch.Tensor | None = None):
+        """Runs one step on `batch` / `packed` (None: the batch already in the static buffers).  Returns the graph's
         static (loss, gnorm, pred) tensors -- overwritten by the next replay."""
+        if packed is not None:
+            if packed.shape != self._flat.shape or packed.dtype != torch.uint8:
+                raise RuntimeError("packed batch does not match the step's input layout (use GraphedTrainStep.pack)")
+            self._flat.copy_(packed, non_blocking=True)      # one copy launch for all inputs
         if batch is not None:
             for dst, src in zip(self.batch, batch):
                 if dst is not src:

@@ -126,3 +126,43 @@ def test_stack_rows_and_clone_adjacent_host_logic():
     u, i = RF.clone_adjacent((torch.arange(24).view(2, 3, 4), torch.arange(24, 48).view(2, 3, 4)))
     st = RF.stack_rows(u.reshape(-1, 4), i.reshape(-1, 4))
     assert st.data_ptr() == u.data_ptr() and torch.equal(st, torch.arange(48).view(12, 4))
+
+
+def test_step_input_block_layout_host_logic():
+    """train_step._flat_layout / _flat_views: all inputs of a step in one block, tower pairs back to back (stack_rows sees
+    a view), everything else 256-byte aligned; a packed copy of another batch lands field by field."""
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.train_step import _flat_layout, _flat_views
+    g = torch.Generator().manual_seed(1)
+    u, i = torch.randint(0, 50, (5, 7), generator=g), torch.randint(0, 50, (5, 7), generator=g)
+    mu, mi = u != 0, i != 0
+    uid, iid = torch.randint(0, 9, (5,), generator=g), torch.randint(0, 9, (5,), generator=g)
+    r = torch.rand(5, generator=g)
+    like = [u, i, mu, mi, uid, iid, r]
+    lay = _flat_layout(like)
+    assert len(lay) == len(like) + 1 and lay[0] == 0 and lay[1] == u.numel() * 8          # the pair is contiguous
+    assert all(lay[k] % 256 == 0 for k in (0, 2, 4, 6, 7))
+    flat = torch.zeros(lay[-1], dtype=torch.uint8)
+    views = _flat_views(flat, lay, like)
+    for v, src in zip(views, like):
+        v.copy_(src)
+    for v, src in zip(views, like):
+        assert v.dtype == src.dtype and torch.equal(v, src)
+    assert RF.stack_rows(views[0], views[1]).data_ptr() == views[0].data_ptr()
+    assert RF.stack_rows(views[2], views[3]).data_ptr() == views[2].data_ptr()
+    assert torch.equal(RF.stack_rows(views[0], views[1]), torch.cat([u, i]))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain invocation launches two ranks through torch.distributed.run before touching the
+    GPU (VERDICT r1 #1).  Without a GPU every rank stops at the device check -- which is the proof that both were started."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the real multi-rank run is the driver's")
+    assert r.returncode != 0
+    assert out.count("bench.py needs an MI355X") >= 2, out[-2000:]
