@@ -311,6 +311,30 @@ int rbr_embedding_fwd(int64_t n_tok, int32_t D, const int64_t* ids, const float*
 int rbr_embedding_bwd(int64_t n_tok, int32_t D, const int64_t* ids, const float* d_out, int32_t pad_idx, float* dtable,
                       void* stream);
 
+/* ---- id range check in front of every embedding-style lookup (nn.Embedding raises IndexError, deepconn/layers.py:23;
+ *      a kernel cannot, and an unchecked id would read or -- in the backward -- write outside its table).
+ *      ONE launch for up to RBR_MAX_ID_SETS tensors: out[k] = in[k] when 0 <= in[k] < limit, else `replace` (a valid
+ *      row, 0 <= replace < limit) and the device record err (int64[4], zero while clean: err[0] = bad ids so far,
+ *      err[1] = one offending value, err[2] = its set) is updated; the host reads `err` at its next synchronisation
+ *      point and raises.  `sets` is a HOST array; the outputs may be adjacent slices of one buffer (stacks the towers). ---- */
+#define RBR_MAX_ID_SETS 8
+typedef struct rbr_id_set {
+    const int64_t* in;
+    int64_t* out;
+    int64_t n, limit, replace;
+} rbr_id_set;
+int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t* err, void* stream);
+
+/* ---- in-batch document dedup (the reference re-encodes a document for every pair it appears in,
+ *      deepconn/deepconn.py:46-47).  Rows [0,B) = user side (ids u_ids, table of U ids), rows [B,2B) = item side.
+ *      first[r] = first row of the same side with the same id (item rows offset by B); mask_out[r,:] = mask_in[r,:]
+ *      (all ones when mask_in is NULL) for rows that are their own first occurrence, 0 otherwise -- the encoder then skips
+ *      the repeated documents and the caller gathers their features from row first[r].  No sync, static shapes.
+ *      ws: rbr_dedup_ws_bytes(U, I) bytes.  Ids outside their table count as unique.                           ---- */
+size_t rbr_dedup_ws_bytes(int32_t U, int32_t I);
+int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const int64_t* i_ids, int32_t U, int32_t I,
+                   const uint8_t* mask_in, void* ws, int64_t* first, uint8_t* mask_out, void* stream);
+
 /* ---- NgramFeat arch="HierPooling" (deepconn/layers.py:62-98,110-114): pooled[doc,d] =
  *      max_l mean_{j<k} x[doc,l+j,d] over l in [0, L-k], x = mask * table[ids]; relu != 0 applies the
  *      trailing ReLU when there is no projection layer.  argmax[doc,d] = first maximising window start.

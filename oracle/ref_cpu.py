@@ -280,3 +280,19 @@ def train_steps(params: Params, forward_fn, ratings, n_steps: int = 1, lr: float
                             gnorm=gnorm.detach().clone(),
                             params={k: v.detach().clone() for k, v in leaves.items()}))
     return history
+
+
+def train_over_batches(params: Params, steps, lr: float = 2e-3, max_grad_norm: float = 5.0):
+    """The same step as train_steps() over a SEQUENCE of batches (one epoch of trainer/train_deepconn_pp.py:143-168):
+    `steps` = [(forward_fn(p) -> pred, ratings), ...].  Returns (per-step losses, the trained leaf parameters)."""
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=lr)
+    losses = []
+    for forward_fn, ratings in steps:
+        opt.zero_grad()
+        loss = F.mse_loss(forward_fn(leaves), ratings)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(leaves.values()), max_grad_norm)
+        opt.step()
+        losses.append(float(loss))
+    return losses, {k: v.detach() for k, v in leaves.items()}

@@ -49,6 +49,13 @@ class AttnParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W_rv", "W_id", "h", "b1", "b2", "ebd")]
 
 
+class IdSet(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("limit", C.c_int64), ("replace", C.c_int64)]
+
+
+MAX_ID_SETS = 8
+
+
 class AttnGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dW_rv", "dW_id", "dh", "db1", "db2", "debd")]
 
@@ -134,6 +141,9 @@ SIGNATURES = {
     "rbr_linear_bwd_ws_floats": (C.c_size_t, [i32, i32]),
     "rbr_linear_bwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p,
                                  c_f32p, c_stream]),
+    "rbr_sanitize_ids": (C.c_int, [i32, C.POINTER(IdSet), C.c_void_p, c_stream]),
+    "rbr_dedup_ws_bytes": (C.c_size_t, [i32, i32]),
+    "rbr_dedup_rows": (C.c_int, [i32, i32, c_i64p, c_i64p, i32, i32, c_u8p, C.c_void_p, c_i64p, c_u8p, c_stream]),
     "rbr_embedding_fwd": (C.c_int, [C.c_int64, i32, c_i64p, c_f32p, c_f32p, c_stream]),
     "rbr_embedding_bwd": (C.c_int, [C.c_int64, i32, c_i64p, c_f32p, i32, c_f32p, c_stream]),
     "rbr_hier_pool_fwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_u8p, c_f32p, i32, c_f32p, c_i32p, c_stream]),

@@ -295,6 +295,125 @@ extern "C" int rbr_hier_pool_bwd(int32_t n_docs, int32_t L, int32_t D, int32_t k
     return 0;
 }
 
+namespace rbr {
+
+// ---------------------------------------------------------------------------------- id range check
+// nn.Embedding raises IndexError for an id outside its table (reference models/deepconn/layers.py:23); a kernel cannot, and
+// an unchecked id would read -- or, in the backward, WRITE -- outside the table.  The modules therefore pass every id tensor
+// through this launch first: out = in where 0 <= in < limit, else `replace` (a valid row) plus a record in `err`
+// (err[0] bad ids so far, err[1] one offending value, err[2] its set), which the host turns into the IndexError at its
+// next synchronisation point (functional.check_id_errors).  Up to 8 tensors per launch; the outputs may be adjacent slices
+// of one buffer, which also stacks the two towers' token ids for free.
+struct IdSets {
+    const long long* in[RBR_MAX_ID_SETS];
+    long long* out[RBR_MAX_ID_SETS];
+    long long n[RBR_MAX_ID_SETS], limit[RBR_MAX_ID_SETS], replace[RBR_MAX_ID_SETS];
+    long long first[RBR_MAX_ID_SETS + 1];     // prefix of n: element k of the launch belongs to the set with first[s] <= k < first[s+1]
+    int count;
+};
+
+__global__ __launch_bounds__(256) void sanitize_ids_kernel(const IdSets S, long long* __restrict__ err) {
+    const long long total = S.first[S.count];
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+        int s = 0;
+#pragma unroll
+        for (int q = 1; q < RBR_MAX_ID_SETS; ++q)
+            if (q < S.count && k >= S.first[q]) s = q;
+        const long long e = k - S.first[s];
+        long long v = S.in[s][e];
+        const bool bad = (unsigned long long)v >= (unsigned long long)S.limit[s];
+        if (bad) {
+            err[1] = v; err[2] = s;                       // any one offender (benign race)
+            atomicAdd(reinterpret_cast<unsigned long long*>(err), 1ull);
+            v = S.replace[s];
+        }
+        S.out[s][e] = v;
+    }
+}
+
+}  // namespace rbr
+
+extern "C" int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t* err, void* stream) {
+    using namespace rbr;
+    if (n_sets <= 0 || n_sets > RBR_MAX_ID_SETS || !sets || !err) { set_error("rbr_sanitize_ids: n_sets=%d", n_sets); return RBR_ERR_BAD_ARG; }
+    IdSets S{};
+    S.count = n_sets;
+    long long total = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        if (sets[s].n < 0 || (sets[s].n > 0 && (!sets[s].in || !sets[s].out)) || sets[s].limit <= 0 ||
+            sets[s].replace < 0 || sets[s].replace >= sets[s].limit) {
+            set_error("rbr_sanitize_ids: set %d is malformed", s);
+            return RBR_ERR_BAD_ARG;
+        }
+        S.in[s] = reinterpret_cast<const long long*>(sets[s].in); S.out[s] = reinterpret_cast<long long*>(sets[s].out);
+        S.n[s] = sets[s].n; S.limit[s] = sets[s].limit; S.replace[s] = sets[s].replace;
+        S.first[s] = total;
+        total += sets[s].n;
+    }
+    S.first[n_sets] = total;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(sanitize_ids_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, S, reinterpret_cast<long long*>(err));
+    RBR_CHECK_LAUNCH("sanitize_ids launch");
+    return 0;
+}
+
+namespace rbr {
+
+// ---------------------------------------------------------------------------------- in-batch document dedup
+// A document is a function of its user / item id (the doc split builds one per id), and the reference re-encodes it for
+// every pair it appears in (models/deepconn/deepconn.py:46-47).  first[b] = the first row of the batch with the same id;
+// rows that are not their own first occurrence get an all-zero mask, so the encoder skips them (their 32-token slabs are
+// inactive) and the caller gathers their features from row first[b].  Shape-static and sync-free: graph-capturable.
+// scratch[id] holds n - (first row) (0 = id absent; zeroed by the launch in front), rows [0, B) are the user side, rows
+// [B, 2B) the item side with its own scratch range.
+__global__ __launch_bounds__(256) void dedup_mark_kernel(int B, const long long* __restrict__ u_ids, const long long* __restrict__ i_ids,
+                                                         int U, int I, int* __restrict__ scratch) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * B) return;
+    const bool item = r >= B;
+    const int b = item ? r - B : r;
+    const long long id = item ? i_ids[b] : u_ids[b];
+    if ((unsigned long long)id >= (unsigned long long)(item ? I : U)) return;         // out of range: its own first occurrence
+    atomicMax(scratch + (item ? U : 0) + id, B - b);
+}
+
+__global__ __launch_bounds__(256) void dedup_apply_kernel(int B, int L, const long long* __restrict__ u_ids,
+                                                          const long long* __restrict__ i_ids, int U, int I,
+                                                          const int* __restrict__ scratch, const unsigned char* __restrict__ mask_in,
+                                                          long long* __restrict__ first, unsigned char* __restrict__ mask_out) {
+    const int r = blockIdx.x;                      // one workgroup per row
+    const bool item = r >= B;
+    const int b = item ? r - B : r;
+    const long long id = item ? i_ids[b] : u_ids[b];
+    int f = b;
+    if ((unsigned long long)id < (unsigned long long)(item ? I : U)) f = B - scratch[(item ? U : 0) + id];
+    if (threadIdx.x == 0) first[r] = (item ? B : 0) + f;
+    const bool keep = f == b;
+    for (int l = threadIdx.x; l < L; l += 256)
+        mask_out[(long)r * L + l] = keep ? (mask_in != nullptr ? mask_in[(long)r * L + l] : (unsigned char)1) : (unsigned char)0;
+}
+
+}  // namespace rbr
+
+extern "C" size_t rbr_dedup_ws_bytes(int32_t U, int32_t I) { return ((size_t)U + (size_t)I) * sizeof(int); }
+
+extern "C" int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const int64_t* i_ids, int32_t U, int32_t I,
+                              const uint8_t* mask_in, void* ws, int64_t* first, uint8_t* mask_out, void* stream) {
+    using namespace rbr;
+    if (B <= 0 || L <= 0 || U <= 0 || I <= 0 || !u_ids || !i_ids || !ws || !first || !mask_out) { set_error("rbr_dedup_rows: bad argument"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    int* scratch = static_cast<int*>(ws);
+    if (int e = zero_words(scratch, ((size_t)U + (size_t)I) * sizeof(int), st)) return e;
+    hipLaunchKernelGGL(dedup_mark_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, B, reinterpret_cast<const long long*>(u_ids),
+                       reinterpret_cast<const long long*>(i_ids), U, I, scratch);
+    RBR_CHECK_LAUNCH("dedup mark launch");
+    hipLaunchKernelGGL(dedup_apply_kernel, dim3(2 * B), dim3(256), 0, st, B, L, reinterpret_cast<const long long*>(u_ids),
+                       reinterpret_cast<const long long*>(i_ids), U, I, scratch, mask_in, reinterpret_cast<long long*>(first), mask_out);
+    RBR_CHECK_LAUNCH("dedup apply launch");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ dropout multiplier
 // out[i] = 0 with probability p, else 1/(1-p): the multiplier nn.Dropout / F.dropout applies (deepconn/layers.py:202,
 // narre.py:73, dual_att.py:33).  Philox4x32-10 keyed by `seed`, counter = (element quad, call number); the call number

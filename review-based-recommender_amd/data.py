@@ -10,9 +10,14 @@ Format (written by the reference's preprocess/divide_and_create_example_{doc,wor
       review split: 7-tuples (valid/test) or 8-tuples (train; the last field is dropped)  (train_narre.py:273-279)
 
 `meta["indexlizer"]` is an instance of the reference's preprocess._tokenizer.Indexlizer holding function
-references (nltk tokenizers, clean_str).  Those modules are not importable here, so `load_pickle` resolves
-any class or function it cannot import to an inert placeholder: the object graph loads, nothing from it is
-executed, and only `_vocab._token2id` (the vocabulary size) is read.  Only load dataset files you produced.
+references (nltk tokenizers, clean_str).  `load_pickle` resolves ONLY an allow-list of globals (plain containers of
+builtins / collections and numpy's array reconstructors); every other class or function a pickle names -- importable or
+not, `os.system` included -- becomes an inert placeholder: the object graph loads, nothing from it is executed, and only
+`_vocab._token2id` (the vocabulary size) is read.
+
+Parity status of the format: UNPINNED.  The reference holds no dataset fixture and its preprocess scripts need nltk, so
+the layout above is restated from the trainers' read sites cited here; tests/make_dataset.py writes files of that layout.
+The loader also validates every token / user / item id against its table once, at load time (`validate_ranges`).
 """
 from __future__ import annotations
 
@@ -40,13 +45,25 @@ class _Placeholder:
         raise RuntimeError("placeholder for an object of a module that is not importable here")
 
 
+# globals a dataset pickle may legitimately reconstruct: containers and numpy arrays / scalars.  Nothing callable with a
+# side effect is on the list; REDUCE on anything else calls a _Placeholder constructor, which does nothing.
+_ALLOWED_GLOBALS = {
+    "builtins": {"list", "dict", "tuple", "set", "frozenset", "int", "float", "complex", "str", "bytes", "bytearray",
+                 "bool", "slice", "range", "object"},
+    "collections": {"OrderedDict", "defaultdict", "Counter", "deque"},
+    "numpy": {"ndarray", "dtype"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"},
+    "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "numpy.core.numeric": {"_frombuffer"},
+    "numpy._core.numeric": {"_frombuffer"},
+}
+
+
 class _TolerantUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            mod = importlib.import_module(module)
-            return getattr(mod, name)
-        except Exception:
-            return type(name, (_Placeholder,), {"__module__": module})
+        if name in _ALLOWED_GLOBALS.get(module, ()):
+            return getattr(importlib.import_module(module), name)
+        return type(name, (_Placeholder,), {"__module__": module})
 
 
 def load_pickle(path):
@@ -64,6 +81,13 @@ def vocab_size_of(indexlizer) -> int:
     if isinstance(indexlizer, int):
         return int(indexlizer)
     raise ValueError("cannot find the vocabulary (_vocab._token2id) in meta['indexlizer']")
+
+
+def _check_range(values, limit: int, what: str) -> None:
+    t = torch.as_tensor(values, dtype=torch.int64)
+    if t.numel() and (int(t.min()) < 0 or int(t.max()) >= limit):
+        raise IndexError(f"{what}: ids span [{int(t.min())}, {int(t.max())}] but the table has {limit} rows "
+                         "(vocabulary / meta.pkl mismatch?)")
 
 
 def get_mask(tensor: torch.Tensor, padding_idx: int = 0) -> torch.Tensor:
@@ -93,6 +117,16 @@ class DocDataset(torch.utils.data.Dataset):
         self.user_docs, self.item_docs = meta["user_docs"], meta["item_docs"]
         self.examples = load_pickle(os.path.join(data_dir, f"{set_name}_exmaples.pkl"))
         self.with_ids = with_ids
+        self.validate_ranges()
+
+    def validate_ranges(self) -> None:
+        """Every token / user / item id of the split against its table, once at load time: the IndexError nn.Embedding
+        would raise on the first bad batch (models/deepconn/layers.py:23), up front.  A model fed from a validated dataset
+        may run with validate_ids = False."""
+        _check_range([e[0] for e in self.examples], self.user_num, "user ids")
+        _check_range([e[1] for e in self.examples], self.item_num, "item ids")
+        _check_range([e[3] for e in self.examples], self.vocab_size, "user document tokens")
+        _check_range([e[4] for e in self.examples], self.vocab_size, "item document tokens")
 
     def __len__(self):
         return len(self.examples)
@@ -121,6 +155,15 @@ class ReviewDataset(torch.utils.data.Dataset):
         self.user_reviews, self.item_reviews = meta["user_reviews"], meta["item_reviews"]
         self.user_rids, self.item_rids = meta["user_rids"], meta["item_rids"]
         self.examples = load_pickle(os.path.join(data_dir, f"{set_name}_exmaples.pkl"))
+        self.validate_ranges()
+
+    def validate_ranges(self) -> None:
+        _check_range([e[0] for e in self.examples], self.user_num, "user ids")
+        _check_range([e[1] for e in self.examples], self.item_num, "item ids")
+        _check_range([e[3] for e in self.examples], self.vocab_size, "user review tokens")
+        _check_range([e[4] for e in self.examples], self.vocab_size, "item review tokens")
+        _check_range([e[5] for e in self.examples], self.item_num, "user-side counterpart (item) ids")
+        _check_range([e[6] for e in self.examples], self.user_num, "item-side counterpart (user) ids")
 
     def __len__(self):
         return len(self.examples)

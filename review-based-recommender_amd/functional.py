@@ -45,6 +45,89 @@ def get_prod_precision() -> str:
     return {v: k for k, v in _lib.PROD_PRECISIONS.items()}[mode]
 
 
+# --------------------------------------------------------------------------- id range check
+_ID_ERR: dict = {}       # per device: int64[4] error record of rbr_sanitize_ids (zero while clean)
+
+
+def _id_err(dev) -> torch.Tensor:
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _ID_ERR.get(idx)
+    if t is None:
+        t = _ID_ERR[idx] = torch.zeros(4, dtype=torch.int64, device=dev)
+    return t
+
+
+def sanitize_ids(sets, stack_first_two: bool = False):
+    """Range check in front of the embedding-style lookups: `sets` = [(ids int64 tensor, table rows, replacement row), ...]
+    (at most 8).  Returns clean copies (one launch, one allocation): an id outside [0, rows) becomes `replacement` and is
+    recorded on the device; check_id_errors() raises the IndexError nn.Embedding would have raised (reference
+    models/deepconn/layers.py:23) at the caller's next synchronisation point.  With `stack_first_two` the first two
+    outputs (equal shapes) are adjacent and the first return value is the stacked [2n, ...] tensor (user rows first)."""
+    if not sets or len(sets) > _lib.MAX_ID_SETS:
+        raise RuntimeError(f"sanitize_ids takes 1..{_lib.MAX_ID_SETS} id tensors")
+    dev = sets[0][0].device
+    tens = []
+    for t, rows, rep in sets:
+        if t.dtype != I64:
+            raise RuntimeError(f"ids must be int64, got {t.dtype}")
+        dev_ptr(t.contiguous(), I64, "ids")        # device gate
+        tens.append(t.contiguous())
+    flat = torch.empty(sum(t.numel() for t in tens), dtype=I64, device=dev)
+    outs, o = [], 0
+    arr = (_lib.IdSet * len(tens))()
+    for k, (t, (_, rows, rep)) in enumerate(zip(tens, sets)):
+        v = flat[o:o + t.numel()].view(t.shape)
+        outs.append(v)
+        o += t.numel()
+        rep = 0 if rep is None or rep < 0 else int(rep)
+        arr[k] = _lib.IdSet(t.data_ptr() if t.numel() else None, v.data_ptr() if t.numel() else None, t.numel(), int(rows), rep)
+    check(_lib.lib().rbr_sanitize_ids(len(tens), arr, _id_err(dev).data_ptr(), current_stream()), "rbr_sanitize_ids")
+    if stack_first_two:
+        a, b = tens[0], tens[1]
+        if a.shape != b.shape:
+            raise RuntimeError("stack_first_two needs equal shapes")
+        outs = [flat[:2 * a.numel()].view(2 * a.shape[0], *a.shape[1:])] + outs[2:]
+    return outs
+
+
+def check_id_errors(device=None) -> None:
+    """Raises IndexError when any id seen by sanitize_ids() since the last call was outside its table (and clears the
+    record).  Synchronises with the device: call it where the trainer synchronises anyway (its loss.item() log points)."""
+    devs = list(_ID_ERR) if device is None else [torch.device(device).index if torch.device(device).index is not None
+                                                 else torch.cuda.current_device()]
+    for idx in devs:
+        t = _ID_ERR.get(idx)
+        if t is None:
+            continue
+        rec = t.cpu()
+        if int(rec[0]) > 0:
+            t.zero_()
+            raise IndexError(f"index out of range in self: {int(rec[0])} id(s) outside their table on cuda:{idx}, e.g. "
+                             f"{int(rec[1])} in id tensor #{int(rec[2])} of its call; such ids were replaced by the padding row")
+
+
+def dedup_rows(u_ids: torch.Tensor, i_ids: torch.Tensor, user_size: int, item_size: int, masks: Optional[torch.Tensor], L: int):
+    """In-batch dedup of the documents by id (rbr_dedup_rows): returns (first [2B] int64, masks_out [2B, L] bool).  Rows
+    [0, B) are the user side, [B, 2B) the item side; first[r] is the first row of the same side carrying the same id, and
+    masks_out blanks every row that is not its own first occurrence, so the encoder skips the repeated documents.
+    Everything has a static shape and nothing synchronises: the step stays graph-capturable."""
+    B = u_ids.shape[0]
+    dev = u_ids.device
+    u_ids, i_ids = u_ids.contiguous(), i_ids.contiguous()
+    mask8 = _mask_u8(masks)
+    if mask8 is not None and mask8.shape != (2 * B, L):
+        raise RuntimeError(f"masks must be [{2 * B}, {L}], got {tuple(mask8.shape)}")
+    L_ = _lib.lib()
+    ws = torch.empty(L_.rbr_dedup_ws_bytes(int(user_size), int(item_size)), dtype=torch.uint8, device=dev)
+    first = torch.empty(2 * B, dtype=I64, device=dev)
+    out = torch.empty(2 * B, L, dtype=torch.uint8, device=dev)
+    check(L_.rbr_dedup_rows(B, int(L), dev_ptr(u_ids, I64, "u_ids"), dev_ptr(i_ids, I64, "i_ids"), int(user_size), int(item_size),
+                            dev_ptr(mask8, U8, "mask"), ws.data_ptr(), dev_ptr(first, I64, "first"), dev_ptr(out, U8, "mask_out"),
+                            current_stream()), "rbr_dedup_rows")
+    return first, out.view(torch.bool)
+
+
 def set_tap_sink(sink) -> None:
     global _TAP_SINK
     _TAP_SINK = sink

@@ -25,6 +25,10 @@ class DeepCoNNpp(nn.Module):
         # document is a function of its id (the doc split builds one document per user / item); the reference
         # re-encodes the same document for every pair it appears in (deepconn.py:46-47).
         self.dedup_by_id = False
+        # every id tensor passes a device-side range check first (one launch; functional.sanitize_ids): an id outside its
+        # table becomes the padding row and functional.check_id_errors() raises nn.Embedding's IndexError at the next
+        # synchronisation point.  False: the caller guarantees the ranges (a dataset validated at load time).
+        self.validate_ids = True
 
     def forward(self, u_revs, i_revs, u_rev_masks, i_rev_masks, u_ids, i_ids):
         """u_revs/i_revs [bz, doc_len] int64, masks [bz, doc_len] bool, ids [bz] -> preds [bz].
@@ -32,27 +36,24 @@ class DeepCoNNpp(nn.Module):
         Both towers share the table and the TextCNN (deepconn.py:43-47), so the user and item
         documents go through ONE launch of the fused gather+conv+pool kernel as a 2*bz batch."""
         bz = u_revs.shape[0]
+        stacked = None
+        if self.validate_ids:
+            pad = self.word_embeddings.padding_idx
+            stacked, u_ids, i_ids = RF.sanitize_ids([(u_revs, self.vocab_size, pad), (i_revs, self.vocab_size, pad),
+                                                     (u_ids, self.user_size, 0), (i_ids, self.item_size, 0)], stack_first_two=True)
+            u_revs, i_revs = stacked[:bz], stacked[bz:]
         if self.dedup_by_id:
-            u_first, u_inv = _first_occurrence(u_ids)
-            i_first, i_inv = _first_occurrence(i_ids)
-            nu = u_first.shape[0]
-            ids = torch.cat([u_revs.index_select(0, u_first), i_revs.index_select(0, i_first)], dim=0)
-            masks = torch.cat([u_rev_masks.index_select(0, u_first), i_rev_masks.index_select(0, i_first)], dim=0)
+            # first occurrence of every id on the device (static shapes, no sync: the step stays graph-capturable); the
+            # repeated documents are blanked, so the encoder skips them, and their features are row gathers
+            ids = stacked if stacked is not None else RF.stack_rows(u_revs, i_revs)
+            first, masks = RF.dedup_rows(u_ids, i_ids, self.user_size, self.item_size,
+                                         RF.stack_rows(u_rev_masks, i_rev_masks), ids.shape[1])
             feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
-            u_rev_feats = feats[:nu].index_select(0, u_inv)
-            i_rev_feats = feats[nu:].index_select(0, i_inv)
+            u_rev_feats, i_rev_feats = feats.index_select(0, first), None       # [2*bz, H], user rows first
         else:
-            ids = RF.stack_rows(u_revs, i_revs)
+            ids = stacked if stacked is not None else RF.stack_rows(u_revs, i_revs)
             masks = RF.stack_rows(u_rev_masks, i_rev_masks)
             feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
             u_rev_feats, i_rev_feats = feats, None          # [2*bz, H], user rows first: the head takes it whole
         preds = rating_head(self.user_feat, self.item_feat, self.fm, u_rev_feats, i_rev_feats, u_ids, i_ids)
         return preds.view(bz)
-
-
-def _first_occurrence(ids: torch.Tensor):
-    """(rows of the first occurrence of every distinct id, inverse map) -- torch index plumbing on the device."""
-    uniq, inv = torch.unique(ids, return_inverse=True)
-    first = torch.full((uniq.shape[0],), ids.shape[0], dtype=torch.int64, device=ids.device)
-    first.scatter_reduce_(0, inv, torch.arange(ids.shape[0], device=ids.device), reduce="amin")
-    return first, inv

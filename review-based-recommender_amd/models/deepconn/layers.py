@@ -43,7 +43,9 @@ class WordEmbedding(nn.Module):
         return self.embedding.weight
 
     def forward(self, inputs):
-        """Materialised lookup [*, D] for callers that want the rows themselves (HIP row gather)."""
+        """Materialised lookup [*, D] for callers that want the rows themselves (HIP row gather); ids are range-checked on
+        the device first (functional.sanitize_ids / check_id_errors stand in for nn.Embedding's IndexError)."""
+        (inputs,) = RF.sanitize_ids([(inputs, self.embedding.num_embeddings, self.padding_idx)])
         return RF.embedding(self.embedding.weight, inputs, self.padding_idx)
 
 
@@ -70,8 +72,25 @@ class MyConv1d(nn.Module):
         return [c.bias for c in self.list_of_conv1d]
 
     def forward(self, inputs):
-        raise RuntimeError("MyConv1d has no standalone HIP forward: the conv is fused with the gather and the "
-                           "max-pool (NgramFeat); a [bz, C, L] activation is never materialised")
+        """Reference signature (layers.py:46-60): inputs [bz, in_features, seq_len] (N x C x L) -> [bz, out_features, seq_len],
+        every width zero-padded 'same', channels width-major.  The models never call this (their conv is fused with the
+        gather and the max-pool and never materialises a [bz, C, L] activation); it serves callers of the layer itself.
+        The contraction runs on the HIP GEMM (functional.linear, forward and backward): T[n, (w, j, c)] = <x[n, :], W_w[c, :, j]>
+        for every position n, then out[b, l, c] = bias[c] + sum_j T[(b, l + j - pad_w), (w, j, c)] as kz shifted adds."""
+        bz, cin, L = inputs.shape
+        x = inputs.transpose(1, 2).reshape(bz * L, cin)                       # one row per position
+        wp = torch.cat([c.weight.permute(2, 0, 1).reshape(-1, cin) for c in self.list_of_conv1d], dim=0)   # [(w, j, c), D]
+        t = RF.linear(x, wp, None).view(bz, L, -1)
+        outs, o = [], 0
+        for conv, kz in zip(self.list_of_conv1d, self.kernel_sizes):
+            ch, pad = conv.weight.shape[0], (kz - 1) // 2
+            tw = torch.nn.functional.pad(t[:, :, o:o + kz * ch].reshape(bz, L, kz, ch), (0, 0, 0, 0, pad, pad))   # zero rows outside the doc
+            acc = conv.bias.view(1, 1, ch)
+            for j in range(kz):
+                acc = acc + tw[:, j:j + L, j, :]
+            outs.append(acc)
+            o += kz * ch
+        return torch.cat(outs, dim=2).transpose(1, 2).contiguous()            # [bz, out_features, seq_len]
 
 
 class HierPooling(nn.Module):
@@ -147,6 +166,13 @@ class LastFeat(nn.Module):
         with torch.no_grad():
             self.b.fill_(self.BIAS_INIT)
 
+    def forward(self, text_feat, my_id):
+        """Reference signature (layers.py:156-165): text_feat [bz, feat_size], my_id [bz] -> [bz, latent_dim] =
+        text_feat @ W + b + ebd(my_id).  The models use the fused rating head (rating_head below); this serves callers of
+        the layer itself: HIP GEMM + HIP row gather, one elementwise add."""
+        (my_id,) = RF.sanitize_ids([(my_id, self.ebd.num_embeddings, self.padding_idx)])
+        return RF.linear(text_feat, self.W.t(), self.b) + RF.embedding(self.ebd.weight, my_id, self.padding_idx)
+
 
 class FM(nn.Module):
     """layers.py:167-209 parameters: h [latent,1], g_bias [1], user_bias [U,1], item_bias [I,1]; Dropout(p)."""
@@ -173,6 +199,22 @@ class FM(nn.Module):
             _uniform_(self.item_bias.weight, self.BOUND)
         with torch.no_grad():
             self.g_bias.fill_(self.G_BIAS_INIT)
+
+    def forward(self, u_feat, i_feat, u_id, i_id):
+        """Reference signature (layers.py:189-209): u_feat / i_feat [bz, latent_dim], ids [bz] -> pred [bz, 1] =
+        dropout(relu(u_feat * i_feat)) @ h + user_bias(u_id) + item_bias(i_id) + g_bias.  The models use the fused rating
+        head; this serves callers of the layer itself (HIP GEMM, HIP row gathers, HIP dropout multiplier)."""
+        fm = torch.relu(u_feat * i_feat)
+        drop = RF.dropout_multiplier(fm.shape, self.dropout.p, self.training, fm.device)
+        if drop is not None:
+            fm = fm * drop
+        pred = RF.linear(fm, self.h.t(), None) + self.g_bias
+        if self.WITH_ID_BIASES:
+            u_id, i_id = RF.sanitize_ids([(u_id, self.user_bias.num_embeddings, self.user_padding_idx),
+                                          (i_id, self.item_bias.num_embeddings, self.item_padding_idx)])
+            pred = pred + RF.embedding(self.user_bias.weight, u_id, self.user_padding_idx) \
+                        + RF.embedding(self.item_bias.weight, i_id, self.item_padding_idx)
+        return pred
 
 
 def rating_head(user_feat: LastFeat, item_feat: LastFeat, fm: FM, u_text_feat, i_text_feat, u_ids, i_ids):

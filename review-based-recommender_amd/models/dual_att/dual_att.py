@@ -15,6 +15,8 @@ class DualAtt(nn.Module):
                  hidden_size_1=500, hidden_size_2=50, dropout=0.5, pretrained_embeddings=None):
         super().__init__()
         self.fc_input = l_out_size + 3 * g_out_size
+        self.vocab_size = vocab_size
+        self.validate_ids = True      # device-side range check of the token ids (functional.sanitize_ids), see DeepCoNNpp
 
         self.word_embeddings = WordEmbedding(vocab_size, emb_size, pretrained_embeddings=pretrained_embeddings)
         self.u_local_atten = LocalAttention(doc_len, l_window_size, l_out_size, emb_size)
@@ -39,6 +41,9 @@ class DualAtt(nn.Module):
     def forward(self, u_docs, i_docs):
         """u_docs / i_docs [bz, doc_len] int64 -> ratings [bz]."""
         bz = u_docs.shape[0]
+        if self.validate_ids:
+            pad = self.word_embeddings.padding_idx
+            u_docs, i_docs = RF.sanitize_ids([(u_docs, self.vocab_size, pad), (i_docs, self.vocab_size, pad)])
         u_enc = self._encode(u_docs, self.u_local_atten, self.u_global_atten)
         i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten)
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their

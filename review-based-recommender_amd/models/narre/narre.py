@@ -58,6 +58,8 @@ class NARRE(nn.Module):
         self.item_feat = LastFeat(item_size, hidden_dim, latent_dim, padding_idx=item_padding_idx)
         self.fm = FM(user_size, item_size, latent_dim, dropout, user_padding_idx=user_padding_idx,
                      item_padding_idx=item_padding_idx)
+        self.user_size, self.item_size, self.vocab_size = user_size, item_size, vocab_size
+        self.validate_ids = True      # device-side range check of every id tensor (functional.sanitize_ids), see DeepCoNNpp
 
     def forward(self, u_text, i_text, u_text_masks, i_text_masks, u_id, i_id, reuid, reiid):
         """u_text/i_text [bz, doc_num, doc_len] int64, masks same shape bool, u_id/i_id [bz],
@@ -67,7 +69,15 @@ class NARRE(nn.Module):
         fused gather+conv+pool kernel as 2*bz*doc_num documents of doc_len tokens."""
         bz = u_text.shape[0]
         R, T = self.doc_num, self.doc_len
-        ids = RF.stack_rows(u_text.reshape(-1, T), i_text.reshape(-1, T))
+        if self.validate_ids:
+            wp = self.word_embeddings.padding_idx
+            ids, u_id, i_id, reuid, reiid = RF.sanitize_ids(
+                [(u_text.reshape(-1, T), self.vocab_size, wp), (i_text.reshape(-1, T), self.vocab_size, wp),
+                 (u_id, self.user_size, self.user_feat.padding_idx), (i_id, self.item_size, self.item_feat.padding_idx),
+                 (reuid, self.item_size, self.user_att.padding_idx), (reiid, self.user_size, self.item_att.padding_idx)],
+                stack_first_two=True)
+        else:
+            ids = RF.stack_rows(u_text.reshape(-1, T), i_text.reshape(-1, T))
         masks = RF.stack_rows(u_text_masks.reshape(-1, T), i_text_masks.reshape(-1, T))
         feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
         # unbind, not two slices: its backward is ONE stack of the two gradients (a slice pair costs two fills, two copies, an add)

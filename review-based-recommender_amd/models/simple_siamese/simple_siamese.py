@@ -16,6 +16,8 @@ class SimpleSiamese(nn.Module):
         self.use_ui_bias = use_ui_bias
         self.embedding_dim = embedding_dim
         self.latent_transform = latent_transform
+        self.vocab_size, self.user_size, self.item_size = vocab_size, user_size, item_size
+        self.validate_ids = True      # device-side range check of every id tensor (functional.sanitize_ids), see DeepCoNNpp
 
         self.word_embedding = WordEmbedding(vocab_size, embedding_dim, pretrained_embeddings=pretrained_embeddings,
                                             freeze_embeddings=freeze_embeddings, padding_idx=0)
@@ -50,10 +52,21 @@ class SimpleSiamese(nn.Module):
         """u_revs / i_revs [bz, rv_num, rv_len] int64, word masks [bz, rv_num, rv_len], review masks [bz, rv_num], ids [bz]
         -> (out_logits [bz], None, None), as the reference returns."""
         bz = u_revs.shape[0]
+        stacked = None
+        if self.validate_ids:
+            same = u_revs.shape == i_revs.shape
+            outs = RF.sanitize_ids([(u_revs, self.vocab_size, 0), (i_revs, self.vocab_size, 0), (u_ids, self.user_size, 0),
+                                    (i_ids, self.item_size, 0)], stack_first_two=same)
+            if same:
+                stacked, u_ids, i_ids = outs
+                u_revs, i_revs = stacked[:bz], stacked[bz:]
+            else:
+                u_revs, i_revs, u_ids, i_ids = outs
         if u_revs.shape == i_revs.shape and u_rev_word_masks.shape == i_rev_word_masks.shape and u_rev_masks.shape == i_rev_masks.shape:
             # the towers share every layer (simple_siamese.py:58-77: one word_embedding, latent_transform_layer, review_att_layer): both sides go through each kernel as ONE batch of
             # 2*bz rows, user rows first, and the head takes the stacked features whole
-            u_rev_feat = self._tower(RF.stack_rows(u_revs, i_revs), RF.stack_rows(u_rev_word_masks, i_rev_word_masks),
+            u_rev_feat = self._tower(stacked if stacked is not None else RF.stack_rows(u_revs, i_revs),
+                                     RF.stack_rows(u_rev_word_masks, i_rev_word_masks),
                                      RF.stack_rows(u_rev_masks, i_rev_masks))
             i_rev_feat = None
         else:

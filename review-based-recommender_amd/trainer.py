@@ -14,7 +14,10 @@ tables (experiment.py:101-123), the step (train_deepconn_pp.py:161-168), the log
 (:226-232).  Deliberate differences: `kernel_sizes` / `hidden_dim` come from the config unless
 `--reference-quirks` restores the trainers' hard-coded `[3]` / 150 (train_deepconn_pp.py:125,
 train_narre.py:124-125); `parallel: true` means one process per GPU with an RCCL gradient all-reduce
-(launch with torch.distributed.run) instead of nn.DataParallel; running loss / gnorm are accumulated on
+(launch with torch.distributed.run) instead of nn.DataParallel -- with nn.DataParallel's semantics: `batch_size` is the
+GLOBAL batch, split evenly over the ranks (train_deepconn_pp.py:130 scatters each batch over the GPUs), every epoch
+draws a new permutation (sampler.set_epoch), and validation shards the examples without padding so each one counts
+once in the all-reduced RMSE; running loss / gnorm are accumulated on
 the device and read back only at log lines (the reference calls loss.item() twice per step); the config key
 `fast_step: true` switches to HipClipAdam and hipGraph replay of the step (train_step.py).
 """
@@ -31,6 +34,7 @@ import torch
 import torch.nn as nn
 
 from . import data as D
+from . import functional as RF
 from .train_step import GraphedTrainStep, make_optimizer, train_step
 
 
@@ -52,7 +56,45 @@ class EarlyStop(Exception):
 
 DEFAULTS = dict(log_dir="logs", dataset="dataset", log=True, log_idx=500, verbose=False, parallel=False, epochs=64,
                 batch_size=50, lr=0.002, max_grad_norm=5.0, patience=5, dropout=0.5, arch="CNN", use_pretrain=False,
-                num_workers=0, device_cache=True, fast_step=False)
+                num_workers=0, fast_step=False, shuffle=True, seed=0, record_steps=False)
+
+
+class _ShardSampler(torch.utils.data.Sampler):
+    """Validation shard of one rank: examples rank, rank + world, ... in order -- no padding, so every example is seen by
+    exactly one rank (DistributedSampler(drop_last=False) repeats examples to even the shards out, which would count them
+    twice in the all-reduced squared error)."""
+
+    def __init__(self, n: int, rank: int, world: int):
+        self.idx = list(range(rank, n, world))
+
+    def __iter__(self):
+        return iter(self.idx)
+
+    def __len__(self):
+        return len(self.idx)
+
+
+def make_loaders(train_set, valid_set, args, rank: int, world: int):
+    """(train_loader, valid_loader, train_sampler, valid_sampler, per-rank batch) with nn.DataParallel's semantics on
+    `world` ranks: `args.batch_size` is the global batch (train_deepconn_pp.py:130 scatters it over the GPUs), the training
+    sampler reshuffles every epoch once the caller runs set_epoch(epoch), validation is sharded without padding."""
+    parallel = world > 1
+    if parallel and args.batch_size % world:
+        raise ValueError(f"batch_size {args.batch_size} does not split evenly over {world} ranks")
+    rank_batch = args.batch_size // world if parallel else args.batch_size
+    train_sampler = valid_sampler = None
+    if parallel:
+        train_sampler = torch.utils.data.distributed.DistributedSampler(
+            train_set, num_replicas=world, rank=rank, shuffle=bool(args.shuffle), seed=int(args.seed), drop_last=True)
+        valid_sampler = _ShardSampler(len(valid_set), rank, world)
+    gen = torch.Generator().manual_seed(int(args.seed))
+    train_loader = torch.utils.data.DataLoader(
+        train_set, batch_size=rank_batch, shuffle=bool(args.shuffle) and train_sampler is None, sampler=train_sampler,
+        collate_fn=train_set.collate_fn, num_workers=args.num_workers, drop_last=train_sampler is not None, generator=gen)
+    valid_loader = torch.utils.data.DataLoader(
+        valid_set, batch_size=rank_batch, shuffle=False, sampler=valid_sampler, collate_fn=valid_set.collate_fn,
+        num_workers=args.num_workers)
+    return train_loader, valid_loader, train_sampler, valid_sampler, rank_batch
 
 
 class ReviewExperiment:
@@ -88,15 +130,22 @@ class ReviewExperiment:
         self.valid_set = cls(args.data_dir, "valid", **kw)
         self._make_dir()
         self.build_model()
+        # both splits were range-checked against their tables when they were loaded (data.validate_ranges): the per-forward
+        # device-side check (one launch) is not needed on top
+        self.model.validate_ids = False
+        self.step_losses = [] if args.record_steps else None      # per-step training loss (device scalars), for tests
+        self.parallel = self.world > 1 and bool(args.parallel)
+        (self.train_loader, self.valid_loader, self.train_sampler, self.valid_sampler,
+         self.rank_batch) = make_loaders(self.train_set, self.valid_set, args, self.rank, self.world if self.parallel else 1)
         # fast_step: clip + Adam as two HIP launches and the whole step replayed as a hipGraph for full-size batches
         # (same update rule; see train_step.HipClipAdam / GraphedTrainStep)
         self.optimizer = make_optimizer(self.model, lr=args.lr, hip_clip_adam=bool(args.fast_step))
         self._graphed = None
         self._graphed_key = None
         self.loss_func = nn.MSELoss()
-        if self.world > 1 and args.parallel:
+        if self.parallel:
             from .distributed import GradAllReduce, broadcast_parameters, init_process_group_from_env
-            init_process_group_from_env("nccl")
+            init_process_group_from_env(os.environ.get("RBR_TRAINER_BACKEND", "nccl"))
             broadcast_parameters(self.model)
             self.grad_sync = GradAllReduce(self.model)
         self.print_args()
@@ -181,15 +230,6 @@ class ReviewExperiment:
         self.model.to(self.device)
 
     # ------------------------------------------------------------------ data
-    def _loader(self, ds, shuffle):
-        sampler = None
-        if self.world > 1 and self.args.parallel:
-            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=self.world, rank=self.rank,
-                                                                      shuffle=shuffle, drop_last=shuffle)
-        return torch.utils.data.DataLoader(ds, batch_size=self.args.batch_size, shuffle=shuffle and sampler is None,
-                                           sampler=sampler, collate_fn=ds.collate_fn, num_workers=self.args.num_workers,
-                                           drop_last=bool(sampler is not None and shuffle))
-
     def _to_device(self, batch):
         batch = [t.to(self.device, non_blocking=True) for t in batch]
         if self.kind == "simple_siamese":
@@ -202,7 +242,9 @@ class ReviewExperiment:
     # ------------------------------------------------------------------ loops (train_deepconn_pp.py:143-232)
     def train_one_epoch(self, epoch: int):
         a = self.args
-        loader = self._loader(self.train_set, shuffle=True)
+        loader = self.train_loader
+        if self.train_sampler is not None:
+            self.train_sampler.set_epoch(epoch)          # a new permutation every epoch, the same one on every rank
         loss_sum = torch.zeros((), device=self.device)
         sq_err = torch.zeros((), device=self.device)
         gnorm = torch.zeros((), device=self.device)
@@ -213,13 +255,16 @@ class ReviewExperiment:
             inputs, ratings = self._to_device(batch)
             loss, gnorm = self._step(inputs, ratings)
             self.updates += 1
+            if self.step_losses is not None:
+                self.step_losses.append(loss.detach().clone())
             loss_sum += loss
             sq_err += loss * ratings.size(0)
             steps += 1
             count += ratings.size(0)
             if (i + 1) % a.log_idx == 0 and a.log:
                 elapsed = (time.time() - start) / a.log_idx
-                rmse = math.sqrt(float(sq_err) / count)
+                rmse = math.sqrt(float(sq_err) / count)       # the step's synchronisation point (the reference syncs every step)
+                RF.check_id_errors(self.device)               # an id outside its table -> IndexError, as nn.Embedding raises
                 self.print_write_to_log(
                     "epoch: {}/{}, step: {}/{}, loss: {:.3f}, rmse: {:.3f}, lr: {}, gnorm: {:3f}, time: {:.3f}".format(
                         epoch, a.epochs, i + 1, len(loader), float(loss_sum) / steps, rmse,
@@ -245,7 +290,7 @@ class ReviewExperiment:
         return loss, gnorm
 
     def valid_one_epoch(self):
-        loader = self._loader(self.valid_set, shuffle=False)
+        loader = self.valid_loader
         sq_err = torch.zeros((), device=self.device, dtype=torch.float64)
         loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
         count = torch.zeros((), device=self.device, dtype=torch.float64)
@@ -261,11 +306,14 @@ class ReviewExperiment:
                 loss_sum += loss.double()
                 count += ratings.size(0)
                 steps += 1
-        if self.world > 1 and self.args.parallel:
+        if self.parallel:
             import torch.distributed as dist
             for t in (sq_err, count):
                 dist.all_reduce(t)
+        self.valid_count = int(count)                     # examples that entered the RMSE: len(valid_set), each once
         rmse = math.sqrt(float(sq_err) / max(float(count), 1.0))
+        self.last_valid_rmse = rmse
+        RF.check_id_errors(self.device)
         if rmse < self.best_rmse:
             self.best_rmse = rmse
             self.save("best_model.pt")

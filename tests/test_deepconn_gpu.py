@@ -135,28 +135,70 @@ def test_cpu_tensors_are_rejected():
                    [p["ngram.feature_layer.0.list_of_conv1d.0.weight"]], [p["ngram.feature_layer.0.list_of_conv1d.0.bias"]])
 
 
-def test_dedup_by_id_equals_plain_path(conv_mode):
-    """f-3: encoding each distinct user / item document once gives the same predictions and gradients."""
-    cfg = synth.DEEPCONN_CFGS["small"]
+def _dup_batch(cfg):
+    """A batch that hits few users / items, each always with the same document (as the doc split guarantees)."""
     b = synth.deepconn_batch(cfg, 1)
-    # make the batch hit few users / items, each always with the same document (as the doc split guarantees)
     u_ids = torch.tensor([1, 2, 1, 3, 2, 1, 3, 3]); i_ids = torch.tensor([4, 4, 5, 5, 4, 6, 6, 4])
     b["u_ids"], b["i_ids"] = u_ids, i_ids
     b["u_docs"], b["u_masks"] = b["u_docs"][u_ids], b["u_masks"][u_ids]
     b["i_docs"], b["i_masks"] = b["i_docs"][i_ids], b["i_masks"][i_ids]
+    return b
+
+
+def test_dedup_by_id_matches_the_oracle_on_the_duplicated_batch(conv_mode):
+    """f-3: with dedup_by_id each distinct user / item document is encoded once; predictions, loss and EVERY gradient must
+    equal the CPU oracle run on the full duplicated batch (the reference re-encodes per pair, deepconn.py:46-47)."""
+    from oracle import ref_cpu as O
+    cfg = synth.DEEPCONN_CFGS["small"]
+    b = _dup_batch(cfg)
+    keys = ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids")
+    sd = synth.deepconn_params(cfg, 0)
+    hist = O.train_steps(sd, lambda q: O.deepconn_forward(q, *[b[k] for k in keys]), b["ratings"], n_steps=1)[0]
     args, ratings = _batch(b)
-    outs = []
-    for dedup in (False, True):
-        model = _model(cfg, synth.deepconn_params(cfg, 0))
-        model.dedup_by_id = dedup
-        model.train()
-        pred = model(*args)
-        torch.nn.functional.mse_loss(pred, ratings).backward()
-        outs.append((pred.detach(), {k: p.grad.clone() for k, p in model.named_parameters()}))
-    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-6
-    for k in outs[0][1]:
-        ref = outs[0][1][k]
-        assert float((ref - outs[1][1][k]).abs().max()) <= 1e-6 + 1e-4 * float(ref.abs().max()), k
+    model = _model(cfg, sd)
+    model.dedup_by_id = True
+    model.train()
+    pred = model(*args)
+    loss = torch.nn.functional.mse_loss(pred, ratings)
+    loss.backward()
+    assert max_err(pred.detach().cpu().numpy(), hist["pred"].numpy()) <= 1e-5
+    assert abs(float(loss) - float(hist["loss"])) <= 1e-5
+    for k, p in model.named_parameters():
+        ref = hist["grads"][k]
+        scale = float(ref.norm()) + 1e-12
+        assert float((p.grad.cpu() - ref).abs().max()) <= 2e-6 + 2e-4 * scale, k
+
+
+def test_dedup_step_is_graph_capturable_and_skips_repeated_documents():
+    """The first-occurrence pass is a device kernel with static shapes (no torch.unique, no host sync): the dedup step
+    replays as a hipGraph on new batches, and the blanked repeated rows are the ones that are not first occurrences."""
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
+    cfg = synth.DEEPCONN_CFGS["small"]
+    b = _dup_batch(cfg)
+    args, ratings = _batch(b)
+    first, masks = RF.dedup_rows(args[4], args[5], cfg["U"], cfg["I"], torch.cat([args[2], args[3]]), cfg["L"])
+    B = cfg["B"]
+    assert first.tolist() == [0, 1, 0, 3, 1, 0, 3, 3] + [B + x for x in [0, 0, 2, 2, 0, 5, 5, 0]]
+    keep = torch.tensor([f == r for r, f in enumerate(first.tolist())], device=masks.device)
+    assert not masks[~keep].any() and torch.equal(masks[keep], torch.cat([args[2], args[3]])[keep])
+
+    sd = synth.deepconn_params(cfg, 0)
+    m_g, m_e = _model(cfg, sd), _model(cfg, sd)
+    m_g.dedup_by_id = m_e.dedup_by_id = True
+    m_g.train(); m_e.train()
+    o_g, o_e = make_optimizer(m_g, hip_clip_adam=True), make_optimizer(m_e, hip_clip_adam=True)
+    stepper = GraphedTrainStep(m_g, o_g, args, ratings)
+    for step in range(3):
+        b2 = _dup_batch(cfg)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(step))      # another duplicate pattern every step
+        for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids", "ratings"):
+            b2[k] = b2[k][perm]
+        a2, r2 = _batch(b2)
+        lg, _, _ = stepper(a2, r2)
+        le, _, _ = train_step(m_e, o_e, a2, r2)
+        torch.cuda.synchronize()
+        assert abs(float(lg) - float(le)) <= 1e-5 * max(1.0, abs(float(le))), (step, float(lg), float(le))
 
 
 def test_dataparallel_wrapper_does_not_crash():
