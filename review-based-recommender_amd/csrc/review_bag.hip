@@ -294,11 +294,13 @@ extern "C" int rbr_review_bag_fwd(int32_t n_rev, int32_t T, int32_t D, const int
 }
 
 // workspace of the backward: keys | vals (in) | keys | vals (sorted) | rocPRIM temporary storage
+// (the larger of the radix sort's and the merge sort's: which of the two runs is decided per call, see rbr_review_bag_bwd)
 static size_t bag_sort_temp_bytes(long n_pos) {
-    size_t bytes = 0;
+    size_t radix = 0, merge = 0;
     int* nul = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)n_pos, 0, 32, (hipStream_t)0);
-    return bytes;
+    (void)rocprim::radix_sort_pairs(nullptr, radix, nul, nul, nul, nul, (size_t)n_pos, 0, 32, (hipStream_t)0);
+    (void)rocprim::merge_sort(nullptr, merge, nul, nul, nul, nul, (size_t)n_pos, rocprim::less<int>(), (hipStream_t)0);
+    return std::max(radix, merge);
 }
 
 extern "C" size_t rbr_review_bag_bwd_ws_bytes(int32_t n_rev, int32_t T) {
@@ -316,15 +318,12 @@ extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V
     const long n_pos = (long)n_rev * T;
     if (n_pos >= (1L << 31)) { set_error("too many token positions"); return RBR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    if (n_pos > (1L << 20)) {
-        // above rocPRIM's merge-sort limit the radix sort re-initialises its state with hipMemsetAsync; memset nodes of this
-        // kind faulted when a recorded hipGraph was replayed (ROCm 7.2): refuse to be recorded rather than fault later
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-            set_error("review_bag backward over %ld token positions cannot be recorded into a hipGraph (sort uses memset nodes)", n_pos);
-            return RBR_ERR_UNSUPPORTED;
-        }
-    }
+    // rocPRIM's radix sort re-initialises its state with hipMemsetAsync (device_radix_sort.hpp:122,251) whenever it takes
+    // its onesweep path, and memset NODES fault when a recorded hipGraph is replayed on this stack (DESIGN.md section 4,
+    // hipGraph).  While the stream is being captured the occurrences are therefore sorted with rocprim::merge_sort, which
+    // issues kernels only -- a choice that does not depend on where rocPRIM switches algorithms.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     const size_t arr = (((size_t)n_pos * sizeof(int)) + 255) & ~(size_t)255;
     char* base = static_cast<char*>(ws);
     int* keys_in = reinterpret_cast<int*>(base);
@@ -339,8 +338,12 @@ extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V
     RBR_CHECK_LAUNCH("review_bag keys launch");
     int bits = 1;
     while ((1L << bits) <= V) ++bits;    // keys are in [0, V]
-    if (int e = check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys, vals_in, vals, (size_t)n_pos, 0, bits, st),
-                          "review_bag radix sort"))
+    if (capturing) {
+        if (int e = check_hip(rocprim::merge_sort(temp, temp_bytes, keys_in, keys, vals_in, vals, (size_t)n_pos, rocprim::less<int>(), st),
+                              "review_bag merge sort"))
+            return e;
+    } else if (int e = check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys, vals_in, vals, (size_t)n_pos, 0, bits, st),
+                                 "review_bag radix sort"))
         return e;
     const long n_waves = (n_pos + kBagChunk - 1) / kBagChunk;
     hipLaunchKernelGGL(bag_bwd_sorted_kernel, dim3((unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG)), dim3(256), 0, st, n_pos, T,

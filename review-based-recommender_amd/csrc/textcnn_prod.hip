@@ -483,6 +483,8 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
     const int D = A.D, nq4 = D >> 2;
     const unsigned long long lt = (1ull << lane) - 1;
     const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);
+    __shared__ int s_poison;      // a non-finite tap (NaN / inf gradient on some rank): the token's row becomes NaN, as the dense
+                                  // all-reduce would propagate it, instead of vanishing in the float -> fixed-point conversion
     for (int v = blockIdx.x; v < V; v += gridDim.x) {
         const int s1 = start1[v];                        // workgroup-uniform
         float* drow = dtable + (long)v * D;
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
         }
         const int s = s1 - 1, e = end[v];
         for (int k = tid; k < A.KG; k += 256) s_g[k] = 0;
+        if (tid == 0) s_poison = 0;
         __syncthreads();
         for (int i0 = s; i0 < e; i0 += 256 * 8) {          // 8 coalesced payload reads in flight per thread
             unsigned long long pl[8];
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
             for (int u = 0; u < 8; ++u) {
                 if (pl[u] != ~0ull) {
                     const float x = __int_as_float((int)(unsigned)(pl[u] & 0xffffffffu));
+                    if (!(fabsf(x) <= 8.0e6f)) { s_poison = 1; continue; }     // NaN, inf, or beyond the fixed-point range
                     const long long q = __float2ll_rn(x * kTapScale);
                     atomicAdd(reinterpret_cast<unsigned long long*>(s_g) + (unsigned)(pl[u] >> 32), (unsigned long long)q);
                 }
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
             f32x4 r = *reinterpret_cast<const f32x4*>(s_part + 4 * q4);
 #pragma unroll
             for (int w = 1; w < kWavesPerWG; ++w) r += *reinterpret_cast<const f32x4*>(s_part + w * D + 4 * q4);
+            if (s_poison) { const float nan = __builtin_nanf(""); r = f32x4{nan, nan, nan, nan}; }
             *reinterpret_cast<f32x4*>(drow + 4 * q4) = r;
         }
         __syncthreads();

@@ -20,8 +20,17 @@
 // f32 MFMA kernel.  What bounds it is the CU's LDS-fill path, not the MFMA pipe and not L2: a stage is 20 one-KiB LDS-DMA
 // instructions per workgroup for 4 x 24 MFMAs, and a CU retires ~1 KiB per 35 cycles whatever the source (with every fill
 // reading one cached 16-byte line and no stores the bf16 kernel still takes 24 us = 381 k instructions / 256 CUs x 35
-// cycles).  The way below that is weights stationary in registers (one 32-column tile x all K per wave = 228 VGPRs at
-// D = 300) so that only token rows move: DESIGN.md section 8.
+// cycles).  Tried and dropped (round 2, each correct to the same 1.3e-6):
+//  * weights stationary in registers (one 32-column tile x all 19 K steps per wave = 228 VGPRs, one wave per SIMD, rows
+//    split into planes once per workgroup and shared through LDS, work balanced by row ranges): 60 % fewer fills -- and
+//    77 us.  With one wave per SIMD nothing hides the per-unit chain (fill issue -> 7 LDS reads -> split -> plane stores
+//    -> barrier, ~570 cycles for 384 MFMA cycles) even with the MFMAs interleaved by sched_group_barrier and the second
+//    step's MFMAs deferred across the barrier; two waves per SIMD do not fit beside 228 weight registers;
+//  * two dedicated loader waves per workgroup issuing all 20 fills of a stage (the MFMA waves issue none): 86 us -- the
+//    fills' cost is not their issue slot in the MFMA waves but the LDS side: a stage pair writes 80 KiB into LDS by DMA and
+//    reads 112 KiB back per CU, which at the DMA's ~64 B/clk into LDS is as long as the stage pair's 1536 MFMA cycles;
+//  * 256-row x 128-column items (8 waves, weights shared by twice the rows, two stages): 78 us.
+// DESIGN.md section 4.
 #include "rbr_common.h"
 
 #include <cstdlib>

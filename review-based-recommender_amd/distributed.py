@@ -66,14 +66,32 @@ class TapExchange:
         self.desc = self.weights = None
         self.calls = 0
         self.captured = None    # (desc, weights) of a backward that was recorded into a hipGraph
+        self.dense_fallbacks = 0   # conv calls over this table that went the dense all-reduce way (second call of a step,
+                                   # unsupported shape): the advertised exchange was not used for them
 
     # ---- called from functional._TextCNN.backward
     def accepts(self, table: torch.Tensor, desc, L_) -> bool:
         import ctypes as C
-        if table.data_ptr() != self.table.data_ptr() or self.calls > 0:
+        if table.data_ptr() != self.table.data_ptr():
+            return False             # a foreign table (functional routes by table, so this is a stale registration)
+        if self.calls > 0:
             self.calls += 1          # a second conv over the table in this step: this one goes the dense way
+            self._note_fallback("a second conv over the word table in one step")
             return False
-        return L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc), self.world) > 0
+        ok = L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc), self.world) > 0
+        if not ok:
+            self._note_fallback("the conv shape is outside what the tap rebuild supports")
+        return ok
+
+    def _note_fallback(self, why: str) -> None:
+        self.dense_fallbacks += 1
+        if self.dense_fallbacks == 1 and self.rank == 0:
+            print(f"[TapExchange] dense all-reduce of the word-table gradient instead of the tap exchange: {why}", flush=True)
+
+    def close(self) -> None:
+        """Uninstalls the sink (the table's backward produces its dense gradient again)."""
+        from . import functional as RF
+        RF.set_tap_sink(None, self.table)
 
     def local_buffers(self, n: int, dev):
         if self.tok is None or self.n != n or self.tok.device != dev:
@@ -146,7 +164,7 @@ class GradAllReduce:
         if tap_table is not None and dist.get_world_size(group) > 1:
             from . import functional as RF
             self.tap = TapExchange(tap_table, group)
-            RF.set_tap_sink(self.tap)
+            RF.set_tap_sink(self.tap)          # keyed by the table: other models' convs never reach this sink
         self.group = group
         self.world = dist.get_world_size(group)
         self.comm_dtype = comm_dtype   # e.g. torch.bfloat16 halves the table bucket; None = exact fp32
@@ -200,6 +218,20 @@ class GradAllReduce:
                     p.grad.mul_(inv)
         if tap_pending:
             self.tap.finish()
+
+
+    def close(self) -> None:
+        """Removes the tap sink this hook installed (no-op for the dense exchange)."""
+        if self.tap is not None:
+            self.tap.close()
+            self.tap = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 def shard_batch(tensors, rank: int, world: int):

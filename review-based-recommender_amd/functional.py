@@ -27,7 +27,7 @@ def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 # Data-parallel tap exchange (distributed.TapExchange): when a sink is installed, the backward of an un-gated conv over the
 # sink's word table emits its (token, value) taps instead of the dense table gradient; the sink rebuilds the averaged
 # gradient of all ranks after an all-gather of the taps (rbr_textcnn_bwd_taps / rbr_textcnn_dtable_from_taps).
-_TAP_SINK = None
+_TAP_SINKS: dict = {}       # word-table data_ptr -> sink: several models (an eval / EMA copy, a second trainer) can coexist
 
 
 def set_prod_precision(name: Optional[str]) -> None:
@@ -128,9 +128,16 @@ def dedup_rows(u_ids: torch.Tensor, i_ids: torch.Tensor, user_size: int, item_si
     return first, out.view(torch.bool)
 
 
-def set_tap_sink(sink) -> None:
-    global _TAP_SINK
-    _TAP_SINK = sink
+def set_tap_sink(sink, table: Optional[torch.Tensor] = None) -> None:
+    """Installs `sink` for the word table it exchanges (sink.table); set_tap_sink(None, table) removes that table's sink,
+    set_tap_sink(None) removes all of them."""
+    if sink is None:
+        if table is None:
+            _TAP_SINKS.clear()
+        else:
+            _TAP_SINKS.pop(table.data_ptr(), None)
+        return
+    _TAP_SINKS[sink.table.data_ptr()] = sink
 
 
 class _TextCNN(torch.autograd.Function):
@@ -249,7 +256,7 @@ class _TextCNN(torch.autograd.Function):
         d_feat = d_feat.contiguous()
         dWs = [torch.empty_like(w) for w in ws]
         dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
-        sink = _TAP_SINK
+        sink = _TAP_SINKS.get(table.data_ptr())          # only the sink installed for THIS table ever sees the call
         use_taps = (sink is not None and need_table and gate is None and sink.accepts(table, desc, L_))
         if use_taps:
             need_table = False          # table.grad is produced by the exchange, after the all-gather of the taps
