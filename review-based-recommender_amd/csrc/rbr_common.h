@@ -85,7 +85,8 @@ int prod_precision();
 bool prod_b16_applicable(const rbr_textcnn_desc* d);
 int prod_b16_groups(int cp_real);
 size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real);
-int prod_b16_pack(const rbr_textcnn_desc* d, const float* const* W, void* bimg, hipStream_t st);
+struct B16Pack;
+B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d);     // textcnn_b16.h
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
                   const float* table, const void* bimg, float* T, hipStream_t st);
 // Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not

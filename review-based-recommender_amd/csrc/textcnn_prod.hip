@@ -21,6 +21,7 @@
 // Backward (rbr_textcnn_bwd_dtable_prod): zero_g_rows, build_g (G[token][(tap, channel)] += g, d(gate) from T),
 //   g_times_w (dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product; absent tokens' rows zeroed).
 #include "rbr_common.h"
+#include "textcnn_b16.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
                                                            const unsigned char* __restrict__ used, int* __restrict__ row_of_token,
                                                            long long* __restrict__ tok_of_row, unsigned char* __restrict__ row_mask,
                                                            int* __restrict__ counter, float* __restrict__ zero_row, int pitch,
-                                                           const PtrArray W, float* __restrict__ packed, float* __restrict__ WT) {
+                                                           const PtrArray W, float* __restrict__ packed, float* __restrict__ WT,
+                                                           const B16Pack JB, unsigned char* __restrict__ bimg) {
     if ((int)blockIdx.x < nb_compact) {
         if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
             for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
@@ -117,8 +119,11 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
     const int DC = P.DC;
     const long n_img = packed != nullptr ? (long)P.nchunks * P.tiles_total * kTile * DC : 0;     // bf16-plane GEMM: no f32 image
     const long n_wt = (long)J.cp_real * J.D;
-    for (long idx = b0 * 256 + threadIdx.x; idx < n_img + n_wt; idx += nb * 256) {
-        if (idx < n_img) {
+    const long n_b16 = bimg != nullptr ? b16_pack_items(JB) : 0;                                 // bf16-plane GEMM: its weight planes
+    for (long idx = b0 * 256 + threadIdx.x; idx < n_img + n_wt + n_b16; idx += nb * 256) {
+        if (idx >= n_img + n_wt) {
+            b16_pack_item(JB, W, bimg, idx - n_img - n_wt);
+        } else if (idx < n_img) {
             long r = idx;
             const int dd = (int)(r % DC); r /= DC;
             const int slot = (int)(r % kTile); r /= kTile;
@@ -950,13 +955,16 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
     const int nb_compact = (d->V + 255) / 256;
     const bool b16 = prod_b16_applicable(d);
-    const long n_pack = (b16 ? 0 : (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC) + (long)S.A.cp_real * d->D;
+    B16Pack JB{};
+    if (b16) JB = prod_b16_pack_job(d);
+    const long n_pack = (b16 ? (long)JB.ngroups * JB.nchunks * 4 * 64 : (long)S.pp[0].nchunks * S.pp[0].tiles_total * kTile * S.pp[0].DC) +
+                        (long)S.A.cp_real * d->D;
     const int nb_pack = (int)std::min<long>((n_pack + 255) / 256, 2048);
+    // (bf16-plane GEMM: the weight planes in MFMA-fragment order instead of the f32 tile image)
     hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, S.Lo.cap, S.used,
                        S.row_of_token, S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch, wp,
-                       b16 ? nullptr : S.packed_p, S.WT);
+                       b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
-    if (b16) return prod_b16_pack(d, W, S.base + S.Lo.bimg, st);      // weight planes in MFMA-fragment order
     return 0;
 }
 

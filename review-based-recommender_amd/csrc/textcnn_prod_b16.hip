@@ -32,25 +32,11 @@
 //  * 256-row x 128-column items (8 waves, weights shared by twice the rows, two stages): 78 us.
 // DESIGN.md section 4.
 #include "rbr_common.h"
+#include "textcnn_b16.h"
 
 #include <cstdlib>
 
 namespace rbr {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kB16Waves = 4, kB16Stages = 4;
-constexpr int kB16BM = 32 * kB16Waves, kB16BN = 128, kB16KC = 16, kB16Threads = 64 * kB16Waves;
-constexpr int kB16ABytes = kB16BM * kB16KC * 4;                 // 8 KiB
-constexpr int kB16BFrag = 1024;                                 // one (tile, plane) fragment: 64 lanes x 16 B
-constexpr int kB16BBytes = (kB16BN / 32) * 3 * kB16BFrag;       // 12 KiB
-constexpr int kB16Lds = kB16Stages * (kB16ABytes + kB16BBytes); // 80 KiB: two workgroups per CU
-static_assert(kB16Waves == 4 && kB16Stages == 4, "the fill schedule below (5 LDS-DMA instructions per wave and stage) assumes 4 x 4");
 
 __device__ float g_b16_zero[4];      // LDS-DMA source of rows / columns outside the problem (zero-initialised, never written)
 
@@ -62,25 +48,6 @@ struct B16Gemm {
     float* T;
     int cap, D, pitch, ngroups, nchunks;
 };
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);       // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, v);
-}
-
-// (x0, x1) -> packed bf16 pairs of the three planes; the residues x - hi and (x - hi) - mid are exact in f32
-template <int NPLANES>
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = pack_bf16(x0, x1);
-    if (NPLANES >= 2) {
-        const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-        mid = pack_bf16(r0, r1);
-        if (NPLANES >= 3) {
-            const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
-            lo = pack_bf16(s0, s1);
-        }
-    }
-}
 
 __device__ __forceinline__ void b16_dma16(const void* gsrc, void* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -223,53 +190,6 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
     }
 }
 
-// Weight planes of the token-product GEMM in fragment order (see the header); element (lane l, j) of fragment
-// (group, step, tile, plane) is plane(Wprod[k = step*16 + 8*(l >> 5) + j][column = group*128 + tile*32 + (l & 31)]).
-struct B16Pack {
-    int n_widths, D, cp_real, ngroups, nchunks;
-    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
-};
-
-__device__ __forceinline__ float b16_prod_weight(const B16Pack& J, const PtrArray& W, int pc, int d) {
-    int w = 0;
-#pragma unroll
-    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
-        if (k < J.n_widths && pc >= J.poff[k]) w = k;
-    const int rel = pc - J.poff[w];
-    const int j = rel / J.ch[w], cl = rel - j * J.ch[w];
-    return W.p[w][((long)cl * J.D + d) * J.kz[w] + j];
-}
-
-__global__ __launch_bounds__(256) void b16_pack_kernel(const B16Pack J, const PtrArray W, unsigned char* __restrict__ bimg) {
-    const long total = (long)J.ngroups * J.nchunks * 4 * 64;           // one thread per (fragment triple, lane)
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        long r = idx;
-        const int l = (int)(r & 63); r >>= 6;
-        const int t = (int)(r & 3); r >>= 2;
-        const int c = (int)(r % J.nchunks);
-        const int ng = (int)(r / J.nchunks);
-        const int col = ng * kB16BN + t * 32 + (l & 31);
-        const int k0 = c * kB16KC + 8 * (l >> 5);
-        u32x4 ph, pm, pl;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = k0 + 2 * q + e;
-                x[e] = (col < J.cp_real && k < J.D) ? b16_prod_weight(J, W, col, k) : 0.f;
-            }
-            unsigned a, b, cc;
-            split_pair<3>(x[0], x[1], a, b, cc);
-            ph[q] = a; pm[q] = b; pl[q] = cc;
-        }
-        unsigned char* dst = bimg + (((size_t)ng * J.nchunks + c) * 4 + t) * 3 * kB16BFrag + l * 16;
-        *reinterpret_cast<u32x4*>(dst) = ph;
-        *reinterpret_cast<u32x4*>(dst + kB16BFrag) = pm;
-        *reinterpret_cast<u32x4*>(dst + 2 * kB16BFrag) = pl;
-    }
-}
-
 // ---------------------------------------------------------------------------------- host side
 static int g_prod_precision = -1;        // -1: RBR_PROD_PRECISION env or the default (bf16x3)
 
@@ -292,7 +212,7 @@ size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real) {
     return (size_t)prod_b16_groups(cp_real) * ((d->D + kB16KC - 1) / kB16KC) * kB16BBytes;
 }
 
-int prod_b16_pack(const rbr_textcnn_desc* d, const float* const* W, void* bimg, hipStream_t st) {
+B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d) {
     B16Pack J{};
     J.n_widths = d->n_widths; J.D = d->D;
     int o = 0;
@@ -300,13 +220,7 @@ int prod_b16_pack(const rbr_textcnn_desc* d, const float* const* W, void* bimg, 
     J.cp_real = o;
     J.ngroups = prod_b16_groups(o);
     J.nchunks = (d->D + kB16KC - 1) / kB16KC;
-    PtrArray wp{};
-    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
-    const long total = (long)J.ngroups * J.nchunks * 4 * 64;
-    hipLaunchKernelGGL(b16_pack_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, J, wp,
-                       static_cast<unsigned char*>(bimg));
-    RBR_CHECK_LAUNCH("textcnn b16 pack launch");
-    return 0;
+    return J;
 }
 
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
