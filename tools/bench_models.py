@@ -16,7 +16,7 @@ def quiet(fn, *a):
         return fn(*a)
 
 
-def run(name, model, args, ratings, B, flops_fwd):
+def run(name, model, args, ratings, B, flops_fwd, bytes_fwd_per_pair):
     model.train()
     graph_ms = None
     if "--no-graph" not in sys.argv:      # the step replayed as a hipGraph (how bench.py times DeepCoNN)
@@ -58,6 +58,10 @@ def run(name, model, args, ratings, B, flops_fwd):
                       "train_ms": round(step * 1e3, 3), "train_pairs_per_s": round(B / step, 1),
                       "fwd_ms": round(fwd * 1e3, 3), "fwd_pairs_per_s": round(B / fwd, 1),
                       "fwd_TFLOPs_algorithmic": round(flops_fwd / fwd / 1e12, 2),
+                      # algorithmic bytes of one forward (ids + masks + gathered rows) against the HBM peak
+                      "roofline": {"bound": "hbm", "achieved": round(bytes_fwd_per_pair * B / fwd / 1e9, 1), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(bytes_fwd_per_pair * B / fwd / 8e12, 4),
+                                   "bytes_per_pair": bytes_fwd_per_pair, "what": "eval forward, whole model (no single dominant kernel)"},
                       "kernels_ms": {k: round(v[1], 4) for k, v in ks.items()}}))
 
 
@@ -69,7 +73,7 @@ if which in ("narre", "all"):
     m.load_state_dict(synth.narre_params(c, 0)); m.to(dev)
     b = synth.narre_batch(c, 1)
     args = tuple(b[k].to(dev) for k in ("u_text", "i_text", "u_masks", "i_masks", "u_id", "i_id", "reuid", "reiid"))
-    run("NARRE cfg3 (B=256, 10x50 tok/side, D=300, fp32)", m, args, b["ratings"].to(dev), c["B"], 270.0e6 * c["B"])
+    run("NARRE cfg3 (B=256, 10x50 tok/side, D=300, fp32)", m, args, b["ratings"].to(dev), c["B"], 270.0e6 * c["B"], 2 * c["R"] * c["T"] * (8 + 1 + 4 * c["D"]) + 2 * c["R"] * 8)
     if "--cpu" in sys.argv:
         from oracle import ref_cpu as O
         p = synth.narre_params(c, 0)
@@ -83,7 +87,7 @@ if which in ("datt", "all"):
     m.load_state_dict(synth.datt_params(c, 0, table_scale=0.3)); m.to(dev)
     b = synth.datt_batch(c, 1)
     args = (b["u_docs"].to(dev), b["i_docs"].to(dev))
-    run("D-ATT cfg4 (B=512, 2x1024 tok, E=100, fp32)", m, args, b["ratings"].to(dev), c["B"], 453.3e6 * c["B"])
+    run("D-ATT cfg4 (B=512, 2x1024 tok, E=100, fp32)", m, args, b["ratings"].to(dev), c["B"], 453.3e6 * c["B"], 2 * c["L"] * (8 + 4 * c["E"]))
     if "--cpu" in sys.argv:
         from oracle import ref_cpu as O
         p = synth.datt_params(c, 0, table_scale=0.3)
@@ -99,7 +103,7 @@ if which in ("siamese", "all"):
     keys = ("u_revs", "i_revs", "u_word_masks", "i_word_masks", "u_rev_masks", "i_rev_masks", "u_ids", "i_ids")
     args = tuple(b[k].to(dev) for k in keys)
     # algorithmic work: 2 towers x R x T row adds of D floats per pair (a gather, not a contraction)
-    run("SimpleSiamese (B=256, 11x50 tok/side, D=108, fp32)", m, args, b["ratings"].to(dev), c["B"], 2.0 * c["R"] * c["T"] * c["D"] * c["B"])
+    run("SimpleSiamese (B=256, 11x50 tok/side, D=108, fp32)", m, args, b["ratings"].to(dev), c["B"], 2.0 * c["R"] * c["T"] * c["D"] * c["B"], 2 * c["R"] * c["T"] * (8 + 1 + 4 * c["D"]))
     if "--cpu" in sys.argv:
         from oracle import ref_cpu as O
         p = synth.siamese_params(c, 0)
