@@ -150,6 +150,15 @@ int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const 
  * OVERWRITTEN (no pre-fill needed).  `bwd_ws`: rbr_textcnn_bwd_prod_ws_bytes(d)
  * bytes (0 = formulation not applicable: use rbr_textcnn_bwd_dtable; env RBR_DTABLE_MODE=scatter forces that). */
 size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d);
+/* The same table gradient for a forward that ran in the DENSE formulation (no workspace of its own): builds the
+ * distinct-token list of ids/mask and Wprod^T from the conv weights W (HOST array) in `ws`, then G and the sparse product as
+ * above; the whole dtable [V, D] is OVERWRITTEN.  Un-gated convs only.  ws: rbr_textcnn_bwd_dtable_list_ws_bytes(d) bytes
+ * (0: D % 4 != 0, the list's worst-case G exceeds 256 MB, or RBR_DTABLE_MODE=scatter -> use rbr_textcnn_bwd_dtable, whose
+ * window scatter issues one row of f32 atomics per (document, channel, tap)). */
+size_t rbr_textcnn_bwd_dtable_list_ws_bytes(const rbr_textcnn_desc* d);
+int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
+                                const float* feat, const int32_t* argmax, const float* d_feat, void* ws, float* dtable,
+                                void* stream);
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                 const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                 float* dtable, float* dgate, void* stream);

@@ -827,6 +827,10 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
+static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
+                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                               float* dtable, float* dgate, hipStream_t st);
+
 extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                            const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
                                            void* bwd_ws, float* dtable, float* dgate, void* stream) {
@@ -836,10 +840,17 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     if (dtable == nullptr && dgate == nullptr) return 0;
     if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream);
+}
+
+// G over the token list in `fwd_ws` (ProdLayout), then dtable = G @ Wprod^T; shared by the token-product backward (the
+// forward's list) and by the dense formulation's backward (a list built for the purpose, rbr_textcnn_bwd_dtable_list)
+static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
+                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                               float* dtable, float* dgate, hipStream_t st) {
     ProdLayout Lo;
     ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
     char* fbase = static_cast<char*>(fwd_ws);
     const int* row_of_token = reinterpret_cast<const int*>(fbase + Lo.row_of_token);
     const long long* tok_of_row = reinterpret_cast<const long long*>(fbase + Lo.tok_of_row);
@@ -966,6 +977,68 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
                        b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
     return 0;
+}
+
+// ---- dense formulation's table gradient through a token list built for the purpose (no product table T: un-gated convs)
+namespace {
+constexpr size_t kListMaxG = (size_t)256 << 20;      // the list's worst-case G (min(V, positions) rows) must stay below this
+bool list_bwd_layout(const rbr_textcnn_desc* d, ProdLayout& Lo, ProdBwdLayout& B, size_t& list_bytes) {
+    if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return false;
+    if (B.total > kListMaxG) return false;
+    ConvPlan pp[kMaxGroups];
+    if (!build_plans(&Lo.dp, pp, kProdGroupTiles)) return false;
+    list_bytes = Lo.table_T + align256((size_t)pp[0].nslots_total * sizeof(float));      // everything but T: one (zero) row of it
+    return true;
+}
+}  // namespace
+
+extern "C" size_t rbr_textcnn_bwd_dtable_list_ws_bytes(const rbr_textcnn_desc* d) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return 0;
+    static const char* env = getenv("RBR_DTABLE_MODE");
+    if (env && !strcmp(env, "scatter")) return 0;
+    ProdLayout Lo; ProdBwdLayout B; size_t list_bytes;
+    if (!list_bwd_layout(d, Lo, B, list_bytes)) return 0;
+    return align256(list_bytes) + B.total;
+}
+
+extern "C" int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W,
+                                           const float* feat, const int32_t* argmax, const float* d_feat, void* ws, float* dtable,
+                                           void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (!ids || !W || !feat || !argmax || !d_feat || !ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    ProdLayout Lo; ProdBwdLayout B; size_t list_bytes;
+    if (!list_bwd_layout(d, Lo, B, list_bytes)) { set_error("token-list table gradient does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(ws);
+    ConvPlan pp[kMaxGroups];
+    if (!build_plans(&Lo.dp, pp, kProdGroupTiles)) return RBR_ERR_BAD_ARG;
+    int* sched_p = reinterpret_cast<int*>(base + Lo.sched);
+    // list state: token marks, row mask, counters
+    ZeroRegions zr{{reinterpret_cast<int*>(base + Lo.used), sched_p + 2 * (size_t)pp[0].total_wt, nullptr},
+                   {(long)((Lo.row_of_token - Lo.used) / sizeof(int)), kSchedCounters, 0}};
+    if (int e = zero_regions(zr, st)) return e;
+    const long n_tok = (long)d->n_docs * d->L;
+    hipLaunchKernelGGL(mark_scan_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, plans[0], 0, n_tok,
+                       reinterpret_cast<const long long*>(ids), mask, (int*)nullptr, reinterpret_cast<unsigned char*>(base + Lo.used));
+    RBR_CHECK_LAUNCH("textcnn mark launch");
+    PackJob J{};
+    J.P = pp[0]; J.n_widths = d->n_widths; J.D = d->D;
+    int o = 0;
+    for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = o; o += d->kz[w] * d->ch[w]; }
+    J.cp_real = o;
+    PtrArray wp{};
+    for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
+    const int nb_compact = (d->V + 255) / 256;
+    const int nb_pack = (int)std::min<long>(((long)J.cp_real * d->D + 255) / 256, 2048);
+    hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, Lo.cap,
+                       reinterpret_cast<unsigned char*>(base + Lo.used), reinterpret_cast<int*>(base + Lo.row_of_token),
+                       reinterpret_cast<long long*>(base + Lo.tok_of_row), reinterpret_cast<unsigned char*>(base + Lo.row_mask),
+                       reinterpret_cast<int*>(base + Lo.counter), reinterpret_cast<float*>(base + Lo.table_T), pp[0].nslots_total, wp,
+                       (float*)nullptr, reinterpret_cast<float*>(base + Lo.wt), B16Pack{}, (unsigned char*)nullptr);
+    RBR_CHECK_LAUNCH("textcnn compact launch");
+    return dtable_through_list(d, plans, ids, mask, nullptr, feat, argmax, d_feat, base, base + align256(list_bytes), dtable, nullptr, st);
 }
 
 // Stage 2 (one kernel): T = table[tok_of_row] @ Wprod on the f32 MFMA pipe.
