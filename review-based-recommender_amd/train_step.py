@@ -88,7 +88,12 @@ class HipClipAdam(torch.optim.Optimizer):
             for k in range(0, len(ps), self.MAX_TENSORS):
                 batches.append((g, ps[k:k + self.MAX_TENSORS]))
         if len(batches) > 1 and max_grad_norm is not None:
-            raise RuntimeError(f"HipClipAdam clips one group of <= {self.MAX_TENSORS} tensors; got {len(batches)} batches")
+            # the fused clip needs every gradient in ONE launch pair; beyond 64 tensors (or with several parameter groups) the
+            # norm and the in-place scaling are torch's clip_grad_norm_ (same maths, device-side, capturable) and the launch
+            # pairs below run without clipping
+            gn = nn.utils.clip_grad_norm_([p for _, p in todo], max_grad_norm)
+            self._gnorm.copy_(gn)
+            max_grad_norm = None
         for g, ps in batches:
             states = [self._state_of(p) for p in ps]
             step = states[0]["step"]
@@ -109,7 +114,7 @@ class HipClipAdam(torch.optim.Optimizer):
                                              numel, float(max_grad_norm) if max_grad_norm is not None else 0.0,
                                              float(g["lr"]), float(b1), float(b2), float(g["eps"]),
                                              _lib.dev_ptr(step, torch.float32, "step"),
-                                             _lib.dev_ptr(self._gnorm, torch.float32, "gnorm"),
+                                             _lib.dev_ptr(self._gnorm, torch.float32, "gnorm") if len(batches) == 1 else None,
                                              _lib.dev_ptr(self._ws, torch.float32, "ws"), st), "rbr_clip_adam_step")
             if ev is not None:
                 ev.record()

@@ -67,3 +67,24 @@ def test_state_dict_interchanges_with_torch_adam():
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
     sd = ob.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_hip_clip_adam_with_more_than_64_tensors():
+    """clipping is no longer refused beyond RBR_OPT_MAX_TENSORS -- the norm / scaling then come from
+    clip_grad_norm_ and the Adam launches run per 64 tensors; the result equals torch's clip + Adam."""
+    from review_based_recommender_amd.train_step import HipClipAdam
+    g = torch.Generator().manual_seed(5)
+    shapes = [(7, 5)] * 40 + [(33,)] * 40 + [(1,)] * 10
+    ps_a = [torch.nn.Parameter(torch.randn(*s, generator=g).to("cuda:0")) for s in shapes]
+    ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+    grads = [torch.randn(*s, generator=g).to("cuda:0") * 3 for s in shapes]
+    oa, ob = HipClipAdam(ps_a, lr=2e-3), torch.optim.Adam(ps_b, lr=2e-3)
+    for step in range(3):
+        for pa, pb, gr in zip(ps_a, ps_b, grads):
+            pa.grad, pb.grad = gr.clone() * (step + 1), gr.clone() * (step + 1)
+        na = oa.clip_and_step(5.0)
+        nb = torch.nn.utils.clip_grad_norm_(ps_b, 5.0)
+        ob.step()
+        assert abs(float(na) - float(nb)) <= 1e-5 * float(nb)
+    for pa, pb in zip(ps_a, ps_b):
+        assert float((pa - pb).abs().max()) <= 2e-6
