@@ -286,19 +286,33 @@ size_t rbr_datt_gate_bwd_ws_floats(int32_t B, int32_t L, int32_t E, int32_t win,
  * ids (table of V rows), the gate is a gather of `win` scalars per position; the backward folds dpre into win tap sums
  * per token and OVERWRITES the whole dtable [V,E] (absent tokens and row pad_idx: 0), dw [E*win] and db0.  `ws`:
  * rbr_datt_local_gate_prod_ws_bytes bytes (0: not worthwhile / unsupported -> use the functions above), the SAME buffer,
- * untouched, for the forward and its backward.  win odd, <= 8. */
+ * untouched, for the forward and its backward.  win odd, <= 8.  `rows`: the tower's shared distinct-token maps
+ * (rbr_datt_token_rows, the same pointer for the forward and the backward) or NULL (the call builds private ones). */
 size_t rbr_datt_local_gate_prod_ws_bytes(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V);
 int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids, const float* table,
-                                 const float* w, const float* b0, float* gate, void* ws, void* stream);
+                                 const float* w, const float* b0, float* gate, void* ws, const void* rows, void* stream);
 int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids, const float* table,
                                  const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw, float* db0,
-                                 float* dtable, void* ws, void* stream);
+                                 float* dtable, void* ws, const void* rows, void* stream);
 int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
                             const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                             float* db0, float* dtable, float* ws, void* stream);
 int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids, const float* table,
                              const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                              float* db0, float* dtable, float* ws, void* stream);
+/* Distinct-token rows of one tower's documents (ids [B,L] over a table of V rows): row_of_token / tok_of_row maps in `rows`
+ * (rbr_datt_token_rows_ws_bytes bytes), built once per tower and step and handed to the gate backwards below.
+ * rbr_datt_global_gate_bwd_rows == rbr_datt_global_gate_bwd, except that the table gradient goes through the occurrence
+ * matrix A[row, p] = sum of dpre over the documents that carry the row's token at position p (one scalar atomic per position
+ * instead of a row of E per distinct token and window), every table row is then written once from its non-zeros, and
+ * dtable [V,E] is OVERWRITTEN (absent tokens and pad_idx: 0).
+ * ws: rbr_datt_global_gate_bwd_rows_ws_floats floats (0: E > 256 or L % 4 != 0 -> use rbr_datt_global_gate_bwd). */
+size_t rbr_datt_token_rows_ws_bytes(int32_t B, int32_t L, int32_t V);
+int rbr_datt_token_rows(int32_t B, int32_t L, int32_t V, const int64_t* ids, void* rows, void* stream);
+size_t rbr_datt_global_gate_bwd_rows_ws_floats(int32_t B, int32_t L, int32_t E, int32_t V);
+int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, int32_t V, const int64_t* ids, const float* table,
+                                  const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
+                                  float* db0, float* dtable, float* ws, const void* rows, void* stream);
 
 /* ---- nn.Linear (+ReLU / Tanh, + dropout multiplier) on the f32 MFMA pipe: y = act(x @ W^T + b) * drop
  *      (`relu`: 0 none, 1 ReLU, 2 Tanh -- SimpleSiamese's latent_transform_layer, simple_siamese.py:24-26)

@@ -68,18 +68,23 @@ __global__ __launch_bounds__(256) void local_gate_fwd_kernel(int B, int L, int E
 // (a per-token atomic row for each of the 1 M tokens of cfg4 ran 1.3 ms: Zipf-hot rows serialise).
 constexpr int kGWin = 256, kGHash = 1024;
 constexpr int kGateWP = 8;       // floats per token row of the tap tables S / c of the token-product local gate (win <= 8)
+constexpr int kGateCopies = 16;  // private copies of the tap-sum table c (summed by gp_csum_kernel)
 
 __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, int win, int is_global, int nwin,
                                                           const long long* __restrict__ ids, const float* __restrict__ w,
                                                           const float* __restrict__ wT, const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, const float* __restrict__ dpre_g,
                                                           int pad_idx, float* __restrict__ dtable,
-                                                          const int* __restrict__ row_of_token, float* __restrict__ c_out) {
+                                                          const int* __restrict__ row_of_token, float* __restrict__ c_out,
+                                                          long c_stride) {
     __shared__ int s_tok[kGWin];
     __shared__ short s_leader[kGWin], s_cnt[kGWin], s_start[kGWin], s_sorted[kGWin];
     __shared__ int s_fill[kGWin];
     __shared__ int s_hkey[kGHash], s_hval[kGHash];
     __shared__ float s_dpre[kGWin + 2 * kMaxKF];     // local: dpre of the window plus a halo of `pad` each side
+    __shared__ short s_keys[kGWin];                  // the leaders (first position of each distinct token), dense
+    __shared__ int s_nkeys;
+    extern __shared__ float s_cj[];                  // dense local mode: [kGWin][win] tap sums per distinct token
     const int b = blockIdx.x / nwin, p0 = (blockIdx.x % nwin) * kGWin;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pad = (win - 1) / 2;
@@ -125,22 +130,25 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, i
         if (lead >= 0) atomicAdd(&s_fill[lead], 1);
     }
     __syncthreads();
-    if (wave == 0) {   // exclusive scan of the per-token counts
-        int run = 0;
+    if (wave == 0) {   // exclusive scan of the per-token counts, and of the leaders themselves (dense key list)
+        int run = 0, krun = 0;
         for (int r0 = 0; r0 < kGWin; r0 += 64) {
             const int r = r0 + lane;
             const int c = s_fill[r];
-            int inc = c;
+            int inc = c, kinc = c > 0;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(inc, o);
-                if (lane >= o) inc += v;
+                const int v = __shfl_up(inc, o), kv = __shfl_up(kinc, o);
+                if (lane >= o) { inc += v; kinc += kv; }
             }
             s_start[r] = (short)(run + inc - c);
             s_cnt[r] = (short)c;
             s_fill[r] = 0;
+            if (c > 0) s_keys[krun + kinc - 1] = (short)r;
             run += __shfl(inc, 63);
+            krun += __shfl(kinc, 63);
         }
+        if (lane == 0) s_nkeys = krun;
     }
     __syncthreads();
     for (int r = tid; r < kGWin; r += 256) {
@@ -148,46 +156,73 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, i
         if (lead >= 0) s_sorted[s_start[lead] + atomicAdd(&s_fill[lead], 1)] = (short)r;
     }
     __syncthreads();
-    const float dp = is_global ? dpre_g[b] : 0.f;
-    for (int key = wave; key < kGWin; key += 4) {
-        const int cnt = s_cnt[key];
-        if (cnt == 0) continue;                      // wave-uniform
-        const int base = s_start[key];
-        if (c_out != nullptr) {
-            // token-product backward of the local gate: only the win tap sums c_j of the token leave the workgroup
+    // The folded rows leave the workgroup thread-parallel: a wave per token walked <= 64 tokens one after the other, each
+    // with a dependent L2 read in front of its atomics (latency-bound: 88 us for the tap sums alone at cfg4).
+    const int nkeys = s_nkeys;
+    if (c_out != nullptr) {
+        // token-product backward of the local gate: only the win tap sums c_j of the token leave the workgroup.  8 lanes
+        // per token (one per tap), so that a token's row is ONE 32-byte atomic request; the workgroup adds into copy
+        // blockIdx % kGateCopies of the tap-sum table: requests to the same line are served one after the other, and the row
+        // of a Zipf-hot token would otherwise receive one from every window of every document.
+        float* mine = c_out + (long)(blockIdx.x % kGateCopies) * c_stride;
+        const int j = tid & (kGateWP - 1);
+        for (int k = tid / kGateWP; k < nkeys; k += 256 / kGateWP) {
+            const int key = s_keys[k], cnt = s_cnt[key], base = s_start[key];
             const int row = row_of_token[s_tok[key]];
-            if (lane < win && row >= 0) {
-                float cj = 0.f;
-                for (int q = 0; q < cnt; ++q) cj += s_dpre[s_sorted[base + q] - lane + 2 * pad];
-                atomicAdd(c_out + (long)row * kGateWP + lane, cj);
-            }
-            continue;
+            if (row < 0 || j >= win) continue;
+            float cj = 0.f;
+            for (int q = 0; q < cnt; ++q) cj += s_dpre[s_sorted[base + q] - j + 2 * pad];
+            atomicAdd(mine + (long)row * kGateWP + j, cj);
         }
-        float* drow = dtable + (long)s_tok[key] * E;
+        return;
+    }
+    if (!is_global) {
+        // the win tap sums of every token of the window, once, into LDS
+        for (int k = tid; k < nkeys; k += 256) {
+            const int key = s_keys[k], cnt = s_cnt[key], base = s_start[key];
+            for (int j = 0; j < win; ++j) {
+                float c = 0.f;
+                for (int q = 0; q < cnt; ++q) c += s_dpre[s_sorted[base + q] - j + 2 * pad];
+                s_cj[k * win + j] = c;
+            }
+        }
+        __syncthreads();
+    }
+    const float dp = is_global ? dpre_g[b] : 0.f;
+    const int total = nkeys * E;
+    constexpr int kU = 4;                            // rows in flight per thread: the reads of 4 items before the first atomic
+    for (int it = tid; it < total; it += 256 * kU) {
+        float s[kU];
+        float* dst[kU];
+        int cnt[kU], base[kU], ee[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int item = it + u * 256;
+            const bool ok = item < total;
+            const int k = ok ? item / E : 0, e = ok ? item - k * E : 0;
+            const int key = s_keys[k];
+            cnt[u] = ok ? s_cnt[key] : 0;
+            base[u] = s_start[key];
+            ee[u] = e;
+            dst[u] = dtable + (long)s_tok[key] * E + e;
+            if (is_global) {
+                s[u] = ok ? wT[(long)(p0 + s_sorted[base[u]]) * E + e] : 0.f;
+            } else {
+                float a = 0.f;
+                for (int j = 0; j < win; ++j) a = fmaf(s_cj[k * win + j], w[(long)e * win + j], a);
+                s[u] = a;
+            }
+        }
         if (is_global) {
-            for (int e = lane; e < E; e += 64) {
-                float s = 0.f;
-                for (int q = 0; q < cnt; ++q) s += wT[(long)(p0 + s_sorted[base + q]) * E + e];
-                atomicAdd(drow + e, dp * s);
-            }
-        } else {
-            for (int j0 = 0; j0 < win; j0 += kMaxKF) {
-                float c[kMaxKF];
 #pragma unroll
-                for (int j = 0; j < kMaxKF; ++j) {
-                    c[j] = 0.f;
-                    if (j0 + j < win)
-                        for (int q = 0; q < cnt; ++q) c[j] += s_dpre[s_sorted[base + q] - (j0 + j) + 2 * pad];
-                }
-                for (int e = lane; e < E; e += 64) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int j = 0; j < kMaxKF; ++j)
-                        if (j0 + j < win) s = fmaf(c[j], w[(long)e * win + j0 + j], s);
-                    atomicAdd(drow + e, s);
-                }
+            for (int u = 0; u < kU; ++u) {
+                for (int q = 1; q < cnt[u]; ++q) s[u] += wT[(long)(p0 + s_sorted[base[u] + q]) * E + ee[u]];
+                s[u] *= dp;
             }
         }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (cnt[u] > 0) atomicAdd(dst[u], s[u]);
     }
 }
 
@@ -495,6 +530,137 @@ __global__ __launch_bounds__(256) void gp_gate_kernel(int B, int L, int win, con
     }
 }
 
+// c[0][k] += c[1..copies-1][k]   (fixed order)
+__global__ __launch_bounds__(256) void gp_csum_kernel(int cap, const int* __restrict__ counter, float* __restrict__ c) {
+    const long n = (long)min(*counter, cap) * kGateWP, stride = (long)cap * kGateWP;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        float s = c[k];
+#pragma unroll
+        for (int g = 1; g < kGateCopies; ++g) s += c[g * stride + k];
+        c[k] = s;
+    }
+}
+
+// ---- global gate, table gradient through the occurrence matrix ------------------------------------------------------
+// dtable[t, :] = sum_p A[t, p] * wT[p, :]  with  A[t, p] = sum over the documents b that carry token t at position p of dpre[b].
+// A is kept per distinct-token ROW ([n_rows, L] f32): building it costs ONE scalar atomic per position instead of a row of E
+// (the f32 atomics are priced per 64-byte request, ~25 G/s chip-wide: the per-window rows of gate_bwd_dx_kernel are 2.9 M
+// requests at cfg4, the scalars 0.5 M), and every table row is then written once, from its non-zeros.
+__global__ __launch_bounds__(256) void gg_zero_kernel(int cap, int L, const int* __restrict__ counter, f32x4g* __restrict__ A,
+                                                      int* __restrict__ dense_count) {
+    const long n = (long)min(*counter, cap) * L / 4;                    // L % 4 == 0 (checked by the caller)
+    const f32x4g z = {0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dense_count = 0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) A[k] = z;
+}
+
+__global__ __launch_bounds__(256) void gg_scatter_kernel(int B, int L, int pad_idx, const long long* __restrict__ ids,
+                                                         const int* __restrict__ row_of_token, const float* __restrict__ dpre,
+                                                         float* __restrict__ A) {
+    const long n = (long)B * L;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        const int t = (int)ids[k];
+        if (t == pad_idx) continue;
+        const int b = (int)(k / L), p = (int)(k - (long)b * L);
+        atomicAdd(A + (long)row_of_token[t] * L + p, dpre[b]);
+    }
+}
+
+// acc[c] += sum over the non-zeros of the 64-position stretch at p0 (lane j holds a = A[row, p0 + j]) of a * wT[p0 + j, c*64 + lane]:
+// the non-zeros are visited kGgU at a time, their weight rows requested before the first use.
+constexpr int kGgChunks = 4;                         // embedding columns per lane: E <= 256
+constexpr int kGgU = 8;
+__device__ __forceinline__ void gg_stretch(float a, int p0, int E, int lane, const float* __restrict__ wT, float (&acc)[kGgChunks]) {
+    unsigned long long m = __ballot(a != 0.f);
+    while (m) {
+        int j[kGgU];
+        float av[kGgU];
+#pragma unroll
+        for (int u = 0; u < kGgU; ++u) {
+            j[u] = m ? __builtin_ctzll(m) : -1;
+            if (m) m &= m - 1;
+            av[u] = (j[u] >= 0) ? __shfl(a, j[u]) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < kGgChunks; ++c) {
+            const int e = c * 64 + lane;
+            if (c * 64 >= E) break;                  // wave-uniform
+            float x[kGgU];
+#pragma unroll
+            for (int u = 0; u < kGgU; ++u) x[u] = (j[u] >= 0 && e < E) ? wT[(long)(p0 + j[u]) * E + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < kGgU; ++u) acc[c] = fmaf(av[u], x[u], acc[c]);
+        }
+    }
+}
+
+// One WAVE per vocabulary entry (absent tokens and the pad row: zeros).  The wave reads its row of A (all stretches requested
+// at once), counts the non-zeros, and either builds the table row from them or -- a row with more than kGgDense of them, a
+// Zipf-hot token -- leaves it on the dense list for gg_dense_rows_kernel (a workgroup of 16 waves per row): a workgroup per
+// entry spent its time on the fixed latencies of 50 k mostly near-empty rows, a wave per entry would walk the hot rows' 1024
+// non-zeros one after the other.
+constexpr int kGgDense = 96, kGgStretch = 16;        // stretches (of 64 positions) of a row held in registers at a time
+__global__ __launch_bounds__(256) void gg_rows_kernel(int V, int L, int E, int pad_idx, const int* __restrict__ row_of_token,
+                                                      const float* __restrict__ A, const float* __restrict__ wT,
+                                                      float* __restrict__ dtable, int* __restrict__ dense_count,
+                                                      int* __restrict__ dense_list) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= V) return;
+    const int row = row_of_token[v];
+    if (row < 0 || v == pad_idx) {
+        for (int e = lane; e < E; e += 64) dtable[(long)v * E + e] = 0.f;
+        return;
+    }
+    const float* arow = A + (long)row * L;
+    int nnz = 0;
+    float acc[kGgChunks];
+#pragma unroll
+    for (int c = 0; c < kGgChunks; ++c) acc[c] = 0.f;
+    for (int pb = 0; pb < L; pb += 64 * kGgStretch) {
+        float a[kGgStretch];
+#pragma unroll
+        for (int q = 0; q < kGgStretch; ++q) { const int p = pb + q * 64 + lane; a[q] = (p < L) ? arow[p] : 0.f; }   // one latency
+#pragma unroll
+        for (int q = 0; q < kGgStretch; ++q) nnz += __popcll(__ballot(a[q] != 0.f));
+        if (nnz > kGgDense) {                        // wave-uniform; what was summed so far is dropped
+            if (lane == 0) dense_list[atomicAdd(dense_count, 1)] = v;
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < kGgStretch; ++q) gg_stretch(a[q], pb + q * 64, E, lane, wT, acc);
+    }
+#pragma unroll
+    for (int c = 0; c < kGgChunks; ++c) { const int e = c * 64 + lane; if (e < E) dtable[(long)v * E + e] = acc[c]; }
+}
+
+// dense rows: one workgroup of 16 waves per listed token, wave w walks the stretches w, w + 16, ...; partial rows meet in LDS
+__global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const int* __restrict__ row_of_token,
+                                                             const float* __restrict__ A, const float* __restrict__ wT,
+                                                             float* __restrict__ dtable, const int* __restrict__ dense_count,
+                                                             const int* __restrict__ dense_list) {
+    __shared__ float s_part[16][kGgChunks * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = *dense_count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int v = dense_list[i];
+        const float* arow = A + (long)row_of_token[v] * L;
+        float acc[kGgChunks];
+#pragma unroll
+        for (int c = 0; c < kGgChunks; ++c) acc[c] = 0.f;
+        for (int p0 = wave * 64; p0 < L; p0 += 16 * 64) gg_stretch(p0 + lane < L ? arow[p0 + lane] : 0.f, p0, E, lane, wT, acc);
+#pragma unroll
+        for (int c = 0; c < kGgChunks; ++c) s_part[wave][c * 64 + lane] = acc[c];
+        __syncthreads();
+        for (int e = tid; e < E; e += 1024) {
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) t += s_part[w2][e];
+            dtable[(long)v * E + e] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // dtable[v, :] = sum_j c[row(v)][j] w[:, j]  (0 for absent tokens and the pad row): the whole [V, E] gradient is overwritten
 __global__ __launch_bounds__(256) void gp_dtable_kernel(int V, int E, int win, int pad_idx, const int* __restrict__ row_of_token,
                                                         const float* __restrict__ c, const float* __restrict__ w,
@@ -614,9 +780,10 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
     RBR_CHECK_LAUNCH("datt local gate bwd reduce launch");
     if (dtable != nullptr) {
         const int nwin = (L + kGWin - 1) / kGWin;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
+        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), (size_t)kGWin * win * sizeof(float), st, B,
+                           L, E, win, 0, nwin, ids64, w,
                            (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable, (const int*)nullptr,
-                           (float*)nullptr);
+                           (float*)nullptr, 0L);
         RBR_CHECK_LAUNCH("datt local gate bwd dx launch");
     }
     return 0;
@@ -640,7 +807,7 @@ extern "C" int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const i
         RBR_CHECK_LAUNCH("datt global gate transpose launch");
         const int nwin = (L + kGWin - 1) / kGWin;
         hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, 1, 1, nwin, ids64, w,
-                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable, (const int*)nullptr, (float*)nullptr);
+                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable, (const int*)nullptr, (float*)nullptr, 0L);
         RBR_CHECK_LAUNCH("datt global gate bwd dx launch");
     }
     return 0;
@@ -661,9 +828,46 @@ bool gate_prod_layout(int B, int L, int E, int win, int V, GateProdLayout& G) {
     G.row_of_token = o; o += al256((size_t)V * sizeof(int));
     G.tok_of_row = o;   o += al256((size_t)G.cap * sizeof(int));
     G.S = o;            o += al256((size_t)G.cap * kGateWP * sizeof(float));
-    G.c = o;            o += al256((size_t)G.cap * kGateWP * sizeof(float));
+    G.c = o;            o += al256((size_t)G.cap * kGateWP * sizeof(float) * kGateCopies);
     G.part = o;         o += al256((size_t)G.n_chunks * ((size_t)win * E + 1) * sizeof(float));
     G.total = o;
+    return true;
+}
+}  // namespace
+
+// ---- distinct-token rows of a document batch, shared by the gates of one tower (layout: counter | used | row_of_token | tok_of_row)
+namespace {
+struct TokenRowsLayout { size_t counter, used, row_of_token, tok_of_row, total; int cap; };
+bool token_rows_layout(int B, int L, int V, TokenRowsLayout& T) {
+    if (B <= 0 || L <= 0 || V <= 0) return false;
+    T.cap = (int)std::min<long>(V, (long)B * L);
+    size_t o = 0;
+    T.counter = o;      o += 256;
+    T.used = o;         o += al256((size_t)V * sizeof(int));      // contiguous with the counter: zeroed together
+    T.row_of_token = o; o += al256((size_t)V * sizeof(int));
+    T.tok_of_row = o;   o += al256((size_t)T.cap * sizeof(int));
+    T.total = o;
+    return true;
+}
+}  // namespace
+
+
+namespace {
+struct GateRowMaps { const int *counter, *row_of_token, *tok_of_row; };
+// the distinct-token maps a token-product gate call works on: the tower's shared ones (`rows`) or the private ones in its ws
+bool gate_row_maps(int B, int L, int V, const GateProdLayout& G, const char* ws_base, const void* rows, GateRowMaps& M) {
+    if (rows == nullptr) {
+        M.counter = reinterpret_cast<const int*>(ws_base + G.counter);
+        M.row_of_token = reinterpret_cast<const int*>(ws_base + G.row_of_token);
+        M.tok_of_row = reinterpret_cast<const int*>(ws_base + G.tok_of_row);
+        return true;
+    }
+    TokenRowsLayout T;
+    if (!token_rows_layout(B, L, V, T) || T.cap != G.cap) { set_error("token rows do not fit the gate shape"); return false; }
+    const char* r = static_cast<const char*>(rows);
+    M.counter = reinterpret_cast<const int*>(r + T.counter);
+    M.row_of_token = reinterpret_cast<const int*>(r + T.row_of_token);
+    M.tok_of_row = reinterpret_cast<const int*>(r + T.tok_of_row);
     return true;
 }
 }  // namespace
@@ -680,24 +884,28 @@ extern "C" size_t rbr_datt_local_gate_prod_ws_bytes(int32_t B, int32_t L, int32_
 
 extern "C" int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids,
                                             const float* table, const float* w, const float* b0, float* gate, void* ws,
-                                            void* stream) {
+                                            const void* rows, void* stream) {
     GateProdLayout G;
     if (!gate_prod_layout(B, L, E, win, V, G)) { set_error("bad local gate shape B=%d L=%d E=%d win=%d V=%d", B, L, E, win, V); return RBR_ERR_BAD_ARG; }
     if (!ids || !table || !w || !b0 || !gate || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     char* base = static_cast<char*>(ws);
     int* used = reinterpret_cast<int*>(base + G.used);
-    int* counter = reinterpret_cast<int*>(base + G.counter);
-    int* row_of_token = reinterpret_cast<int*>(base + G.row_of_token);
-    int* tok_of_row = reinterpret_cast<int*>(base + G.tok_of_row);
     float* S = reinterpret_cast<float*>(base + G.S);
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
-    if (int e = zero_words(used, G.row_of_token - G.used, st)) return e;
     const long n_pos = (long)B * L;
-    hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos, ids64, used);
-    RBR_CHECK_LAUNCH("datt gate mark launch");
-    hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, G.cap, used, row_of_token, tok_of_row, counter);
-    RBR_CHECK_LAUNCH("datt gate compact launch");
+    GateRowMaps M;
+    if (!gate_row_maps(B, L, V, G, base, rows, M)) return RBR_ERR_BAD_ARG;
+    const int *counter = M.counter, *row_of_token = M.row_of_token, *tok_of_row = M.tok_of_row;
+    if (rows == nullptr) {               // the tower's shared maps (rbr_datt_token_rows) were not handed in: build private ones
+        if (int e = zero_words(used, G.row_of_token - G.used, st)) return e;
+        hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos, ids64, used);
+        RBR_CHECK_LAUNCH("datt gate mark launch");
+        hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, G.cap, used,
+                           reinterpret_cast<int*>(base + G.row_of_token), reinterpret_cast<int*>(base + G.tok_of_row),
+                           reinterpret_cast<int*>(base + G.counter));
+        RBR_CHECK_LAUNCH("datt gate compact launch");
+    }
     hipLaunchKernelGGL(gp_taps_kernel, dim3((unsigned)std::min((G.cap + 3) / 4, 4096)), dim3(256), 0, st, E, win, G.cap, counter,
                        tok_of_row, table, w, S);
     RBR_CHECK_LAUNCH("datt gate taps launch");
@@ -709,23 +917,27 @@ extern "C" int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int
 
 extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids,
                                             const float* table, const float* w, const float* gate, const float* dgate,
-                                            int32_t pad_idx, float* dw, float* db0, float* dtable, void* ws, void* stream) {
+                                            int32_t pad_idx, float* dw, float* db0, float* dtable, void* ws, const void* rows,
+                                            void* stream) {
     GateProdLayout G;
     if (!gate_prod_layout(B, L, E, win, V, G)) { set_error("bad local gate shape B=%d L=%d E=%d win=%d V=%d", B, L, E, win, V); return RBR_ERR_BAD_ARG; }
     if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     char* base = static_cast<char*>(ws);
-    const int* counter = reinterpret_cast<const int*>(base + G.counter);
-    const int* row_of_token = reinterpret_cast<const int*>(base + G.row_of_token);
-    const int* tok_of_row = reinterpret_cast<const int*>(base + G.tok_of_row);
+    GateRowMaps M;
+    if (!gate_row_maps(B, L, V, G, base, rows, M)) return RBR_ERR_BAD_ARG;
+    const int *counter = M.counter, *row_of_token = M.row_of_token, *tok_of_row = M.tok_of_row;
     float* c = reinterpret_cast<float*>(base + G.c);
     float* part = reinterpret_cast<float*>(base + G.part);
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
-    if (int e = zero_words(c, (size_t)G.cap * kGateWP * sizeof(float), st)) return e;
+    if (int e = zero_words(c, (size_t)G.cap * kGateWP * sizeof(float) * kGateCopies, st)) return e;
     const int nwin = (L + kGWin - 1) / kGWin;
     hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
-                       (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, (float*)nullptr, row_of_token, c);
+                       (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, (float*)nullptr, row_of_token, c,
+                       (long)G.cap * kGateWP);
     RBR_CHECK_LAUNCH("datt gate tap-sum launch");
+    hipLaunchKernelGGL(gp_csum_kernel, dim3((unsigned)std::min((G.cap * kGateWP + 255) / 256, 2048)), dim3(256), 0, st, G.cap, counter, c);
+    RBR_CHECK_LAUNCH("datt gate tap-sum fold launch");
     const int n_out = win * E + 1;
     hipLaunchKernelGGL(gp_dw_partial_kernel, dim3(G.n_chunks), dim3(256), 0, st, E, win, G.cap, counter, tok_of_row, table, c, part);
     RBR_CHECK_LAUNCH("datt gate dw partial launch");
@@ -736,6 +948,78 @@ extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int
         hipLaunchKernelGGL(gp_dtable_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, V, E, win, pad_idx,
                            row_of_token, c, w, dtable);
         RBR_CHECK_LAUNCH("datt gate dtable launch");
+    }
+    return 0;
+}
+
+extern "C" size_t rbr_datt_token_rows_ws_bytes(int32_t B, int32_t L, int32_t V) {
+    TokenRowsLayout T;
+    return token_rows_layout(B, L, V, T) ? T.total : 0;
+}
+
+extern "C" int rbr_datt_token_rows(int32_t B, int32_t L, int32_t V, const int64_t* ids, void* rows, void* stream) {
+    TokenRowsLayout T;
+    if (!token_rows_layout(B, L, V, T)) { set_error("bad token-rows shape B=%d L=%d V=%d", B, L, V); return RBR_ERR_BAD_ARG; }
+    if (!ids || !rows) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    char* base = static_cast<char*>(rows);
+    int* counter = reinterpret_cast<int*>(base + T.counter);
+    int* used = reinterpret_cast<int*>(base + T.used);
+    if (int e = zero_words(counter, T.row_of_token - T.counter, st)) return e;
+    const long n_pos = (long)B * L;
+    hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos,
+                       reinterpret_cast<const long long*>(ids), used);
+    RBR_CHECK_LAUNCH("token rows mark launch");
+    hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, T.cap, used,
+                       reinterpret_cast<int*>(base + T.row_of_token), reinterpret_cast<int*>(base + T.tok_of_row), counter);
+    RBR_CHECK_LAUNCH("token rows compact launch");
+    return 0;
+}
+
+extern "C" size_t rbr_datt_global_gate_bwd_rows_ws_floats(int32_t B, int32_t L, int32_t E, int32_t V) {
+    TokenRowsLayout T;
+    if (!token_rows_layout(B, L, V, T) || E <= 0 || E > kGgChunks * 64 || L % 4 != 0) return 0;   // 0: use rbr_datt_global_gate_bwd
+    return (size_t)B + (size_t)E * L + 8 + (size_t)T.cap * L + 4 + (size_t)V;       // dpre | wT | A | dense count + list
+}
+
+extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, int32_t V, const int64_t* ids, const float* table,
+                                             const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
+                                             float* db0, float* dtable, float* ws, const void* rows, void* stream) {
+    TokenRowsLayout T;
+    if (!gate_args_ok(B, L, E, 1) || !token_rows_layout(B, L, V, T)) return RBR_ERR_BAD_ARG;
+    if (E > kGgChunks * 64 || L % 4 != 0) { set_error("global gate over token rows needs E <= %d and L %% 4 == 0 (E=%d L=%d)", kGgChunks * 64, E, L); return RBR_ERR_UNSUPPORTED; }
+    if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws || !rows) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const long long* ids64 = reinterpret_cast<const long long*>(ids);
+    const char* base = static_cast<const char*>(rows);
+    const int* counter = reinterpret_cast<const int*>(base + T.counter);
+    const int* row_of_token = reinterpret_cast<const int*>(base + T.row_of_token);
+    hipLaunchKernelGGL(global_gate_bwd_dpre_kernel, dim3(B), dim3(256), 0, st, B, L, gate, dgate, ws);
+    RBR_CHECK_LAUNCH("datt global gate bwd dpre launch");
+    hipLaunchKernelGGL(global_gate_bwd_dw_kernel, dim3(L + 1), dim3(256), 0, st, B, L, E, ids64, table, ws, dw, db0);
+    RBR_CHECK_LAUNCH("datt global gate bwd dw launch");
+    if (dtable != nullptr) {
+        float* wT = ws + B;
+        float* A = wT + (((size_t)E * L + 3) & ~(size_t)3);             // 16-byte aligned behind wT when ws is
+        if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) A += 4 - ((reinterpret_cast<uintptr_t>(A) & 15) >> 2);
+        hipLaunchKernelGGL(transpose_w_kernel, dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0,
+                           st, E, L, w, wT);
+        RBR_CHECK_LAUNCH("datt global gate transpose launch");
+        int* dense_count = reinterpret_cast<int*>(A + (size_t)T.cap * L);
+        int* dense_list = dense_count + 4;
+        hipLaunchKernelGGL(gg_zero_kernel, dim3((unsigned)std::min<long>(((long)T.cap * L / 4 + 255) / 256, 8192)), dim3(256), 0, st,
+                           T.cap, L, counter, reinterpret_cast<f32x4g*>(A), dense_count);
+        RBR_CHECK_LAUNCH("datt global gate occurrence zero launch");
+        const long n_pos = (long)B * L;
+        hipLaunchKernelGGL(gg_scatter_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, B, L,
+                           pad_idx, ids64, row_of_token, (const float*)ws, A);
+        RBR_CHECK_LAUNCH("datt global gate occurrence scatter launch");
+        hipLaunchKernelGGL(gg_rows_kernel, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, V, L, E, pad_idx, row_of_token,
+                           (const float*)A, (const float*)wT, dtable, dense_count, dense_list);
+        RBR_CHECK_LAUNCH("datt global gate rows launch");
+        hipLaunchKernelGGL(gg_dense_rows_kernel, dim3((unsigned)std::min(V, 512)), dim3(1024), 0, st, L, E, row_of_token,
+                           (const float*)A, (const float*)wT, dtable, (const int*)dense_count, (const int*)dense_list);
+        RBR_CHECK_LAUNCH("datt global gate dense rows launch");
     }
     return 0;
 }

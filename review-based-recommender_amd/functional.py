@@ -935,8 +935,9 @@ class _DattGate(torch.autograd.Function):
     """gate[B,L] of LocalAttention (win odd) or GlobalAttention (is_global) -- rbr_datt_*_gate_* in rbr_hip.h."""
 
     @staticmethod
-    def forward(ctx, table, w, b0, ids, is_global, padding_idx):
+    def forward(ctx, table, w, b0, ids, is_global, padding_idx, rows=None):
         ctx.gate_ws = None
+        ctx.rows = rows                              # the tower's distinct-token rows (datt_token_rows) or None
         B, L = ids.shape
         E = table.shape[1]
         win = w.shape[2]
@@ -956,7 +957,8 @@ class _DattGate(torch.autograd.Function):
                 ctx.gate_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
                 check(L_.rbr_datt_local_gate_fwd_prod(B, L, E, win, V, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
                                                       dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
-                                                      ctx.gate_ws.data_ptr(), current_stream()), "rbr_datt_local_gate_fwd_prod")
+                                                      ctx.gate_ws.data_ptr(), None if rows is None else rows.data_ptr(),
+                                                      current_stream()), "rbr_datt_local_gate_fwd_prod")
             else:
                 check(L_.rbr_datt_local_gate_fwd(B, L, E, win, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
                                                  dev_ptr(w, F32, "w"), dev_ptr(b0, F32, "b0"), dev_ptr(gate, F32, "gate"),
@@ -980,8 +982,20 @@ class _DattGate(torch.autograd.Function):
                                                   dev_ptr(table, F32, "table"), dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"),
                                                   dev_ptr(dgate, F32, "dgate"), pad, dev_ptr(dw, F32, "dw"),
                                                   dev_ptr(db0, F32, "db0"), dev_ptr(dtable, F32, "dtable"),
-                                                  ctx.gate_ws.data_ptr(), current_stream()), "rbr_datt_local_gate_bwd_prod")
-            return dtable, dw, db0, None, None, None
+                                                  ctx.gate_ws.data_ptr(), None if ctx.rows is None else ctx.rows.data_ptr(),
+                                                  current_stream()), "rbr_datt_local_gate_bwd_prod")
+            return dtable, dw, db0, None, None, None, None
+        V = table.shape[0]
+        rows_floats = L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V) if (ctx.rows is not None and is_global) else 0
+        if rows_floats:                  # global gate over the tower's token rows: occurrence matrix, dtable overwritten
+            dtable = torch.empty_like(table) if ctx.needs_input_grad[0] else None
+            ws = torch.empty(rows_floats, dtype=F32, device=dev)
+            check(L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
+                                                   dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"), dev_ptr(dgate, F32, "dgate"),
+                                                   pad, dev_ptr(dw, F32, "dw"), dev_ptr(db0, F32, "db0"),
+                                                   dev_ptr(dtable, F32, "dtable"), dev_ptr(ws, F32, "ws"), ctx.rows.data_ptr(),
+                                                   current_stream()), "rbr_datt_global_gate_bwd_rows")
+            return dtable, dw, db0, None, None, None, None
         dtable = torch.zeros_like(table) if ctx.needs_input_grad[0] else None
         ws = torch.empty(max(1, L_.rbr_datt_gate_bwd_ws_floats(B, L, E, win, int(is_global))), dtype=F32, device=dev)
         if is_global:
@@ -996,9 +1010,25 @@ class _DattGate(torch.autograd.Function):
                                              pad, dev_ptr(dw, F32, "dw"), dev_ptr(db0, F32, "db0"),
                                              dev_ptr(dtable, F32, "dtable"), dev_ptr(ws, F32, "ws"), current_stream()),
                   "rbr_datt_local_gate_bwd")
-        return dtable, dw, db0, None, None, None
+        return dtable, dw, db0, None, None, None, None
 
 
-def datt_gate(table, w, b0, ids, *, is_global, padding_idx=0):
-    """sigmoid attention gate [B,L]; w is the Conv1d weight [1,E,win] (local) or [1,E,L] (global)."""
-    return _DattGate.apply(table, w, b0, ids, is_global, padding_idx)
+def datt_gate(table, w, b0, ids, *, is_global, padding_idx=0, rows=None):
+    """sigmoid attention gate [B,L]; w is the Conv1d weight [1,E,win] (local) or [1,E,L] (global).  `rows`: the tower's
+    distinct-token rows (datt_token_rows), shared by its two gates -- the token-product local gate uses them instead of
+    building its own, the global gate's backward builds the table gradient from the occurrence matrix over them."""
+    return _DattGate.apply(table, w, b0, ids, is_global, padding_idx, rows)
+
+
+def datt_token_rows(ids, vocab_size):
+    """Distinct-token row maps of one tower's documents (rbr_datt_token_rows), or None where they do not pay (few positions
+    per vocabulary entry: the same rule as the token-product conv)."""
+    B, L = ids.shape
+    if vocab_size * 5 > B * L * 2 or B * L < 4096 or os.environ.get("RBR_DATT_ROWS", "1") == "0":
+        return None
+    L_ = _lib.lib()
+    rows = torch.empty(L_.rbr_datt_token_rows_ws_bytes(B, L, vocab_size), dtype=torch.uint8, device=ids.device)
+    ids = ids.contiguous()
+    check(L_.rbr_datt_token_rows(B, L, vocab_size, dev_ptr(ids, I64, "ids"), rows.data_ptr(), current_stream()),
+          "rbr_datt_token_rows")
+    return rows

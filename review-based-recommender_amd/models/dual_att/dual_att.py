@@ -30,7 +30,8 @@ class DualAtt(nn.Module):
     def _encode(self, docs, local, glob):
         table = self.word_embeddings.weight
         pad = self.word_embeddings.padding_idx
-        return torch.cat((local.encode(table, docs, pad), glob.encode(table, docs, pad)), dim=1)   # [bz, fc_input]
+        rows = RF.datt_token_rows(docs, table.shape[0])        # distinct-token maps, once per tower: both gates work on them
+        return torch.cat((local.encode(table, docs, pad, rows=rows), glob.encode(table, docs, pad, rows=rows)), dim=1)
 
     def _fc(self, feat):
         p = self.fc[2].p

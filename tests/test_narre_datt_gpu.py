@@ -129,6 +129,31 @@ def test_datt_cfg4_full_step(golden_dir, conv_mode):
             check_params_after(model, g, f"after{step + 1}")
 
 
+def test_global_gate_backward_over_token_rows_matches_the_plain_one():
+    """rbr_datt_global_gate_bwd_rows (private row-compacted copies of the table gradient, dtable overwritten) against
+    rbr_datt_global_gate_bwd (atomics straight into a zeroed dtable): same dw / db0 bit for bit, same dtable to f32 sum
+    reordering; Zipf-like ids so that hot rows exist, pad tokens included."""
+    from review_based_recommender_amd import functional as RF
+    gen = torch.Generator().manual_seed(5)
+    B, L, V, E = 24, 512, 3000, 100
+    ids = (torch.rand(B, L, generator=gen) ** 4 * V).long().clamp_(0, V - 1).to(DEV)
+    table = (torch.randn(V, E, generator=gen) * 0.3).to(DEV).requires_grad_()
+    w = (torch.randn(1, E, L, generator=gen) * 0.05).to(DEV).requires_grad_()
+    b0 = torch.zeros(1, device=DEV, requires_grad=True)
+    up = torch.randn(B, L, generator=gen).to(DEV)
+    rows = RF.datt_token_rows(ids, V)
+    assert rows is not None
+    outs = []
+    for r in (None, rows):
+        gate = RF.datt_gate(table, w, b0, ids, is_global=True, padding_idx=0, rows=r)
+        outs.append(torch.autograd.grad((gate * up).sum(), (table, w, b0)))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    scale = float(outs[0][0].abs().max())
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-6 * scale   # hot rows sum thousands of f32 terms in another order
+    assert float(outs[1][0][0].abs().max()) == 0.0                       # the pad row gets no gradient
+    assert RF.datt_token_rows(ids[:2, :64], V) is None                   # too few positions: the plain path is kept
+
+
 def test_datt_state_dict_keys():
     cfg = synth.DATT_CFGS["tiny"]
     assert list(_datt(cfg).state_dict().keys()) == list(synth.datt_params(cfg, 0).keys())
