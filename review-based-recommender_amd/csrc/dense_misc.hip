@@ -7,6 +7,8 @@
 //   * NgramFeat arch="HierPooling" (layers.py:62-98,110-114): sliding-window mean + global max.
 #include "rbr_common.h"
 
+#include <type_traits>
+
 namespace rbr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,11 +27,9 @@ struct Epi {
     int relu;            // activation: 0 none, 1 ReLU, 2 Tanh
 };
 
-// The next K chunk's global loads are issued into registers before the current chunk's MFMAs, so their latency hides
-// behind the LDS reads and the matrix pipe (these GEMMs have only ~64 workgroups: nothing else would hide it).
 __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long sam, long sak,
                                                    const float* __restrict__ B, long sbn, long sbk, float* __restrict__ C,
-                                                   long ldc, const Epi ep) {
+                                                   long ldc, const Epi ep, long bytes_a, long bytes_b) {
     __shared__ __attribute__((aligned(16))) float As[64 * GS];
     __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -47,26 +47,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         arow[q] = (sak == 1) ? e / GK : e % 64; akk[q] = (sak == 1) ? e % GK : e / 64;
         brow[q] = (sbk == 1) ? e / GK : e % 64; bkk[q] = (sbk == 1) ? e % GK : e / 64;
     }
-    float ra[8], rb[8];
-    auto fetch = [&](int k0) {
+    // two K chunks of global loads in flight (register sets 0 / 1) while a third is multiplied out of LDS.
+    // Buffer loads: the per-lane byte offset of an element at k0 = 0 is formed once, a chunk only moves the scalar offset, and
+    // rows outside the operand carry an offset past its end (the range check returns 0): no per-chunk address arithmetic and no
+    // predicated loads.  (Flat loads with per-element 64-bit multiplies kept the VALU as busy as the matrix pipe, and a
+    // predicated load compiles to a branch, behind which the compiler drains every load in flight before the LDS writes.)
+    float ra[2][8], rb[2][8];
+    const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)bytes_a, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)bytes_b, 0x00020000);
+    constexpr int kOutside = 0x7f000000;             // beyond every operand (launch_gemm: < 2^30 bytes), no wrap with the chunk offset
+    int offa[8], offb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int m = m0 + arow[q], n = n0 + brow[q];
+        offa[q] = (m < M) ? (int)((m * sam + akk[q] * sak) * 4) : kOutside;
+        offb[q] = (n < N) ? (int)((n * sbn + bkk[q] * sbk) * 4) : kOutside;
+    }
+    auto fetch = [&](int k0, float (&fa)[8], float (&fb)[8]) {       // one straight-line path: 16 loads
+        const int sa = (int)(k0 * sak * 4), sb = (int)(k0 * sbk * 4);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int m = m0 + arow[q], ka = k0 + akk[q];
-            ra[q] = (m < M && ka < K) ? A[m * sam + ka * sak] : 0.f;
-            const int n = n0 + brow[q], kb = k0 + bkk[q];
-            rb[q] = (n < N && kb < K) ? B[n * sbn + kb * sbk] : 0.f;
+            fa[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_desc, offa[q], sa, 0));
+            fb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_desc, offb[q], sb, 0));
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += GK) {
+    // `masked`: the K tail (past K a row-major operand continues into its next row).  The full chunks of the main loop write
+    // the loaded values as they are: a select in front of the LDS write is a use the scheduler hoists into the previous
+    // chunk's MFMAs, waiting for the loads a whole chunk early.
+    auto chunk = [&](int k0, auto masked, float (&fa)[8], float (&fb)[8]) {
         __syncthreads();       // previous chunk's LDS reads are done
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            As[arow[q] * GS + akk[q]] = ra[q];
-            Bs[brow[q] * GS + bkk[q]] = rb[q];
+            if constexpr (decltype(masked)::value) {
+                As[arow[q] * GS + akk[q]] = (k0 + akk[q] < K) ? fa[q] : 0.f;
+                Bs[brow[q] * GS + bkk[q]] = (k0 + bkk[q] < K) ? fb[q] : 0.f;
+            } else {
+                As[arow[q] * GS + akk[q]] = fa[q];
+                Bs[brow[q] * GS + bkk[q]] = fb[q];
+            }
         }
         __syncthreads();
-        if (k0 + GK < K) fetch(k0 + GK);
+        fetch(k0 + 2 * GK, fa, fb);   // ALWAYS 16 loads (past the end they are never used): a conditional fetch leaves the number
+                                      // of loads in flight unknown at the next LDS write, and the compiler then drains them all
         const float* pa = As + (wm * 32 + i) * GS + 4 * h;
         const float* pb = Bs + (wn * 32 + i) * GS + 4 * h;
 #pragma unroll
@@ -78,6 +100,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
+    };
+    fetch(0, ra[0], rb[0]);
+    __builtin_amdgcn_sched_barrier(0);               // set 0's loads strictly before set 1's, as on the loop's back edge: the
+    fetch(GK, ra[1], rb[1]);                         // waits at the loop head are counted against the worse of the two orders
+    __builtin_amdgcn_sched_barrier(0);
+    const int k_full = (K / GK) * GK;                // [0, k_full): whole chunks
+    int k0 = 0;
+    for (; k0 + 2 * GK <= k_full; k0 += 2 * GK) {    // pairs of whole chunks: one straight-line body, register sets 0 / 1 never merge
+        chunk(k0, std::false_type{}, ra[0], rb[0]);
+        chunk(k0 + GK, std::false_type{}, ra[1], rb[1]);
+    }
+    if (k0 < K) {                                    // at most one whole chunk and the tail are left
+        chunk(k0, std::true_type{}, ra[0], rb[0]);
+        if (k0 + GK < K) chunk(k0 + GK, std::true_type{}, ra[1], rb[1]);
     }
     const int n = n0 + wn * 32 + i;
     if (n >= N) return;
@@ -97,8 +133,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 
 static int launch_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
                        long ldc, Epi ep, hipStream_t st) {
+    const long bytes_a = ((long)(M - 1) * sam + (long)(K - 1) * sak + 1) * 4, bytes_b = ((long)(N - 1) * sbn + (long)(K - 1) * sbk + 1) * 4;
+    if (bytes_a >= (1L << 30) || bytes_b >= (1L << 30)) {
+        set_error("gemm operand of %ld / %ld bytes exceeds the 1 GiB the buffer addressing of this kernel covers", bytes_a, bytes_b);
+        return RBR_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, C,
-                       ldc, ep);
+                       ldc, ep, bytes_a, bytes_b);
     RBR_CHECK_LAUNCH("gemm launch");
     return 0;
 }
