@@ -415,15 +415,17 @@ def main():
             launch_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches"
             torch.cuda.synchronize()
 
-    def make_runner(bs):
+    def make_runner(bs, st=None, sync=None):
         """step(i) over the resident batches `bs`: len(bs) == 1 replays the batch already in the input block."""
+        st = stepper if st is None else st
+        sync = grad_sync if sync is None else sync
         if use_graph:
             if len(bs) == 1:
-                stepper(*bs[0])               # resident from here on
-                return lambda i: stepper()
-            blobs = [stepper.pack(*b) for b in bs]
-            return lambda i: stepper(packed=blobs[i % len(blobs)])
-        return lambda i: train_step(model, opt, bs[i % len(bs)][0], bs[i % len(bs)][1], grad_sync=grad_sync)
+                st(*bs[0])               # resident from here on
+                return lambda i: st()
+            blobs = [st.pack(*b) for b in bs]
+            return lambda i: st(packed=blobs[i % len(blobs)])
+        return lambda i: train_step(model, opt, bs[i % len(bs)][0], bs[i % len(bs)][1], grad_sync=sync)
 
     def timed_blocks(step, min_s=MIN_TIMED_S, max_repeats=400):
         """Blocks of exactly a.steps steps, barrier + synchronize on both sides, max over ranks; repeated until the timed
@@ -495,6 +497,25 @@ def main():
             model(*args)
         torch.cuda.synchronize()
         fwd_s = (time.perf_counter() - f0) / 20
+
+    # BASELINE configs[4] names this job's 8-GPU point in bf16 ("batch 2048 data-parallel, RCCL grad all-reduce, bf16"): the same
+    # ranks once more with the conv contraction in plain bf16 (f32 accumulate) and every gradient all-reduced densely in a bf16
+    # wire format.  A variant beside the fp32 line (whose dtype matches the N = 1 point), never the headline.
+    if world > 1 and not a.no_variants:
+        grad_sync.close()                               # uninstalls the tap sink: the table gradient is dense again
+        RF.set_prod_precision("bf16")
+        model.train()
+        sync5 = GradAllReduce(model, comm_dtype=torch.bfloat16)
+        try:
+            st5 = GraphedTrainStep(model, opt, args, ratings, grad_sync=sync5) if use_graph else None
+            blk = timed_blocks(make_runner(batches, st=st5, sync=sync5), min_s=0.25)
+            variants["cfg5_bf16"] = {"ms_per_step": round(1e3 * statistics.median(blk) / a.steps, 4),
+                                     "pairs_per_s": round(cfg["B"] * world * a.steps / statistics.median(blk), 1),
+                                     "repeats": len(blk), "dtype": "bf16 conv operands (f32 accumulate), f32 parameters and Adam state",
+                                     "grad_exchange": "RCCL all-reduce of every gradient, bf16 wire format"}
+        except Exception as e:
+            variants["cfg5_bf16"] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+        RF.set_prod_precision(precision)
 
     if rank == 0:
         flops = conv_fwd_flops(cfg)
