@@ -463,21 +463,90 @@ __global__ __launch_bounds__(256) void taps_bounds_kernel(long total, int V, con
 }
 
 // Wprod^T rows for the rebuild (the forward's copy lives in a per-call workspace the exchange does not see)
-__global__ __launch_bounds__(256) void taps_wt_kernel(const PackJob J, const PtrArray W, float* __restrict__ WT) {
+// ... and the work items (token, part, parts, slot) of the tokens with more than kTapsSplit taps: each is summed by several
+// workgroups of taps_rows_kernel (adjacent in the list, so they run side by side) that meet in the global row `slot`.
+constexpr int kTapsCold = 16;        // wave-per-token rows: at most 4 dependent rounds of weight-row reads
+constexpr int kTapsSplit = 4096;     // taps of one token summed by one workgroup
+__global__ __launch_bounds__(256) void taps_wt_kernel(const PackJob J, const PtrArray W, float* __restrict__ WT, int V,
+                                                      const int* __restrict__ start1, const int* __restrict__ end,
+                                                      int* __restrict__ hot_count, int4* __restrict__ hot_list) {
     const long n_wt = (long)J.cp_real * J.D;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n_wt; e += (long)gridDim.x * 256) {
         const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
         WT[e] = prod_weight(J, W, pc, d);
     }
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+        const int s1 = start1[v];
+        const int cnt = (s1 == 0) ? 0 : end[v] - (s1 - 1);
+        if (cnt > kTapsSplit) {
+            const int parts = (cnt + kTapsSplit - 1) / kTapsSplit;
+            const int base = atomicAdd(hot_count, parts);
+            const int slot = atomicAdd(hot_count + 1, 1);
+            for (int p = 0; p < parts; ++p) hot_list[base + p] = int4{v, p, parts, slot};
+        }
+    }
 }
 
-// One workgroup per token id (grid-stride over the vocabulary).  The token's taps (all ranks, adjacent after the sort)
+// Rows of the tokens with at most kTapsCold taps (and the zero rows of the tokens with none): one WAVE per vocabulary entry.
+// Every rank holds the same sorted tap array (the all-gather delivers the same bytes everywhere and the sort is stable), so a
+// sum taken in ARRAY ORDER by one wave is the same bits on every rank without fixed point: lane i keeps tap i, the wave walks
+// the taps 4 at a time (4 weight rows in flight) and adds val/N * WT[col, :] in registers.  No LDS row, no compaction, no
+// barrier: at 8 ranks' taps 35 k of the 45.6 k touched tokens are of this kind, and a workgroup spent ~3 us of fixed costs
+// (zeroing and scanning a 750-cell row, four barriers) on each.  Runs as the second role of taps_rows_kernel's launch.
+__device__ __forceinline__ void taps_cold_row(const ProdBwdArgs& A, int v, int lane, const int* __restrict__ start1,
+                                              const int* __restrict__ end, const unsigned long long* __restrict__ pay,
+                                              float inv_sets, const float* __restrict__ WT, float* __restrict__ dtable) {
+    const int D = A.D, nq4 = D >> 2;
+    float* drow = dtable + (long)v * D;
+    const int s1 = start1[v];
+    const int s = s1 - 1, cnt = (s1 == 0) ? 0 : end[v] - s;
+    if (cnt > kTapsCold) return;                     // the workgroup role of taps_rows_kernel takes these
+    const unsigned long long mine = (lane < cnt) ? pay[s + lane] : 0ull;
+    const int my_off = (int)(unsigned)(mine >> 32) * D;
+    const float my_val = __int_as_float((int)(unsigned)(mine & 0xffffffffu)) * inv_sets;
+    for (int qblk = 0; qblk < nq4; qblk += 64 * kSpQ4) {
+        f32x4 sum[kSpQ4];
+        int doff[kSpQ4];
+#pragma unroll
+        for (int u = 0; u < kSpQ4; ++u) {
+            const int q4 = qblk + lane + 64 * u;
+            doff[u] = (q4 < nq4) ? 4 * q4 : -1;
+            sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int q0 = 0; q0 < cnt; q0 += 4) {
+            f32x4 wv[4][kSpQ4];
+            float gv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = q0 + t < cnt;
+                const int it = ok ? q0 + t : q0;
+                const float* wrow = WT + __shfl(my_off, it);
+                gv[t] = ok ? __shfl(my_val, it) : 0.f;
+#pragma unroll
+                for (int u = 0; u < kSpQ4; ++u)
+                    wv[t][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < kSpQ4; ++u) sum[u] += gv[t] * wv[t][u];
+        }
+#pragma unroll
+        for (int u = 0; u < kSpQ4; ++u)
+            if (doff[u] >= 0) *reinterpret_cast<f32x4*>(drow + doff[u]) = sum[u];
+    }
+}
+
+// One workgroup per listed (hot) token.  The token's taps (all ranks, adjacent after the sort)
 // are summed into an LDS row of 64-bit fixed-point cells (2^-40 units, integer atomics: the sum does not depend on the
 // order, so every rank gets the same bits), then the row goes through the same compaction + sparse product as
-// g_times_w_kernel; tokens without taps get a zero row.  No global G, no zero-fill, no global atomics.
-__global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, const int KGW, int V, const int* __restrict__ start1,
+// g_times_w_kernel.  No global G, no zero-fill, no global atomics.
+__global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, const int KGW, int V, const int* __restrict__ hot_count,
+                                                        const int4* __restrict__ hot_list, const int* __restrict__ start1,
                                                         const int* __restrict__ end, const unsigned long long* __restrict__ pay,
-                                                        float gscale, const float* __restrict__ WT, float* __restrict__ dtable) {
+                                                        float gscale, const float* __restrict__ WT, float* __restrict__ dtable,
+                                                        unsigned long long* __restrict__ split_rows, int* __restrict__ split_arrived,
+                                                        int n_row_wgs) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     long long* s_g = reinterpret_cast<long long*>(s_dyn);                          // [KG]
@@ -490,14 +559,31 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
     const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);
     __shared__ int s_poison;      // a non-finite tap (NaN / inf gradient on some rank): the token's row becomes NaN, as the dense
                                   // all-reduce would propagate it, instead of vanishing in the float -> fixed-point conversion
-    for (int v = blockIdx.x; v < V; v += gridDim.x) {
-        const int s1 = start1[v];                        // workgroup-uniform
-        float* drow = dtable + (long)v * D;
-        if (s1 == 0) {
-            for (int q4 = tid; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(drow + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
-            continue;
+    __shared__ int s_last;
+    if ((int)blockIdx.x >= n_row_wgs) {                  // second role: a wave per vocabulary entry, the cold and the empty rows
+        const int v = ((int)blockIdx.x - n_row_wgs) * kWavesPerWG + wave;     // (dispatched after the row workgroups: interleaving
+        if (v < V) taps_cold_row(A, v, lane, start1, end, pay, gscale * kTapScale, WT, dtable);   // the roles delayed the long items, +100 us)
+        return;
+    }
+    const int n_hot = *hot_count;
+    // the parts of the split tokens first (the longest items), then the vocabulary, of which this role takes the tokens
+    // with more than kTapsCold and at most kTapsSplit taps
+    for (int h = blockIdx.x; h < n_hot + V; h += n_row_wgs) {
+        int4 item;                                       // workgroup-uniform: token, part, parts, slot
+        int s, e;
+        if (h < n_hot) {
+            item = hot_list[h];
+            s = start1[item.x] - 1 + item.y * kTapsSplit;
+            e = min(end[item.x], s + kTapsSplit);
+        } else {
+            item = int4{h - n_hot, 0, 1, -1};
+            const int s1 = start1[item.x];
+            if (s1 == 0) continue;
+            s = s1 - 1; e = end[item.x];
+            if (e - s <= kTapsCold || e - s > kTapsSplit) continue;
         }
-        const int s = s1 - 1, e = end[v];
+        const int v = item.x;
+        float* drow = dtable + (long)v * D;
         for (int k = tid; k < A.KG; k += 256) s_g[k] = 0;
         if (tid == 0) s_poison = 0;
         __syncthreads();
@@ -519,6 +605,24 @@ __global__ __launch_bounds__(256) void taps_rows_kernel(const ProdBwdArgs A, con
             }
         }
         __syncthreads();
+        if (item.z > 1) {
+            // a part of a split token: its cells go into the token's global row (64-bit integer adds: order-free, lanes on
+            // adjacent cells); the part that arrives last takes the complete row back and carries on alone
+            unsigned long long* grow = split_rows + (long)item.w * A.KG;
+            for (int k = tid; k < A.KG; k += 256)
+                if (s_g[k] != 0) atomicAdd(grow + k, (unsigned long long)s_g[k]);
+            if (s_poison) atomicOr(split_arrived + 2 * item.w + 1, 1);
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) s_last = atomicAdd(split_arrived + 2 * item.w, 1) == item.z - 1;
+            __syncthreads();
+            if (!s_last) continue;                       // workgroup-uniform
+            __threadfence();
+            for (int k = tid; k < A.KG; k += 256)       // agent-scope loads: the other parts' adds were made by other XCDs
+                s_g[k] = (long long)__hip_atomic_load(grow + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) s_poison = __hip_atomic_load(split_arrived + 2 * item.w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+        }
         // non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
         int cnt = 0;
         for (int k0 = kbeg; k0 < kend; k0 += 64) {
@@ -1142,7 +1246,7 @@ bool taps_args(const rbr_textcnn_desc* d, ProdBwdArgs& A, int& cp_real, int& KG)
     A.KG = KG;
     return true;
 }
-struct TapsLayout { size_t keys_in, keys, pay_in, pay, start1, end, WT, temp, total; size_t temp_bytes; int KGW; };
+struct TapsLayout { size_t keys_in, keys, pay_in, pay, start1, end, hot_count, hot_list, split_arrived, split_rows, WT, temp, total; size_t temp_bytes; int KGW, max_split; };
 bool taps_layout(const rbr_textcnn_desc* d, int n_sets, long n_items, int cp_real, int KG, TapsLayout& T) {
     if (d->D % 4 != 0 || n_sets <= 0) return false;
     T.KGW = ((KG / 4 + kWavesPerWG - 1) / kWavesPerWG) * 4;
@@ -1159,6 +1263,11 @@ bool taps_layout(const rbr_textcnn_desc* d, int n_sets, long n_items, int cp_rea
     T.pay = o;     o += align256(total * sizeof(unsigned long long));
     T.start1 = o;  o += align256((size_t)d->V * sizeof(int));
     T.end = o;     o += align256((size_t)d->V * sizeof(int));
+    T.hot_count = o; o += 256;
+    T.max_split = (int)(total / kTapsSplit) + 1;                 // tokens with more than kTapsSplit taps
+    T.hot_list = o; o += align256(((size_t)d->V + 2 * (size_t)T.max_split) * sizeof(int4));     // parts: at most cnt / kTapsSplit + 1 per token
+    T.split_arrived = o; o += align256((size_t)T.max_split * 2 * sizeof(int));                  // contiguous with split_rows: zeroed together
+    T.split_rows = o; o += align256((size_t)T.max_split * KG * sizeof(unsigned long long));
     T.WT = o;      o += align256((size_t)cp_real * d->D * sizeof(float));
     T.temp = o;    o += align256(T.temp_bytes) + 256;
     T.total = o;
@@ -1217,7 +1326,15 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
     if (int e = check_hip(rocprim::radix_sort_pairs(base + T.temp, temp_bytes, keys_in, keys, pay_in, pay, (size_t)total, 0, bits, st),
                           "textcnn taps radix sort"))
         return e;
-    if (int e = zero_words(start1, align256((size_t)d->V * sizeof(int)), st)) return e;
+    int* hot_count = reinterpret_cast<int*>(base + T.hot_count);
+    int4* hot_list = reinterpret_cast<int4*>(base + T.hot_list);
+    int* split_arrived = reinterpret_cast<int*>(base + T.split_arrived);
+    unsigned long long* split_rows = reinterpret_cast<unsigned long long*>(base + T.split_rows);
+    {
+        ZeroRegions z{{start1, hot_count, split_arrived},
+                      {(long)(align256((size_t)d->V * sizeof(int)) / sizeof(int)), 64, (long)((T.WT - T.split_arrived) / sizeof(int))}};
+        if (int e = zero_regions(z, st)) return e;
+    }
     hipLaunchKernelGGL(taps_bounds_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, total, d->V, keys,
                        start1, end);
     RBR_CHECK_LAUNCH("textcnn taps bounds launch");
@@ -1226,11 +1343,13 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
     for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = A.poff[w]; }
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
-    hipLaunchKernelGGL(taps_wt_kernel, dim3((unsigned)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024)), dim3(256), 0, st, J, wp, WT);
+    hipLaunchKernelGGL(taps_wt_kernel, dim3((unsigned)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024)), dim3(256), 0, st, J, wp, WT,
+                       d->V, start1, end, hot_count, hot_list);
     RBR_CHECK_LAUNCH("textcnn taps weights launch");
     const size_t lds = (size_t)KG * 8 + (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    hipLaunchKernelGGL(taps_rows_kernel, dim3((unsigned)std::min(d->V, 16384)), dim3(256), lds, st, A, T.KGW, d->V, start1, end, pay,
-                       1.f / (kTapScale * (float)n_sets), WT, dtable);
+    const int n_row_wgs = std::min(d->V, 8192), n_cold_wgs = (d->V + kWavesPerWG - 1) / kWavesPerWG;
+    hipLaunchKernelGGL(taps_rows_kernel, dim3((unsigned)(n_row_wgs + n_cold_wgs)), dim3(256), lds, st, A, T.KGW, d->V, hot_count, hot_list,
+                       start1, end, pay, 1.f / (kTapScale * (float)n_sets), WT, dtable, split_rows, split_arrived, n_row_wgs);
     RBR_CHECK_LAUNCH("textcnn taps rows launch");
     return 0;
 }

@@ -31,8 +31,16 @@ for n_sets in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]:
     for _ in range(3):
         assert L_.rbr_textcnn_dtable_from_taps(C.byref(d), n_sets, tok.data_ptr(), val.data_ptr(), W, wsb.data_ptr(), dtable.data_ptr(), st) == 0
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(20):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    host = []
+    evs[0].record()
+    for k in range(20):
+        h0 = time.perf_counter()
         L_.rbr_textcnn_dtable_from_taps(C.byref(d), n_sets, tok.data_ptr(), val.data_ptr(), W, wsb.data_ptr(), dtable.data_ptr(), st)
+        host.append(time.perf_counter() - h0)
+        evs[k + 1].record()
     torch.cuda.synchronize()
-    print(f"n_sets={n_sets}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per rebuild; union tokens {int((tok >= 0).sum())} taps, "
+    per = sorted(evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(20))
+    print(f"n_sets={n_sets}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per rebuild (events: median {per[10]:.1f}, max {per[-1]:.1f}; "
+          f"host call median {sorted(host)[10] * 1e6:.0f}, max {max(host) * 1e6:.0f} us); union tokens {int((tok >= 0).sum())} taps, "
           f"{int(torch.unique(tok[tok >= 0]).numel())} distinct; payload {n * 8 / 1e6:.1f} MB per rank", flush=True)
