@@ -162,6 +162,12 @@ int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int64_t* ids, c
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                 const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                 float* dtable, float* dgate, void* stream);
+/* The two halves of rbr_textcnn_bwd_dtable_prod as separate calls (G is always built; dgate as above): for a caller that
+ * runs other consumers of G -- rbr_textcnn_bwd_dw_from_g -- beside the product, on another stream. */
+int rbr_textcnn_bwd_g_build(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                            const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                            float* dgate, void* stream);
+int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, float* dtable, void* stream);
 /* Conv weight / bias gradients from the G the call above left in `bwd_ws` (dW = G^T @ table[distinct tokens] on the f32
  * MFMA pipe, split over token ranges, fixed-order reduce).  For many short documents (NARRE's reviews) this replaces
  * rbr_textcnn_bwd_dw; rbr_textcnn_bwd_dw_from_g_ws_floats(d) == 0 means "use rbr_textcnn_bwd_dw".  Needs the SAME fwd_ws /

@@ -89,6 +89,9 @@ SIGNATURES = {
     "rbr_textcnn_bwd_prod_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
                                               c_f32p, c_f32p, c_stream]),
+    "rbr_textcnn_bwd_g_build": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p, c_f32p,
+                                          c_stream]),
+    "rbr_textcnn_bwd_g_product": (C.c_int, [_DESC, C.c_void_p, C.c_void_p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_dtable_list_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dtable_list": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_f32p, c_i32p, c_f32p, C.c_void_p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_dw_from_g_ws_floats": (C.c_size_t, [_DESC]),

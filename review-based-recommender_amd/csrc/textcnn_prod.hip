@@ -931,9 +931,10 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
+enum { kGBuild = 1, kGProduct = 2 };     // phases of dtable_through_list
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                               float* dtable, float* dgate, hipStream_t st);
+                               float* dtable, float* dgate, hipStream_t st, int phases = kGBuild | kGProduct);
 
 extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                            const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
@@ -947,11 +948,34 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream);
 }
 
+// The two halves of rbr_textcnn_bwd_dtable_prod as separate calls, for callers that put work between them or beside the
+// second one (functional: NARRE's dW = G^T @ table rows runs on a second stream while the product runs on the first).
+extern "C" int rbr_textcnn_bwd_g_build(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                       const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                       float* dgate, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (dgate != nullptr && gate == nullptr) dgate = nullptr;
+    if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, nullptr, dgate, (hipStream_t)stream,
+                               kGBuild);
+}
+
+extern "C" int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, float* dtable, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (!fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    return dtable_through_list(d, plans, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, fwd_ws, bwd_ws, dtable, nullptr,
+                               (hipStream_t)stream, kGProduct);
+}
+
 // G over the token list in `fwd_ws` (ProdLayout), then dtable = G @ Wprod^T; shared by the token-product backward (the
 // forward's list) and by the dense formulation's backward (a list built for the purpose, rbr_textcnn_bwd_dtable_list)
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                               float* dtable, float* dgate, hipStream_t st) {
+                               float* dtable, float* dgate, hipStream_t st, int phases) {
     ProdLayout Lo;
     ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
@@ -976,16 +1000,20 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
         A.kz[w] = d->kz[w]; A.ch[w] = d->ch[w]; A.ch_off[w] = plans[0].ch_off[w];
         A.poff[w] = cp_real; cp_real += d->kz[w] * d->ch[w];
     }
-    if (dtable != nullptr) {
-        hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
-        RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+    // kGBuild alone (rbr_textcnn_bwd_g_build) always builds G: its caller multiplies it out later (rbr_textcnn_bwd_g_product)
+    const bool want_g = dtable != nullptr || !(phases & kGProduct);
+    if (phases & kGBuild) {
+        if (want_g) {
+            hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
+            RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+        }
+        const long n_items = (long)d->n_docs * A.C * A.KF;
+        hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
+                           reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat,
+                           want_g ? G : nullptr, dgate);
+        RBR_CHECK_LAUNCH("textcnn build_g launch");
     }
-    const long n_items = (long)d->n_docs * A.C * A.KF;
-    hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
-                       reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat,
-                       dtable != nullptr ? G : nullptr, dgate);
-    RBR_CHECK_LAUNCH("textcnn build_g launch");
-    if (dtable == nullptr) return 0;
+    if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
                        tok_of_row, row_of_token, d->V, dtable);

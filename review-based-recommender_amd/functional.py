@@ -313,6 +313,38 @@ class _TextCNN(torch.autograd.Function):
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
             # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
             bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+            if dwg_floats:
+                # G first; then its two consumers side by side: dtable = G @ Wprod^T on this stream, dW = G^T @ table rows on the
+                # second one (fork after the build, join before returning; two parallel branches in a captured graph)
+                check(L_.rbr_textcnn_bwd_g_build(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                 dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dgate, F32, "dgate"), st),
+                      "rbr_textcnn_bwd_g_build")
+                dwg_ws = torch.empty(dwg_floats, dtype=F32, device=dev)
+                side = _side_stream(dev)
+                if side is not None:
+                    fork = torch.cuda.Event()
+                    fork.record()
+                    side.wait_event(fork)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    ev2 = TIMER.record("textcnn_bwd_dw")
+                    check(L_.rbr_textcnn_bwd_dw_from_g(C.byref(desc), dev_ptr(table, F32, "table"), dev_ptr(feat, F32, "feat"),
+                                                       dev_ptr(d_feat, F32, "d_feat"), ctx.prod_ws.data_ptr(), bws.data_ptr(),
+                                                       ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                                       dev_ptr(dwg_ws, F32, "ws"), current_stream()), "rbr_textcnn_bwd_dw_from_g")
+                    if ev2 is not None:
+                        ev2.record()
+                    if side is not None:
+                        join = torch.cuda.Event()
+                        join.record()
+                if need_table:
+                    check(L_.rbr_textcnn_bwd_g_product(C.byref(desc), ctx.prod_ws.data_ptr(), bws.data_ptr(),
+                                                       dev_ptr(dtable, F32, "dtable"), st), "rbr_textcnn_bwd_g_product")
+                if ev is not None:
+                    ev.record()
+                _join(join)
+                return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
             check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
                                                  dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
                                                  dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
@@ -320,15 +352,6 @@ class _TextCNN(torch.autograd.Function):
                                                  dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
-            if dwg_floats:
-                ev = TIMER.record("textcnn_bwd_dw")
-                dwg_ws = torch.empty(dwg_floats, dtype=F32, device=dev)
-                check(L_.rbr_textcnn_bwd_dw_from_g(C.byref(desc), dev_ptr(table, F32, "table"), dev_ptr(feat, F32, "feat"),
-                                                   dev_ptr(d_feat, F32, "d_feat"), ctx.prod_ws.data_ptr(), bws.data_ptr(),
-                                                   ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
-                                                   dev_ptr(dwg_ws, F32, "ws"), st), "rbr_textcnn_bwd_dw_from_g")
-                if ev is not None:
-                    ev.record()
             _join(join)
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if list_bytes:
