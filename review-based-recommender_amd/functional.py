@@ -277,6 +277,8 @@ class _TextCNN(torch.autograd.Function):
         # table-gradient call builds anyway (0 floats of workspace = not this shape: the window-row kernels below)
         dwg_floats = L_.rbr_textcnn_bwd_dw_from_g_ws_floats(C.byref(desc)) if (need_table and bws_bytes) else 0
         join = None
+        fork = None
+        side = None
         if not dwg_floats:
             # the weight-gradient kernels and the table-gradient kernels below both start from d_feat and share nothing
             # else: the former go to a second stream (fork here, join before returning), so the two chains overlap --
@@ -285,18 +287,29 @@ class _TextCNN(torch.autograd.Function):
             if side is not None:
                 fork = torch.cuda.Event()
                 fork.record()
+
+        def run_dw():
+            """The weight-gradient chain, enqueued AFTER the table-gradient chain: in a replayed graph the branch captured first
+            keeps the queue of the nodes before and after the fork, and the join of the other branch into that queue costs
+            ~10 us -- so the longer (table) branch goes first and the step's next kernel follows it without a gap."""
+            if dwg_floats:
+                return join
+            j = None
+            if side is not None:
                 side.wait_event(fork)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                ev = TIMER.record("textcnn_bwd_dw")
+                ev_dw = TIMER.record("textcnn_bwd_dw")
                 check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
                                             dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
                                             ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"), current_stream()),
                       "rbr_textcnn_bwd_dw")
-                if ev is not None:
-                    ev.record()
+                if ev_dw is not None:
+                    ev_dw.record()
                 if side is not None:
-                    join = torch.cuda.Event()
-                    join.record()
+                    j = torch.cuda.Event()
+                    j.record()
+            return j
+
         ev = TIMER.record("textcnn_bwd_dtable")
         if use_taps:
             tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
@@ -307,7 +320,7 @@ class _TextCNN(torch.autograd.Function):
             sink.record(desc, list(ws))
             if ev is not None:
                 ev.record()
-            _join(join)
+            _join(run_dw())
             return (None, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if (need_table or need_gate) and bws_bytes:
             # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
@@ -352,7 +365,7 @@ class _TextCNN(torch.autograd.Function):
                                                  dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
-            _join(join)
+            _join(run_dw())
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if list_bytes:
             lws = torch.empty(list_bytes, dtype=torch.uint8, device=dev)
@@ -362,7 +375,7 @@ class _TextCNN(torch.autograd.Function):
                                                  dev_ptr(dtable, F32, "dtable"), st), "rbr_textcnn_bwd_dtable_list")
             if ev is not None:
                 ev.record()
-            _join(join)
+            _join(run_dw())
             return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
         if packed is None:
             packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
@@ -372,7 +385,7 @@ class _TextCNN(torch.autograd.Function):
               "rbr_textcnn_bwd_dtable")
         if ev is not None:
             ev.record()
-        _join(join)
+        _join(run_dw())
         return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
 
 

@@ -8,7 +8,7 @@ idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 best = None
 for a, b in zip(idx, idx[1:]):                                  # the shortest anchor-to-anchor interval: a replayed step
     w = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])
-    if best is None or w < best[0]: best = (w, a, b)
+    if b - a >= 10 and (best is None or w < best[0]): best = (w, a, b)        # at least 10 kernels: not a back-to-back timing loop
 w, a, b = best
 seg = rows[a + 1:b + 1]
 t0 = int(rows[a]["End_Timestamp"])
