@@ -872,7 +872,9 @@ int run_conv_groups(const ConvPlan* plans, int ngroups, const long long* ids, co
 extern "C" int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx,
                                          const float* const* bias, float* feat, int32_t* argmax, void* stream) {
     ConvPlan plans[kMaxGroups];
-    const int ng = build_plans(d, plans);
+    // the widest groups a plan can describe (the slot order and the partials' layout do not depend on the grouping): one launch
+    // for up to 256 channel slots instead of one per 160
+    const int ng = build_plans(d, plans, kMaxTiles);
     if (!ng) return RBR_ERR_BAD_ARG;
     if (!pval || !pidx || !bias || !feat || !argmax) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     PtrArray bp{};
