@@ -1,6 +1,6 @@
 """Secondary measurements (not the driver's bench line): NARRE cfg3, D-ATT cfg4 and SimpleSiamese (defalut_simple_train.json
 shape, batch 256) forward / train step on one GPU, plus the CPU oracle's forward on the same batch.
-python tools/bench_models.py [narre|datt|siamese|all] [--cpu] [--no-graph]"""
+python tools/bench_models.py [narre|datt|siamese|all] [--cpu] [--no-graph] [--precision=bf16]"""
 import contextlib, io, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -9,6 +9,10 @@ from review_based_recommender_amd import _lib
 from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
 
 dev = torch.device("cuda:0")
+PRECISION = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--precision=")), None)   # f32 | bf16x3 | bf16x2 | bf16
+if PRECISION:
+    from review_based_recommender_amd import functional as _RF
+    _RF.set_prod_precision(PRECISION)
 
 
 def quiet(fn, *a):
@@ -53,7 +57,7 @@ def run(name, model, args, ratings, B, flops_fwd, bytes_fwd_per_pair):
             model(*args)
         torch.cuda.synchronize()
         fwd = (time.perf_counter() - t0) / n
-    print(json.dumps({"model": name, "train_graph_ms": None if graph_ms is None else round(graph_ms, 3),
+    print(json.dumps({"model": name, "conv_precision": PRECISION or "bf16x3 (default)", "train_graph_ms": None if graph_ms is None else round(graph_ms, 3),
                       "train_graph_pairs_per_s": None if graph_ms is None else round(B / graph_ms * 1e3, 1),
                       "train_ms": round(step * 1e3, 3), "train_pairs_per_s": round(B / step, 1),
                       "fwd_ms": round(fwd * 1e3, 3), "fwd_pairs_per_s": round(B / fwd, 1),
