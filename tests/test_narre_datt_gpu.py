@@ -129,13 +129,14 @@ def test_datt_cfg4_full_step(golden_dir, conv_mode):
             check_params_after(model, g, f"after{step + 1}")
 
 
-def test_global_gate_backward_over_token_rows_matches_the_plain_one():
+@pytest.mark.parametrize("L", [512, 1280])
+def test_global_gate_backward_over_token_rows_matches_the_plain_one(L):
     """rbr_datt_global_gate_bwd_rows (private row-compacted copies of the table gradient, dtable overwritten) against
     rbr_datt_global_gate_bwd (atomics straight into a zeroed dtable): same dw / db0 bit for bit, same dtable to f32 sum
     reordering; Zipf-like ids so that hot rows exist, pad tokens included."""
     from review_based_recommender_amd import functional as RF
     gen = torch.Generator().manual_seed(5)
-    B, L, V, E = 24, 512, 3000, 100
+    B, V, E = 24, 3000, 100            # L = 1280: rows longer than the 1024 positions a wave holds at a time
     ids = (torch.rand(B, L, generator=gen) ** 4 * V).long().clamp_(0, V - 1).to(DEV)
     table = (torch.randn(V, E, generator=gen) * 0.3).to(DEV).requires_grad_()
     w = (torch.randn(1, E, L, generator=gen) * 0.05).to(DEV).requires_grad_()
