@@ -497,6 +497,22 @@ def main():
             model(*args)
         torch.cuda.synchronize()
         fwd_s = (time.perf_counter() - f0) / 20
+    fwd_graph_s = None
+    if use_graph:                                   # the same forward replayed from a hipGraph (train_step.GraphedForward)
+        try:
+            from review_based_recommender_amd.train_step import GraphedForward
+            gf = GraphedForward(model, args)
+            blobs = [gf.pack(b[0]) for b in batches]
+            for i in range(5):
+                gf(packed=blobs[i % nb])
+            torch.cuda.synchronize()
+            f0 = time.perf_counter()
+            for i in range(100):
+                gf(packed=blobs[i % nb])
+            torch.cuda.synchronize()
+            fwd_graph_s = (time.perf_counter() - f0) / 100
+        except Exception as e:
+            launch_note = (launch_note or "") + f" [forward graph failed: {type(e).__name__}]"
 
     # BASELINE configs[4] names this job's 8-GPU point in bf16 ("batch 2048 data-parallel, RCCL grad all-reduce, bf16"): the same
     # ranks once more with the conv contraction in plain bf16 (f32 accumulate) and every gradient all-reduced densely in a bf16
@@ -542,6 +558,7 @@ def main():
                        "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)",
                        "grad_exchange": None if world == 1 else (exchange_note or f"RCCL all-reduce, {a.comm_dtype} wire format, before the clip")},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
+            "fwd_only_graph_pairs_per_s": None if fwd_graph_s is None else round(cfg["B"] / fwd_graph_s, 1),
             "kernels_ms": {k: round(v[1], 4) for k, v in ksum.items()},
             "kernel_timing": "HIP events around the C-ABI launches, eager pass over the same steps after the timed region",
         }

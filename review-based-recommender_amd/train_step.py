@@ -200,6 +200,61 @@ def _flat_views(flat: torch.Tensor, layout, like):
     return [flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(layout, like)]
 
 
+class GraphedForward:
+    """model(*batch) under torch.no_grad(), recorded once into a hipGraph and replayed: the eval / serving forward of a
+    fixed batch shape (the trainers' validation loops, trainer/train_deepconn_pp.py:171-196: ~25 short kernels whose eager
+    launches leave the GPU waiting on Python).  The model's train/eval mode at construction is what the graph holds -- put
+    the model in eval() first.  __call__ copies a batch of the same shapes into the static input block (one copy when it was
+    pack()ed) and replays; the returned prediction tensor is static: overwritten by the next replay."""
+
+    def __init__(self, model: nn.Module, batch, warmup: int = 2, capture_error_mode: str = "global"):
+        batch = list(batch)
+        if not batch or not batch[0].is_cuda:
+            raise RuntimeError("GraphedForward needs HIP tensors")
+        self.model = model
+        self._layout = _flat_layout(batch)
+        self._flat = torch.empty(self._layout[-1], dtype=torch.uint8, device=batch[0].device)
+        views = _flat_views(self._flat, self._layout, batch)
+        for v, src in zip(views, batch):
+            v.copy_(src)
+        self.batch = tuple(views)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up off the default stream (allocator, lazy module state)
+            for _ in range(warmup):
+                model(*self.batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+            out = model(*self.batch)
+        self.pred = out[0] if isinstance(out, tuple) else out
+
+    def matches(self, batch) -> bool:
+        """True when `batch` has the shapes and dtypes the graph was recorded with (a ragged last batch does not)."""
+        return len(batch) == len(self.batch) and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(batch, self.batch))
+
+    def pack(self, batch) -> torch.Tensor:
+        blob = torch.empty_like(self._flat)
+        for v, src in zip(_flat_views(blob, self._layout, list(batch)), batch):
+            v.copy_(src)
+        return blob
+
+    def __call__(self, batch=None, packed: torch.Tensor | None = None) -> torch.Tensor:
+        if packed is not None:
+            if packed.shape != self._flat.shape or packed.dtype != torch.uint8:
+                raise RuntimeError("packed batch does not match the forward's input layout (use GraphedForward.pack)")
+            self._flat.copy_(packed, non_blocking=True)
+        if batch is not None:
+            if not self.matches(batch):
+                raise RuntimeError("batch shapes differ from the recorded forward's (run ragged batches eagerly)")
+            for dst, src in zip(self.batch, batch):
+                if dst is not src:
+                    dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.pred
+
+
 class GraphedTrainStep:
     """train_step() recorded once into a hipGraph and replayed: the step is ~70 short kernels (0.8 ms of GPU
     work at the cfg2 shape), so launching them one by one from Python leaves the GPU waiting on the host.

@@ -35,7 +35,7 @@ import torch.nn as nn
 
 from . import data as D
 from . import functional as RF
-from .train_step import GraphedTrainStep, make_optimizer, train_step
+from .train_step import GraphedForward, GraphedTrainStep, make_optimizer, train_step
 
 
 class Args:
@@ -289,6 +289,23 @@ class ReviewExperiment:
         loss, gnorm, _ = train_step(self.model, self.optimizer, inputs, ratings, a.max_grad_norm, self.grad_sync)
         return loss, gnorm
 
+    def _eval_forward(self, inputs):
+        """The eval forward: replayed from a hipGraph for the loader's regular batch shape (recorded at first use; the
+        parameters are read in place, so training steps in between need no re-recording), eager for any other shape
+        (the ragged last batch) and when graphs are off."""
+        if self.args.fast_step and inputs and inputs[0].is_cuda:
+            g = getattr(self, "_graphed_eval", None)
+            if g is None:
+                try:
+                    g = self._graphed_eval = GraphedForward(self.model, inputs)
+                except Exception as e:          # a capture the runtime refuses costs the speed-up, not the validation
+                    self.print_write_to_log(f"eval forward not graphed ({type(e).__name__}: {str(e)[:100]})")
+                    g = self._graphed_eval = False
+            if g and g.matches(inputs):
+                return g(inputs)
+        out = self.model(*inputs)
+        return out[0] if isinstance(out, tuple) else out
+
     def valid_one_epoch(self):
         loader = self.valid_loader
         sq_err = torch.zeros((), device=self.device, dtype=torch.float64)
@@ -299,8 +316,7 @@ class ReviewExperiment:
         with torch.no_grad():
             for batch in loader:
                 inputs, ratings = self._to_device(batch)
-                out = self.model(*inputs)
-                pred = out[0] if isinstance(out, tuple) else out
+                pred = self._eval_forward(inputs)
                 loss = self.loss_func(pred, ratings)
                 sq_err += loss.double() * ratings.size(0)
                 loss_sum += loss.double()
