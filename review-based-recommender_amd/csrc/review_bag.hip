@@ -107,37 +107,46 @@ __global__ __launch_bounds__(256) void bag_bwd_sorted_kernel(long n_pos, int T, 
     const int my_key = (lane < n) ? keys[e0 + lane] : sentinel;
     const int my_rev = (lane < n) ? vals[e0 + lane] / T : 0;
     const float my_inv = (lane < n && my_key != sentinel) ? inv_len[my_rev] : 0.f;
-    for (int d0 = 0; d0 < D; d0 += 64) {          // lanes = embedding columns
-        const int d = d0 + lane;
-        const bool on = d < D;
-        float acc = 0.f;
+    // lanes = embedding columns, two 64-column stretches per pass; 8 occurrences' gradient rows in flight (16 loads per lane):
+    // a wave walks its 64 occurrences in 8 dependent rounds instead of 16 per 64 columns (75 -> 35 us at the toys shape)
+    for (int d0 = 0; d0 < D; d0 += 128) {
+        const int da = d0 + lane, db = d0 + 64 + lane;
+        const bool ona = da < D, onb = db < D;
+        float acca = 0.f, accb = 0.f;
         int cur = __builtin_amdgcn_readfirstlane(my_key);
-        for (int j0 = 0; j0 < n; j0 += 4) {        // 4 independent gradient rows in flight
-            int t[4];
-            float g[4];
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            int t[8];
+            float ga[8], gb[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = min(j0 + u, n - 1);
                 t[u] = (j0 + u < n) ? __builtin_amdgcn_readlane(my_key, j) : sentinel;
                 const int r = __builtin_amdgcn_readlane(my_rev, j);
                 const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_inv), j));
-                g[u] = 0.f;
-                if (on && t[u] != sentinel) {
-                    g[u] = d_out[(long)r * D + d] * inv;
-                    if (drop != nullptr) g[u] *= drop[(long)r * D + d];
+                ga[u] = gb[u] = 0.f;
+                if (t[u] != sentinel) {          // wave-uniform
+                    if (ona) { ga[u] = d_out[(long)r * D + da] * inv; if (drop != nullptr) ga[u] *= drop[(long)r * D + da]; }
+                    if (onb) { gb[u] = d_out[(long)r * D + db] * inv; if (drop != nullptr) gb[u] *= drop[(long)r * D + db]; }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 if (t[u] != cur) {                  // wave-uniform
-                    if (cur != sentinel && on) atomicAdd(dtable + (long)cur * D + d, acc);
-                    acc = 0.f;
+                    if (cur != sentinel) {
+                        if (ona) atomicAdd(dtable + (long)cur * D + da, acca);
+                        if (onb) atomicAdd(dtable + (long)cur * D + db, accb);
+                    }
+                    acca = accb = 0.f;
                     cur = t[u];
                 }
-                acc += g[u];
+                acca += ga[u];
+                accb += gb[u];
             }
         }
-        if (cur != sentinel && on) atomicAdd(dtable + (long)cur * D + d, acc);
+        if (cur != sentinel) {
+            if (ona) atomicAdd(dtable + (long)cur * D + da, acca);
+            if (onb) atomicAdd(dtable + (long)cur * D + db, accb);
+        }
     }
 }
 
