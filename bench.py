@@ -628,7 +628,7 @@ def main():
                     "traffic_source": "profiles/r02_clip_adam_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)",
                     "bytes_per_launch": obytes, "avg_launch_ms": round(oms, 4), "launches_timed": oc,
                     "timing": "HIP events on the launch stream around 50 back-to-back rbr_clip_adam_step calls (two kernels each)",
-                    "note": "longest kernel of the step (rocprofv3: clip_adam_kernel 78 us + grad_sqnorm_kernel 14 us); "
+                    "note": "longest kernel of the step (rocprofv3: clip_adam_kernel 76 us + grad_sqnorm_kernel 13 us); "
                             "36 B per parameter x 15.3 M parameters; per pair: 36 * 15 301 513 / 256 = 2.15 MB of optimizer traffic"}
             else:
                 out["roofline"] = out["roofline_gemm"]
