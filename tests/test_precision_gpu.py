@@ -56,6 +56,9 @@ def _grad_norm_errs(model, g):
 def test_default_is_the_exact_split():
     from review_based_recommender_amd import functional as RF
     RF.set_prod_precision(None)
+    import os
+    if os.environ.get("RBR_PROD_PRECISION"):
+        pytest.skip("RBR_PROD_PRECISION overrides the default in this run")
     assert RF.get_prod_precision() == "bf16x3"
     with pytest.raises(ValueError):
         RF.set_prod_precision("fp8")
