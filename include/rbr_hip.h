@@ -269,11 +269,13 @@ typedef struct rbr_attn_grads {
     float* dW_rv; float* dW_id; float* dh; float* db1; float* db2; float* debd; /* debd ACCUMULATED */
 } rbr_attn_grads;
 
+/* `drop` [B,H] or NULL: the multiplier of the nn.Dropout that follows the pooled feature (narre.py:62), applied to `out` in
+ * the forward and to d_out in the backward (pass the same tensor to both). */
 int rbr_review_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
-                        const rbr_attn_params* p, float* out, float* att, float* hid, void* stream);
+                        const rbr_attn_params* p, const float* drop, float* out, float* att, float* hid, void* stream);
 size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t A);
 int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
-                        const rbr_attn_params* p, const float* att, const float* hid, const float* d_out,
+                        const rbr_attn_params* p, const float* drop, const float* att, const float* hid, const float* d_out,
                         const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat, float* ws,
                         void* stream);
 

@@ -15,7 +15,7 @@ namespace rbr {
 __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int A, const float* __restrict__ feat,
                                                        const long long* __restrict__ oid, const rbr_attn_params p,
                                                        float* __restrict__ out, float* __restrict__ att,
-                                                       float* __restrict__ hid) {
+                                                       float* __restrict__ hid, const float* __restrict__ drop) {
     extern __shared__ float sm[];
     float* s_hid = sm;                  // [R*A]
     float* s_e = s_hid + R * A;         // [R] exp(logit), then att
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
     for (int hh = tid; hh < H; hh += 256) {
         float s = 0.f;
         for (int r = 0; r < R; ++r) s = fmaf(s_e[r], s_f[r * H + hh], s);
-        out[(long)b * H + hh] = s;
+        out[(long)b * H + hh] = (drop != nullptr) ? s * drop[(long)b * H + hh] : s;     // nn.Dropout on the pooled feature (narre.py:62)
     }
 }
 
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
 __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int H, int A, const float* __restrict__ feat,
                                                               const long long* __restrict__ oid, const rbr_attn_params p,
                                                               const float* __restrict__ att, const float* __restrict__ hid,
-                                                              const float* __restrict__ d_out,
+                                                              const float* __restrict__ d_out, const float* __restrict__ drop,
                                                               const float* __restrict__ d_att, int pad_idx,
                                                               float* __restrict__ debd, float* __restrict__ d_feat,
                                                               float* __restrict__ ws_dpre, float* __restrict__ ws_dl) {
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         const int wave = tid >> 6, lane = tid & 63;
         for (int r = wave; r < R; r += 4) {
             float s = 0.f;
-            for (int hh = lane; hh < H; hh += 64) s = fmaf(d_out[(long)b * H + hh], fb[(long)r * H + hh], s);
+            for (int hh = lane; hh < H; hh += 64) {
+                const float g = (drop != nullptr) ? d_out[(long)b * H + hh] * drop[(long)b * H + hh] : d_out[(long)b * H + hh];
+                s = fmaf(g, fb[(long)r * H + hh], s);
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if (lane == 0) s_da[r] = s + ((d_att != nullptr) ? d_att[(long)b * R + r] : 0.f);
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
     const bool vec = (A & 3) == 0 && ((((uintptr_t)p.W_rv) | ((uintptr_t)p.W_id)) & 15) == 0;     // rows of A floats as float4
     for (int idx = tid; idx < R * H; idx += 256) {
         const int r = idx / H, hh = idx - r * H;
-        float s = ab[r] * d_out[(long)b * H + hh];
+        float s = ab[r] * ((drop != nullptr) ? d_out[(long)b * H + hh] * drop[(long)b * H + hh] : d_out[(long)b * H + hh]);
         const float* wrow = p.W_rv + (long)hh * A;
         if (vec) {
             for (int a = 0; a < A; a += 4) {
@@ -228,11 +231,11 @@ static bool attn_args_ok(int B, int R, int H, int A) {
 }
 
 extern "C" int rbr_review_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
-                                   const rbr_attn_params* p, float* out, float* att, float* hid, void* stream) {
+                                   const rbr_attn_params* p, const float* drop, float* out, float* att, float* hid, void* stream) {
     if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
     if (!feat || !other_id || !p || !out || !att || !hid) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), (size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float),
-                       (hipStream_t)stream, B, R, H, A, feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid);
+                       (hipStream_t)stream, B, R, H, A, feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid, drop);
     RBR_CHECK_LAUNCH("review_attn_fwd launch");
     return 0;
 }
@@ -243,9 +246,9 @@ extern "C" size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H,
 }
 
 extern "C" int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
-                                   const rbr_attn_params* p, const float* att, const float* hid, const float* d_out,
-                                   const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat, float* ws,
-                                   void* stream) {
+                                   const rbr_attn_params* p, const float* drop, const float* att, const float* hid,
+                                   const float* d_out, const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat,
+                                   float* ws, void* stream) {
     if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
     if (!feat || !other_id || !p || !att || !hid || !d_out || !g || !d_feat || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -253,7 +256,7 @@ extern "C" int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, c
     float* ws_dl = ws + (size_t)B * R * A;
     const long long* oid = reinterpret_cast<const long long*>(other_id);
     hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B), dim3(256), (size_t)(R * A + 2 * R) * sizeof(float), st, B, R, H, A,
-                       feat, oid, *p, att, hid, d_out, d_att, pad_idx, g->debd, d_feat, ws_dpre, ws_dl);
+                       feat, oid, *p, att, hid, d_out, drop, d_att, pad_idx, g->debd, d_feat, ws_dpre, ws_dl);
     RBR_CHECK_LAUNCH("review_attn_bwd sample launch");
     float* part = ws_dl + (size_t)B * R;
     const int N = B * R, chunks = (N + kRedRows - 1) / kRedRows, n_out = H * A + A * A + 2 * A + 1;

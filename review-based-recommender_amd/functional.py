@@ -675,7 +675,7 @@ class _ReviewAttn(torch.autograd.Function):
     """out[B,H], att[B,R,1] = LinearAttention(feat[B,R,H], other_id[B,R])  -- rbr_review_attn_* in rbr_hip.h."""
 
     @staticmethod
-    def forward(ctx, feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd):
+    def forward(ctx, feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd, drop=None):
         B, R, H = feat.shape
         A = W_rv.shape[1]
         dev = feat.device
@@ -688,18 +688,23 @@ class _ReviewAttn(torch.autograd.Function):
         out = torch.empty(B, H, dtype=F32, device=dev)
         att = torch.empty(B, R, 1, dtype=F32, device=dev)
         hid = torch.empty(B, R, A, dtype=F32, device=dev)
+        drop = drop.contiguous() if drop is not None else None
+        if drop is not None and tuple(drop.shape) != (B, H):
+            raise RuntimeError(f"review_attention: dropout multiplier {tuple(drop.shape)} is not [B, H] = {(B, H)}")
         check(L_.rbr_review_attn_fwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(ap),
-                                     dev_ptr(out, F32, "out"), dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"),
-                                     current_stream()), "rbr_review_attn_fwd")
+                                     dev_ptr(drop, F32, "drop"), dev_ptr(out, F32, "out"), dev_ptr(att, F32, "att"),
+                                     dev_ptr(hid, F32, "hid"), current_stream()), "rbr_review_attn_fwd")
         ctx.dims = (B, R, H, A, int(pad_idx))
-        ctx.save_for_backward(feat, other_id, att, hid, *params)
+        ctx.has_drop = drop is not None
+        ctx.save_for_backward(feat, other_id, att, hid, *params, *([drop] if drop is not None else []))
         return out, att
 
     @staticmethod
     def backward(ctx, d_out, d_att):
         B, R, H, A, pad_idx = ctx.dims
         feat, other_id, att, hid = ctx.saved_tensors[:4]
-        params = ctx.saved_tensors[4:]
+        params = ctx.saved_tensors[4:10]
+        drop = ctx.saved_tensors[10] if ctx.has_drop else None
         names = ("W_rv", "W_id", "h", "b1", "b2", "ebd")
         dev = feat.device
         L_ = _lib.lib()
@@ -711,15 +716,17 @@ class _ReviewAttn(torch.autograd.Function):
         d_out = d_out.contiguous()
         d_att = d_att.contiguous() if d_att is not None else None
         check(L_.rbr_review_attn_bwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(ap),
-                                     dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"), dev_ptr(d_out, F32, "d_out"),
-                                     dev_ptr(d_att, F32, "d_att"), pad_idx, C.byref(ag), dev_ptr(d_feat, F32, "d_feat"),
-                                     dev_ptr(ws, F32, "ws"), current_stream()), "rbr_review_attn_bwd")
-        return (d_feat, None, None, *grads)
+                                     dev_ptr(drop, F32, "drop"), dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"),
+                                     dev_ptr(d_out, F32, "d_out"), dev_ptr(d_att, F32, "d_att"), pad_idx, C.byref(ag),
+                                     dev_ptr(d_feat, F32, "d_feat"), dev_ptr(ws, F32, "ws"), current_stream()),
+              "rbr_review_attn_bwd")
+        return (d_feat, None, None, *grads, None)
 
 
-def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0):
-    """NARRE LinearAttention: returns (out [B,H], att [B,R,1])."""
-    return _ReviewAttn.apply(feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd)
+def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0, drop=None):
+    """NARRE LinearAttention: returns (out [B,H], att [B,R,1]).  `drop` [B,H]: the multiplier of the nn.Dropout that follows
+    (dropout_multiplier), applied inside the kernels -- forward and backward -- instead of by two elementwise launches."""
+    return _ReviewAttn.apply(feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd, drop)
 
 
 # --------------------------------------------------------------------------- nn.Linear on MFMA

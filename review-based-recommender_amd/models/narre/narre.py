@@ -31,12 +31,9 @@ class LinearAttention(nn.Module):
 
     def forward(self, feat, other_id):
         """feat [bz, dnum, hidden], other_id [bz, dnum] -> (out [bz, hidden], att_scores [bz, dnum, 1])."""
-        out, att = RF.review_attention(feat, other_id, self.W_rv, self.W_id, self.h, self.b_1, self.b_2,
-                                       self.ebd_vals.weight, pad_idx=self.padding_idx)
-        drop = RF.dropout_multiplier(out.shape, self.dropout.p, self.training, out.device, lane=self.rng_lane)
-        if drop is not None:
-            out = out * drop
-        return out, att
+        drop = RF.dropout_multiplier((feat.shape[0], feat.shape[2]), self.dropout.p, self.training, feat.device, lane=self.rng_lane)
+        return RF.review_attention(feat, other_id, self.W_rv, self.W_id, self.h, self.b_1, self.b_2,
+                                   self.ebd_vals.weight, pad_idx=self.padding_idx, drop=drop)
 
 
 class NARRE(nn.Module):

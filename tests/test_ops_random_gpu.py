@@ -63,10 +63,14 @@ def test_review_attention_random(case):
           torch.randn(A, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1, torch.randn(NI, A, generator=g) * 0.1]
     cl = [_leaf(feat)] + [_leaf(p) for p in ps]
     ro, ra = O.linear_attention(cl[0], oid, *cl[1:])
+    # odd cases: the dropout multiplier that follows the pooled feature (narre.py:62) is applied inside the kernels
+    drop = ((torch.rand(B, H, generator=g) > 0.3).float() / 0.7) if case % 2 else None
+    if drop is not None:
+        ro = ro * drop
     d = torch.randn(B, H, generator=g)
     (ro * d).sum().backward()
     gl = [_leaf(t.detach().to(DEV)) for t in [feat] + ps]
-    go, ga = RF.review_attention(gl[0], oid.to(DEV), *gl[1:], pad_idx=0)
+    go, ga = RF.review_attention(gl[0], oid.to(DEV), *gl[1:], pad_idx=0, drop=None if drop is None else drop.to(DEV))
     (go * d.to(DEV)).sum().backward()
     assert max_err(go.detach().cpu().numpy(), ro.detach().numpy()) <= 1e-5
     assert max_err(ga.detach().cpu().numpy(), ra.detach().numpy()) <= 1e-6
