@@ -696,6 +696,7 @@ class _ReviewAttn(torch.autograd.Function):
                                      dev_ptr(hid, F32, "hid"), current_stream()), "rbr_review_attn_fwd")
         ctx.dims = (B, R, H, A, int(pad_idx))
         ctx.has_drop = drop is not None
+        ctx.set_materialize_grads(False)     # an unused `att` output arrives as None in backward, not as a freshly filled zero tensor
         ctx.save_for_backward(feat, other_id, att, hid, *params, *([drop] if drop is not None else []))
         return out, att
 
@@ -713,7 +714,7 @@ class _ReviewAttn(torch.autograd.Function):
         ag = _lib.AttnGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, names)])
         d_feat = torch.empty_like(feat)
         ws = torch.empty(L_.rbr_review_attn_bwd_ws_floats(B, R, H, A), dtype=F32, device=dev)
-        d_out = d_out.contiguous()
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros(B, H, dtype=F32, device=dev)
         d_att = d_att.contiguous() if d_att is not None else None
         check(L_.rbr_review_attn_bwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(ap),
                                      dev_ptr(drop, F32, "drop"), dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"),
