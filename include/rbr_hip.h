@@ -162,6 +162,11 @@ int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int64_t* ids, c
 int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                 const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                 float* dtable, float* dgate, void* stream);
+/* rbr_textcnn_bwd_dtable_prod with the rows added to dtable instead of the whole [V,D] gradient being overwritten (see
+ * `accumulate` of the D-ATT gate backwards). */
+int rbr_textcnn_bwd_dtable_prod_acc(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                    const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                    float* dtable, float* dgate, void* stream);
 /* The two halves of rbr_textcnn_bwd_dtable_prod as separate calls (G is always built; dgate as above): for a caller that
  * runs other consumers of G -- rbr_textcnn_bwd_dw_from_g -- beside the product, on another stream. */
 int rbr_textcnn_bwd_g_build(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
@@ -301,7 +306,7 @@ int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, i
                                  const float* w, const float* b0, float* gate, void* ws, const void* rows, void* stream);
 int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids, const float* table,
                                  const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw, float* db0,
-                                 float* dtable, void* ws, const void* rows, void* stream);
+                                 float* dtable, void* ws, const void* rows, int32_t accumulate, void* stream);
 int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t win, const int64_t* ids, const float* table,
                             const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
                             float* db0, float* dtable, float* ws, void* stream);
@@ -314,13 +319,15 @@ int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids
  * matrix A[row, p] = sum of dpre over the documents that carry the row's token at position p (one scalar atomic per position
  * instead of a row of E per distinct token and window), every table row is then written once from its non-zeros, and
  * dtable [V,E] is OVERWRITTEN (absent tokens and pad_idx: 0).
- * ws: rbr_datt_global_gate_bwd_rows_ws_floats floats (0: E > 256 or L % 4 != 0 -> use rbr_datt_global_gate_bwd). */
+ * ws: rbr_datt_global_gate_bwd_rows_ws_floats floats (0: E > 256 or L % 4 != 0 -> use rbr_datt_global_gate_bwd).
+ * `accumulate` != 0 (here and in rbr_datt_local_gate_bwd_prod): the rows of the batch's tokens are ADDED to dtable -- a gradient
+ * buffer shared by the producers of one step, which run one after the other on one stream -- and nothing else is written. */
 size_t rbr_datt_token_rows_ws_bytes(int32_t B, int32_t L, int32_t V);
 int rbr_datt_token_rows(int32_t B, int32_t L, int32_t V, const int64_t* ids, void* rows, void* stream);
 size_t rbr_datt_global_gate_bwd_rows_ws_floats(int32_t B, int32_t L, int32_t E, int32_t V);
 int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, int32_t V, const int64_t* ids, const float* table,
                                   const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
-                                  float* db0, float* dtable, float* ws, const void* rows, void* stream);
+                                  float* db0, float* dtable, float* ws, const void* rows, int32_t accumulate, void* stream);
 
 /* ---- nn.Linear (+ReLU / Tanh, + dropout multiplier) on the f32 MFMA pipe: y = act(x @ W^T + b) * drop
  *      (`relu`: 0 none, 1 ReLU, 2 Tanh -- SimpleSiamese's latent_transform_layer, simple_siamese.py:24-26)

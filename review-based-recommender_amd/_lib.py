@@ -89,6 +89,8 @@ SIGNATURES = {
     "rbr_textcnn_bwd_prod_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dtable_prod": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
                                               c_f32p, c_f32p, c_stream]),
+    "rbr_textcnn_bwd_dtable_prod_acc": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
+                                                  c_f32p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_g_build": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p, c_f32p,
                                           c_stream]),
     "rbr_textcnn_bwd_g_product": (C.c_int, [_DESC, C.c_void_p, C.c_void_p, c_f32p, c_stream]),
@@ -106,7 +108,7 @@ SIGNATURES = {
     "rbr_datt_local_gate_fwd_prod": (C.c_int, [i32, i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                                C.c_void_p, c_stream]),
     "rbr_datt_local_gate_bwd_prod": (C.c_int, [i32, i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p,
-                                               c_f32p, c_f32p, C.c_void_p, C.c_void_p, c_stream]),
+                                               c_f32p, c_f32p, C.c_void_p, C.c_void_p, i32, c_stream]),
     "rbr_review_bag_fwd": (C.c_int, [i32, i32, i32, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_review_bag_bwd_ws_bytes": (C.c_size_t, [i32, i32]),
     "rbr_review_bag_bwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, i32, c_f32p, C.c_void_p,
@@ -146,7 +148,7 @@ SIGNATURES = {
     "rbr_datt_token_rows": (C.c_int, [i32, i32, i32, c_i64p, C.c_void_p, c_stream]),
     "rbr_datt_global_gate_bwd_rows_ws_floats": (C.c_size_t, [i32, i32, i32, i32]),
     "rbr_datt_global_gate_bwd_rows": (C.c_int, [i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p,
-                                                c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),
+                                                c_f32p, c_f32p, c_f32p, C.c_void_p, i32, c_stream]),
     "rbr_linear_fwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_stream]),
     "rbr_linear_bwd_ws_floats": (C.c_size_t, [i32, i32]),
     "rbr_linear_bwd": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p,

@@ -611,12 +611,13 @@ constexpr int kGgDense = 96, kGgStretch = 16;        // stretches (of 64 positio
 __global__ __launch_bounds__(256) void gg_rows_kernel(int V, int L, int E, int pad_idx, const int* __restrict__ row_of_token,
                                                       const float* __restrict__ A, const float* __restrict__ wT,
                                                       float* __restrict__ dtable, int* __restrict__ dense_count,
-                                                      int* __restrict__ dense_list) {
+                                                      int* __restrict__ dense_list, int accumulate) {
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= V) return;
     const int row = row_of_token[v];
     if (row < 0 || v == pad_idx) {
-        for (int e = lane; e < E; e += 64) dtable[(long)v * E + e] = 0.f;
+        if (!accumulate)
+            for (int e = lane; e < E; e += 64) dtable[(long)v * E + e] = 0.f;
         return;
     }
     const float* arow = A + (long)row * L;
@@ -638,14 +639,17 @@ __global__ __launch_bounds__(256) void gg_rows_kernel(int V, int L, int E, int p
         for (int q = 0; q < kGgStretch; ++q) gg_stretch(a[q], pb + q * 64, E, lane, wT, acc);
     }
 #pragma unroll
-    for (int c = 0; c < kGgChunks; ++c) { const int e = c * 64 + lane; if (e < E) dtable[(long)v * E + e] = acc[c]; }
+    for (int c = 0; c < kGgChunks; ++c) {
+        const int e = c * 64 + lane;
+        if (e < E) dtable[(long)v * E + e] = accumulate ? dtable[(long)v * E + e] + acc[c] : acc[c];
+    }
 }
 
 // dense rows: one workgroup of 16 waves per listed token, wave w walks the stretches w, w + 16, ...; partial rows meet in LDS
 __global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const int* __restrict__ row_of_token,
                                                              const float* __restrict__ A, const float* __restrict__ wT,
                                                              float* __restrict__ dtable, const int* __restrict__ dense_count,
-                                                             const int* __restrict__ dense_list) {
+                                                             const int* __restrict__ dense_list, int accumulate) {
     __shared__ float s_part[16][kGgChunks * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = *dense_count;
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const
             float t = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < 16; ++w2) t += s_part[w2][e];
-            dtable[(long)v * E + e] = t;
+            dtable[(long)v * E + e] = accumulate ? dtable[(long)v * E + e] + t : t;
         }
         __syncthreads();
     }
@@ -672,15 +676,35 @@ __global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const
 // dtable[v, :] = sum_j c[row(v)][j] w[:, j]  (0 for absent tokens and the pad row): the whole [V, E] gradient is overwritten
 __global__ __launch_bounds__(256) void gp_dtable_kernel(int V, int E, int win, int pad_idx, const int* __restrict__ row_of_token,
                                                         const float* __restrict__ c, const float* __restrict__ w,
-                                                        float* __restrict__ dtable) {
+                                                        float* __restrict__ dtable, int accumulate) {
     const long n = (long)V * E;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
         const int v = (int)(k / E), e = (int)(k - (long)v * E);
         const int row = row_of_token[v];
         float s = 0.f;
-        if (row >= 0 && v != pad_idx)
+        const bool live = row >= 0 && v != pad_idx;
+        if (live)
             for (int j = 0; j < win; ++j) s = fmaf(c[(long)row * kGateWP + j], w[(long)e * win + j], s);
-        dtable[k] = s;
+        if (!accumulate) dtable[k] = s;
+        else if (live) dtable[k] += s;                  // shared gradient buffer (functional.table_fanout): rows of the batch only
+    }
+}
+
+// accumulate form: dtable[tok_of_row[row], :] += sum_j c[row][j] w[:, j] over the batch's rows only (the shared gradient buffer of
+// functional.table_fanout): 2.1 M elements at cfg4 instead of the vocabulary's 5 M
+__global__ __launch_bounds__(256) void gp_dtable_rows_kernel(int E, int win, int cap, int pad_idx, const int* __restrict__ counter,
+                                                             const int* __restrict__ tok_of_row, const float* __restrict__ c,
+                                                             const float* __restrict__ w, float* __restrict__ dtable) {
+    const long n = (long)min(*counter, cap) * E;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
+        const int row = (int)(k / E), e = (int)(k - (long)row * E);
+        const int v = tok_of_row[row];
+        if (v == pad_idx) continue;
+        float* dst = dtable + (long)v * E + e;
+        const float old = *dst;
+        float s = 0.f;
+        for (int j = 0; j < win; ++j) s = fmaf(c[(long)row * kGateWP + j], w[(long)e * win + j], s);
+        *dst = old + s;
     }
 }
 
@@ -926,7 +950,7 @@ extern "C" int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int
 extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int32_t win, int32_t V, const int64_t* ids,
                                             const float* table, const float* w, const float* gate, const float* dgate,
                                             int32_t pad_idx, float* dw, float* db0, float* dtable, void* ws, const void* rows,
-                                            void* stream) {
+                                            int32_t accumulate, void* stream) {
     GateProdLayout G;
     if (!gate_prod_layout(B, L, E, win, V, G)) { set_error("bad local gate shape B=%d L=%d E=%d win=%d V=%d", B, L, E, win, V); return RBR_ERR_BAD_ARG; }
     if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
@@ -953,8 +977,12 @@ extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int
     RBR_CHECK_LAUNCH("datt gate dw final launch");
     if (dtable != nullptr) {
         const long n = (long)V * E;
-        hipLaunchKernelGGL(gp_dtable_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, V, E, win, pad_idx,
-                           row_of_token, c, w, dtable);
+        if (accumulate)
+            hipLaunchKernelGGL(gp_dtable_rows_kernel, dim3((unsigned)std::min<long>(((long)G.cap * E + 255) / 256, 8192)), dim3(256), 0, st, E,
+                               win, G.cap, pad_idx, counter, tok_of_row, c, w, dtable);
+        else
+            hipLaunchKernelGGL(gp_dtable_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, V, E, win, pad_idx,
+                               row_of_token, c, w, dtable, 0);
         RBR_CHECK_LAUNCH("datt gate dtable launch");
     }
     return 0;
@@ -992,7 +1020,7 @@ extern "C" size_t rbr_datt_global_gate_bwd_rows_ws_floats(int32_t B, int32_t L, 
 
 extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, int32_t V, const int64_t* ids, const float* table,
                                              const float* w, const float* gate, const float* dgate, int32_t pad_idx, float* dw,
-                                             float* db0, float* dtable, float* ws, const void* rows, void* stream) {
+                                             float* db0, float* dtable, float* ws, const void* rows, int32_t accumulate, void* stream) {
     TokenRowsLayout T;
     if (!gate_args_ok(B, L, E, 1) || !token_rows_layout(B, L, V, T)) return RBR_ERR_BAD_ARG;
     if (E > kGgChunks * 64 || L % 4 != 0) { set_error("global gate over token rows needs E <= %d and L %% 4 == 0 (E=%d L=%d)", kGgChunks * 64, E, L); return RBR_ERR_UNSUPPORTED; }
@@ -1023,10 +1051,10 @@ extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, in
                            pad_idx, ids64, row_of_token, (const float*)ws, A);
         RBR_CHECK_LAUNCH("datt global gate occurrence scatter launch");
         hipLaunchKernelGGL(gg_rows_kernel, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, V, L, E, pad_idx, row_of_token,
-                           (const float*)A, (const float*)wT, dtable, dense_count, dense_list);
+                           (const float*)A, (const float*)wT, dtable, dense_count, dense_list, accumulate);
         RBR_CHECK_LAUNCH("datt global gate rows launch");
         hipLaunchKernelGGL(gg_dense_rows_kernel, dim3((unsigned)std::min(V, 512)), dim3(1024), 0, st, L, E, row_of_token,
-                           (const float*)A, (const float*)wT, dtable, (const int*)dense_count, (const int*)dense_list);
+                           (const float*)A, (const float*)wT, dtable, (const int*)dense_count, (const int*)dense_list, accumulate);
         RBR_CHECK_LAUNCH("datt global gate dense rows launch");
     }
     return 0;

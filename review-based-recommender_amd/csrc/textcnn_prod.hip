@@ -302,7 +302,10 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
-                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
+                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable,
+                                                        int accumulate) {
+    // accumulate: dtable is a gradient buffer shared with other producers on this stream (functional.table_fanout) -- the rows
+    // of the batch's tokens are ADDED to it, nothing else is touched (no zero rows, the pad row is skipped)
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* s_pc = s_dyn + wave * 2 * KGW;
@@ -315,9 +318,15 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
         if (tok_of_row[row] == A.padding_idx) {             // nn.Embedding(padding_idx): that row gets no gradient
             float* dst = dtable + (long)A.padding_idx * D;
-            for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!accumulate)
+                for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
             continue;                                        // workgroup-uniform
         }
+        // accumulate mode: what the shared buffer holds for this row is requested now and added at the end (a read in front
+        // of the store would put one more memory latency on every row)
+        const long trow = (long)tok_of_row[row] * D;
+        f32x4 old = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate && (int)threadIdx.x < nq4) old = *reinterpret_cast<const f32x4*>(dtable + trow + 4 * threadIdx.x);
         // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
         int cnt = 0;
         for (int k0 = kbeg; k0 < kend; k0 += 256) {
@@ -371,17 +380,17 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
         }
         __syncthreads();
         // 3. the four partial rows, summed in wave order, written once
-        const long trow = (long)tok_of_row[row] * D;
         for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) {
             f32x4 r = *reinterpret_cast<const f32x4*>(s_part + 4 * q4);
 #pragma unroll
             for (int w = 1; w < kWavesPerWG; ++w) r += *reinterpret_cast<const f32x4*>(s_part + w * D + 4 * q4);
+            if (accumulate) r += (q4 == (int)threadIdx.x) ? old : *reinterpret_cast<const f32x4*>(dtable + trow + 4 * q4);   // D > 1024: later quads read late
             *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
         }
         __syncthreads();      // lists and partial rows are rewritten for the next row
     }
     // rows of tokens the batch does not contain: zero (the caller need not pre-fill dtable); one wave per row
-    if (row_of_token != nullptr) {
+    if (row_of_token != nullptr && !accumulate) {
         const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
         for (int v = blockIdx.x * kWavesPerWG + wv; v < V; v += gridDim.x * kWavesPerWG) {
             if (row_of_token[v] >= 0) continue;                 // wave-uniform
@@ -931,7 +940,7 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
-enum { kGBuild = 1, kGProduct = 2 };     // phases of dtable_through_list
+enum { kGBuild = 1, kGProduct = 2, kGAccumulate = 4 };     // phases of dtable_through_list (+ dtable is added to, not overwritten)
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                float* dtable, float* dgate, hipStream_t st, int phases = kGBuild | kGProduct);
@@ -946,6 +955,20 @@ extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int6
     if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
     return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream);
+}
+
+// rbr_textcnn_bwd_dtable_prod with the table rows ADDED to `dtable` (a gradient buffer shared by several producers that run
+// one after the other on the same stream: functional.table_fanout) instead of the whole [V, D] gradient being overwritten.
+extern "C" int rbr_textcnn_bwd_dtable_prod_acc(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
+                                               void* bwd_ws, float* dtable, float* dgate, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (dgate != nullptr && gate == nullptr) dgate = nullptr;
+    if (!ids || !feat || !argmax || !d_feat || !fwd_ws || !bwd_ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream,
+                               kGBuild | kGProduct | kGAccumulate);
 }
 
 // The two halves of rbr_textcnn_bwd_dtable_prod as separate calls, for callers that put work between them or beside the
@@ -1016,7 +1039,7 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                       tok_of_row, row_of_token, d->V, dtable);
+                       tok_of_row, row_of_token, d->V, dtable, (phases & kGAccumulate) ? 1 : 0);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }

@@ -140,11 +140,64 @@ def set_tap_sink(sink, table: Optional[torch.Tensor] = None) -> None:
     _TAP_SINKS[sink.table.data_ptr()] = sink
 
 
+# ---- one gradient buffer for several producers of a table's gradient ------------------------------------------------------
+_TABLE_ACC: dict = {}        # table.data_ptr() -> (accumulation buffer, stream it was made on)
+
+
+def _from_fanout(table: torch.Tensor) -> bool:
+    """Called in an op's forward: is `table` one of table_fanout's aliases?  Only then may its backward use the shared buffer
+    (an op handed the bare table while a buffer of an unfinished step is still registered must not touch it)."""
+    return type(table.grad_fn).__name__ == "_TableFanoutBackward"
+
+
+def _table_acc(table: torch.Tensor, from_fanout: bool):
+    """The shared gradient buffer of `table` (see table_fanout) when this op may add its rows to it: same stream only."""
+    ent = _TABLE_ACC.get(table.data_ptr()) if from_fanout else None
+    if ent is None or ent[1] != torch.cuda.current_stream(table.device):
+        return None
+    return ent[0]
+
+
+class _TableFanout(torch.autograd.Function):
+    """n aliases of a table, one per consumer.  The consumers' backwards that support it add their rows into ONE zeroed buffer
+    (_TABLE_ACC) and each hand that same buffer back; here the duplicates are dropped, so a step with 8 producers of table
+    gradient (D-ATT: two gates and two convs per tower) pays one 20 MB fill instead of seven 60 MB autograd adds and eight
+    dense [V, D] outputs.  A consumer that returns a tensor of its own is added the ordinary way."""
+
+    @staticmethod
+    def forward(ctx, table, n):
+        ctx.key = table.data_ptr()
+        ctx.set_materialize_grads(False)
+        return tuple(table.view(table.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _TABLE_ACC.pop(ctx.key, None)
+        total, seen = None, set()
+        for g in grads:
+            if g is None or g.data_ptr() in seen:
+                continue
+            seen.add(g.data_ptr())
+            total = g if total is None else total + g
+        return total, None
+
+
+def table_fanout(table: torch.Tensor, n: int):
+    """`n` aliases of `table` for `n` consumer ops of one step (hand each op its own alias).  With gradients on, the ops that
+    can (token-product convs and gates) then add their table-gradient rows into one shared buffer instead of producing a
+    dense gradient each: see _TableFanout.  Without gradients: the table itself, n times."""
+    if not (torch.is_grad_enabled() and table.requires_grad and table.is_cuda):
+        return (table,) * n
+    _TABLE_ACC[table.data_ptr()] = (torch.zeros_like(table), torch.cuda.current_stream(table.device))
+    return _TableFanout.apply(table, n)
+
+
 class _TextCNN(torch.autograd.Function):
     """feat[n_docs, C] = pool(act(conv(mask * gate * table[ids])))  -- see rbr_textcnn_* in rbr_hip.h."""
 
     @staticmethod
     def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *wb):
+        ctx.from_fanout = _from_fanout(table)
         n = len(kernel_sizes)
         weights, biases = wb[:n], wb[n:]
         dev_ptr(table.contiguous(), F32, "word table")   # device / dtype gate before anything touches HIP
@@ -358,11 +411,15 @@ class _TextCNN(torch.autograd.Function):
                     ev.record()
                 _join(join)
                 return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-            check(L_.rbr_textcnn_bwd_dtable_prod(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                 dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
-                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"),
-                                                 dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
+            acc = _table_acc(table, ctx.from_fanout) if need_table else None
+            if acc is not None:          # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
+                dtable = acc
+            fn = L_.rbr_textcnn_bwd_dtable_prod_acc if acc is not None else L_.rbr_textcnn_bwd_dtable_prod
+            check(fn(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                     dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                     dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                     ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"),
+                     dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
             _join(run_dw())
@@ -980,6 +1037,7 @@ class _DattGate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, w, b0, ids, is_global, padding_idx, rows=None):
+        ctx.from_fanout = _from_fanout(table)
         ctx.gate_ws = None
         ctx.rows = rows                              # the tower's distinct-token rows (datt_token_rows) or None
         B, L = ids.shape
@@ -1020,25 +1078,26 @@ class _DattGate(torch.autograd.Function):
         dgate = dgate.contiguous()
         dw = torch.empty_like(w)
         db0 = torch.empty(1, dtype=F32, device=dev)
-        if ctx.gate_ws is not None:      # token-product local gate: the whole table gradient is overwritten
-            dtable = torch.empty_like(table) if ctx.needs_input_grad[0] else None
+        acc = _table_acc(table, ctx.from_fanout) if ctx.needs_input_grad[0] else None      # the step's shared gradient buffer
+        if ctx.gate_ws is not None:      # token-product local gate: the whole table gradient is overwritten (or its rows added)
+            dtable = (acc if acc is not None else torch.empty_like(table)) if ctx.needs_input_grad[0] else None
             check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, table.shape[0], dev_ptr(ids, I64, "ids"),
                                                   dev_ptr(table, F32, "table"), dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"),
                                                   dev_ptr(dgate, F32, "dgate"), pad, dev_ptr(dw, F32, "dw"),
                                                   dev_ptr(db0, F32, "db0"), dev_ptr(dtable, F32, "dtable"),
                                                   ctx.gate_ws.data_ptr(), None if ctx.rows is None else ctx.rows.data_ptr(),
-                                                  current_stream()), "rbr_datt_local_gate_bwd_prod")
+                                                  int(acc is not None), current_stream()), "rbr_datt_local_gate_bwd_prod")
             return dtable, dw, db0, None, None, None, None
         V = table.shape[0]
         rows_floats = L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V) if (ctx.rows is not None and is_global) else 0
         if rows_floats:                  # global gate over the tower's token rows: occurrence matrix, dtable overwritten
-            dtable = torch.empty_like(table) if ctx.needs_input_grad[0] else None
+            dtable = (acc if acc is not None else torch.empty_like(table)) if ctx.needs_input_grad[0] else None
             ws = torch.empty(rows_floats, dtype=F32, device=dev)
             check(L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "table"),
                                                    dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "gate"), dev_ptr(dgate, F32, "dgate"),
                                                    pad, dev_ptr(dw, F32, "dw"), dev_ptr(db0, F32, "db0"),
                                                    dev_ptr(dtable, F32, "dtable"), dev_ptr(ws, F32, "ws"), ctx.rows.data_ptr(),
-                                                   current_stream()), "rbr_datt_global_gate_bwd_rows")
+                                                   int(acc is not None), current_stream()), "rbr_datt_global_gate_bwd_rows")
             return dtable, dw, db0, None, None, None, None
         dtable = torch.zeros_like(table) if ctx.needs_input_grad[0] else None
         ws = torch.empty(max(1, L_.rbr_datt_gate_bwd_ws_floats(B, L, E, win, int(is_global))), dtype=F32, device=dev)

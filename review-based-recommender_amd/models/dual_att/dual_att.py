@@ -27,11 +27,11 @@ class DualAtt(nn.Module):
         self.fc = nn.Sequential(nn.Linear(self.fc_input, hidden_size_1), nn.ReLU(), nn.Dropout(dropout),
                                 nn.Linear(hidden_size_1, hidden_size_2))
 
-    def _encode(self, docs, local, glob):
-        table = self.word_embeddings.weight
+    def _encode(self, docs, local, glob, tabs):
+        """`tabs`: four aliases of the word table (RF.table_fanout), one per table-consuming op of the tower."""
         pad = self.word_embeddings.padding_idx
-        rows = RF.datt_token_rows(docs, table.shape[0])        # distinct-token maps, once per tower: both gates work on them
-        return torch.cat((local.encode(table, docs, pad, rows=rows), glob.encode(table, docs, pad, rows=rows)), dim=1)
+        rows = RF.datt_token_rows(docs, tabs[0].shape[0])      # distinct-token maps, once per tower: both gates work on them
+        return torch.cat((local.encode(tabs[0:2], docs, pad, rows=rows), glob.encode(tabs[2:4], docs, pad, rows=rows)), dim=1)
 
     def _fc(self, feat):
         p = self.fc[2].p
@@ -45,8 +45,11 @@ class DualAtt(nn.Module):
         if self.validate_ids:
             pad = self.word_embeddings.padding_idx
             u_docs, i_docs = RF.sanitize_ids([(u_docs, self.vocab_size, pad), (i_docs, self.vocab_size, pad)])
-        u_enc = self._encode(u_docs, self.u_local_atten, self.u_global_atten)
-        i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten)
+        # eight ops of the step produce gradient for the word table (a gate and a conv, local and global, per tower): each gets
+        # its own alias, and their backwards add their rows into one buffer instead of eight dense gradients summed by autograd
+        tabs = RF.table_fanout(self.word_embeddings.weight, 8)
+        u_enc = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs[0:4])
+        i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
         # backward) as a single 2*bz batch, user rows first
         u_feat, i_feat = self._fc(torch.cat((u_enc, i_enc), dim=0)).view(2, bz, -1).unbind(0)

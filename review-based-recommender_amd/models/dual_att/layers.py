@@ -44,10 +44,12 @@ class LocalAttention(nn.Module):
         self.conv = nn.Sequential(nn.Conv1d(emb_size, out_size, kernel_size=1), nn.Tanh(), nn.MaxPool1d(doc_len))
 
     def encode(self, table, ids, padding_idx=0, rows=None):
-        gate = RF.datt_gate(table, self.attn[0].weight, self.attn[0].bias, ids, is_global=False, padding_idx=padding_idx,
+        """`table`: the word table, or a pair of its aliases (RF.table_fanout) for the gate and the conv."""
+        t_gate, t_conv = table if isinstance(table, (tuple, list)) else (table, table)
+        gate = RF.datt_gate(t_gate, self.attn[0].weight, self.attn[0].bias, ids, is_global=False, padding_idx=padding_idx,
                             rows=rows)
         c = self.conv[0]
-        return RF.textcnn(table, ids, None, [c.weight], [c.bias], gate=gate, pad_mode=RF.PAD_SAME, act=RF.ACT_TANH,
+        return RF.textcnn(t_conv, ids, None, [c.weight], [c.bias], gate=gate, pad_mode=RF.PAD_SAME, act=RF.ACT_TANH,
                           padding_idx=padding_idx)                       # [bz, out_size]
 
     def forward(self, x):
@@ -70,11 +72,13 @@ class GlobalAttention(nn.Module):
         self.conv3 = nn.Sequential(nn.Conv1d(emb_size, out_size, kernel_size=4), nn.Tanh(), nn.MaxPool1d(doc_len - 3))
 
     def encode(self, table, ids, padding_idx=0, rows=None):
-        gate = RF.datt_gate(table, self.attn[0].weight, self.attn[0].bias, ids, is_global=True, padding_idx=padding_idx,
+        """`table`: the word table, or a pair of its aliases (RF.table_fanout) for the gate and the convs."""
+        t_gate, t_conv = table if isinstance(table, (tuple, list)) else (table, table)
+        gate = RF.datt_gate(t_gate, self.attn[0].weight, self.attn[0].bias, ids, is_global=True, padding_idx=padding_idx,
                             rows=rows)
         convs = [self.conv1[0], self.conv2[0], self.conv3[0]]
         # the three widths run in ONE launch of the fused kernel; channels come back width-major
-        return RF.textcnn(table, ids, None, [c.weight for c in convs], [c.bias for c in convs], gate=gate,
+        return RF.textcnn(t_conv, ids, None, [c.weight for c in convs], [c.bias for c in convs], gate=gate,
                           pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=padding_idx)   # [bz, 3*out_size]
 
     def forward(self, x):
