@@ -142,7 +142,8 @@ int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const 
                            const float* table, const float* packed, const float* feat, const int32_t* argmax,
                            const float* d_feat, float* dtable, float* dgate, void* stream);
 /* Table (and gate) gradient through the token-product formulation (same maths as rbr_textcnn_bwd_dtable; with a gate,
- * dgate[doc,p] is ACCUMULATED from the forward's product table T, which must still be intact in `fwd_ws`):
+ * dgate[doc,p] is OVERWRITTEN -- zeroed by the call, then summed from the forward's product table T, which must still be
+ * intact in `fwd_ws`):
  * G[token][tap, channel] = sum of g over the argmax windows touching that token, for the DISTINCT tokens the
  * forward listed in `fwd_ws` (the workspace rbr_textcnn_conv_fwd was given for the SAME ids/mask, still intact),
  * then dtable[token, :] = G[token, :] @ Wprod^T as a sparse row product (G is ~2 % dense); each listed row of
@@ -258,6 +259,10 @@ int rbr_dropout_multiplier(int64_t n, float p, uint64_t seed, uint64_t* state, f
  *   that a backward called with that gradient (loss.backward()) needs no launch of its own.
  */
 int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* loss, float* d_pred_unit, void* stream);
+/* D-ATT's rating (dual_att.py:58): out[b] = <x[b,:], x[B+b,:]> over the stacked [2B, K] output of the shared fc (user rows
+ * first); backward: d_x[b,:] = d_out[b] * x[B+b,:], d_x[B+b,:] = d_out[b] * x[b,:] (d_x OVERWRITTEN). */
+int rbr_pair_dot_fwd(int32_t B, int32_t K, const float* x, float* out, void* stream);
+int rbr_pair_dot_bwd(int32_t B, int32_t K, const float* x, const float* d_out, float* d_x, void* stream);
 int rbr_mse_loss_bwd(int64_t n, const float* pred, const float* target, const float* d_loss, float* d_pred,
                      void* stream);
 

@@ -131,6 +131,8 @@ SIGNATURES = {
                                     c_stream]),
     "rbr_dropout_multiplier": (C.c_int, [C.c_int64, C.c_float, C.c_uint64, C.c_void_p, c_f32p, c_stream]),
     "rbr_mse_loss_fwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_pair_dot_fwd": (C.c_int, [i32, i32, c_f32p, c_f32p, c_stream]),
+    "rbr_pair_dot_bwd": (C.c_int, [i32, i32, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_mse_loss_bwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_review_attn_fwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p, c_f32p,
                                       c_f32p, c_stream]),

@@ -335,3 +335,45 @@ extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u
     RBR_CHECK_LAUNCH("pair_head_bwd launch");
     return 0;
 }
+
+// ---- D-ATT's rating: ratings[b] = sum_k u[b,k] * i[b,k] (dual_att.py:58) over a STACKED [2B, K] feature block (user rows
+// first, the shared fc's output), and its backward straight into the stacked gradient -- two launches instead of mul, sum,
+// two elementwise products and a stack.  16 lanes per pair.
+namespace rbr {
+__global__ __launch_bounds__(256) void pair_dot_fwd_kernel(int B, int K, const float* __restrict__ x, float* __restrict__ out) {
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    float s = 0.f;
+    if (b < B)
+        for (int k = l; k < K; k += 16) s = fmaf(x[(long)b * K + k], x[(long)(B + b) * K + k], s);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (b < B && l == 0) out[b] = s;
+}
+
+__global__ __launch_bounds__(256) void pair_dot_bwd_kernel(int B, int K, const float* __restrict__ x, const float* __restrict__ d_out,
+                                                           float* __restrict__ d_x) {
+    const long n = (long)2 * B * K;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int row = (int)(e / K), k = (int)(e - (long)row * K);
+        const int b = row < B ? row : row - B, other = row < B ? row + B : row - B;
+        d_x[e] = d_out[b] * x[(long)other * K + k];
+    }
+}
+}  // namespace rbr
+
+extern "C" int rbr_pair_dot_fwd(int32_t B, int32_t K, const float* x, float* out, void* stream) {
+    if (B <= 0 || K <= 0 || !x || !out) { set_error("bad pair_dot arguments"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(pair_dot_fwd_kernel, dim3((B + 15) / 16), dim3(256), 0, (hipStream_t)stream, B, K, x, out);
+    RBR_CHECK_LAUNCH("pair_dot fwd launch");
+    return 0;
+}
+
+extern "C" int rbr_pair_dot_bwd(int32_t B, int32_t K, const float* x, const float* d_out, float* d_x, void* stream) {
+    if (B <= 0 || K <= 0 || !x || !d_out || !d_x) { set_error("bad pair_dot arguments"); return RBR_ERR_BAD_ARG; }
+    const long n = (long)2 * B * K;
+    hipLaunchKernelGGL(pair_dot_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, B, K,
+                       x, d_out, d_x);
+    RBR_CHECK_LAUNCH("pair_dot bwd launch");
+    return 0;
+}
+

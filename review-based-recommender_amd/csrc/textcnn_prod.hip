@@ -252,9 +252,12 @@ struct ProdBwdArgs {
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
 };
 
-__global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G) {
-    const long n = (long)min(*counter, cap) * KG4;
+// ... and the gate gradient build_g accumulates into (n_dgate floats, 0 for un-gated convs): one launch for both
+__global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
+                                                          float* __restrict__ dgate, long n_dgate) {
+    const long n = (G != nullptr) ? (long)min(*counter, cap) * KG4 : 0;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_dgate; k += (long)gridDim.x * 256) dgate[k] = 0.f;
 }
 
 // one thread per (doc, channel, tap).  Gated convs (D-ATT: x = gate[doc,p] * table[id]): the token's share is g * gate, and
@@ -1026,8 +1029,9 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     // kGBuild alone (rbr_textcnn_bwd_g_build) always builds G: its caller multiplies it out later (rbr_textcnn_bwd_g_product)
     const bool want_g = dtable != nullptr || !(phases & kGProduct);
     if (phases & kGBuild) {
-        if (want_g) {
-            hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4, reinterpret_cast<f32x4*>(G));
+        if (want_g || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
+            hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4,
+                               want_g ? reinterpret_cast<f32x4*>(G) : nullptr, dgate, dgate != nullptr ? (long)d->n_docs * d->L : 0L);
             RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;

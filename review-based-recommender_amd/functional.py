@@ -320,7 +320,8 @@ class _TextCNN(torch.autograd.Function):
                       if (need_table and not bws_bytes and gate is None) else 0)
         # the token-list backwards overwrite the whole table gradient; the window scatter accumulates into zeros
         dtable = (torch.empty_like(table) if (bws_bytes or list_bytes) else torch.zeros_like(table)) if need_table else None
-        dgate = torch.zeros_like(gate) if need_gate else None
+        # the token-product backward zeroes dgate in the launch that zeroes its G rows; the window scatter accumulates into zeros
+        dgate = (torch.empty_like(gate) if bws_bytes else torch.zeros_like(gate)) if need_gate else None
         wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
         wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
         st = current_stream()
@@ -785,6 +786,35 @@ def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0, d
     """NARRE LinearAttention: returns (out [B,H], att [B,R,1]).  `drop` [B,H]: the multiplier of the nn.Dropout that follows
     (dropout_multiplier), applied inside the kernels -- forward and backward -- instead of by two elementwise launches."""
     return _ReviewAttn.apply(feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd, drop)
+
+
+class _PairDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, K = x.shape[0] // 2, x.shape[1]
+        out = torch.empty(B, dtype=F32, device=x.device)
+        check(_lib.lib().rbr_pair_dot_fwd(B, K, dev_ptr(x, F32, "x"), dev_ptr(out, F32, "out"), current_stream()), "rbr_pair_dot_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        B, K = x.shape[0] // 2, x.shape[1]
+        d_x = torch.empty_like(x)
+        d_out = d_out.contiguous()
+        check(_lib.lib().rbr_pair_dot_bwd(B, K, dev_ptr(x, F32, "x"), dev_ptr(d_out, F32, "d_out"), dev_ptr(d_x, F32, "d_x"),
+                                          current_stream()), "rbr_pair_dot_bwd")
+        return d_x
+
+
+def pair_dot(stacked: torch.Tensor) -> torch.Tensor:
+    """ratings[b] = sum_k stacked[b, k] * stacked[B + b, k] for a [2B, K] block with the user rows first (D-ATT's
+    `torch.sum(torch.mul(u_feat, i_feat), 1)`, dual_att.py:58, on the shared fc's stacked output)."""
+    if stacked.dim() != 2 or stacked.shape[0] % 2:
+        raise RuntimeError(f"pair_dot: expected a [2B, K] block, got {tuple(stacked.shape)}")
+    return _PairDot.apply(stacked)
 
 
 # --------------------------------------------------------------------------- nn.Linear on MFMA

@@ -52,6 +52,5 @@ class DualAtt(nn.Module):
         i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
         # backward) as a single 2*bz batch, user rows first
-        u_feat, i_feat = self._fc(torch.cat((u_enc, i_enc), dim=0)).view(2, bz, -1).unbind(0)
-        ratings = torch.sum(torch.mul(u_feat, i_feat), 1)
-        return ratings.view(-1)
+        feats = self._fc(torch.cat((u_enc, i_enc), dim=0))                  # [2*bz, hidden_2], user rows first
+        return RF.pair_dot(feats).view(-1)                                  # sum(u_feat * i_feat, 1)  (dual_att.py:58)
