@@ -263,6 +263,11 @@ int rbr_mse_loss_fwd(int64_t n, const float* pred, const float* target, float* l
  * first); backward: d_x[b,:] = d_out[b] * x[B+b,:], d_x[B+b,:] = d_out[b] * x[b,:] (d_x OVERWRITTEN). */
 int rbr_pair_dot_fwd(int32_t B, int32_t K, const float* x, float* out, void* stream);
 int rbr_pair_dot_bwd(int32_t B, int32_t K, const float* x, const float* d_out, float* d_x, void* stream);
+/* out [2B, C1+C2] = [[a, b], [c, d]] (a, c [B,C1]; b, d [B,C2]) and its inverse: D-ATT's cat(local, global) per tower stacked
+ * user-over-item for the shared fc (dual_att.py:50-57), as one launch each way. */
+int rbr_block_cat(int32_t B, int32_t C1, int32_t C2, const float* a, const float* b, const float* c, const float* d, float* out,
+                  void* stream);
+int rbr_block_split(int32_t B, int32_t C1, int32_t C2, const float* g, float* a, float* b, float* c, float* d, void* stream);
 int rbr_mse_loss_bwd(int64_t n, const float* pred, const float* target, const float* d_loss, float* d_pred,
                      void* stream);
 

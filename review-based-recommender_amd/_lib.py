@@ -133,6 +133,8 @@ SIGNATURES = {
     "rbr_mse_loss_fwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_pair_dot_fwd": (C.c_int, [i32, i32, c_f32p, c_f32p, c_stream]),
     "rbr_pair_dot_bwd": (C.c_int, [i32, i32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_block_cat": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_block_split": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_mse_loss_bwd": (C.c_int, [C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_review_attn_fwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p, c_f32p,
                                       c_f32p, c_stream]),

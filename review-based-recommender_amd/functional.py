@@ -788,6 +788,36 @@ def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0, d
     return _ReviewAttn.apply(feat, other_id, pad_idx, W_rv, W_id, h, b1, b2, ebd, drop)
 
 
+class _BlockCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c, d):
+        a, b, c, d = (t.contiguous() for t in (a, b, c, d))
+        B, C1, C2 = a.shape[0], a.shape[1], b.shape[1]
+        if c.shape != a.shape or d.shape != b.shape or b.shape[0] != B:
+            raise RuntimeError("block_cat: expected a, c [B, C1] and b, d [B, C2]")
+        out = torch.empty(2 * B, C1 + C2, dtype=F32, device=a.device)
+        check(_lib.lib().rbr_block_cat(B, C1, C2, dev_ptr(a, F32, "a"), dev_ptr(b, F32, "b"), dev_ptr(c, F32, "c"),
+                                       dev_ptr(d, F32, "d"), dev_ptr(out, F32, "out"), current_stream()), "rbr_block_cat")
+        ctx.dims = (B, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C1, C2 = ctx.dims
+        g = g.contiguous()
+        a, c = (torch.empty(B, C1, dtype=F32, device=g.device) for _ in range(2))
+        b, d = (torch.empty(B, C2, dtype=F32, device=g.device) for _ in range(2))
+        check(_lib.lib().rbr_block_split(B, C1, C2, dev_ptr(g, F32, "g"), dev_ptr(a, F32, "a"), dev_ptr(b, F32, "b"),
+                                         dev_ptr(c, F32, "c"), dev_ptr(d, F32, "d"), current_stream()), "rbr_block_split")
+        return a, b, c, d
+
+
+def block_cat(a, b, c, d):
+    """[[a, b], [c, d]] as one [2B, C1 + C2] tensor (a, c [B, C1]; b, d [B, C2]): torch.cat((cat((a, b), 1), cat((c, d), 1)), 0)
+    in one launch, and contiguous gradient pieces from one launch in the backward."""
+    return _BlockCat.apply(a, b, c, d)
+
+
 class _PairDot(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

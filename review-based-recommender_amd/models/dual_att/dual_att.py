@@ -31,7 +31,7 @@ class DualAtt(nn.Module):
         """`tabs`: four aliases of the word table (RF.table_fanout), one per table-consuming op of the tower."""
         pad = self.word_embeddings.padding_idx
         rows = RF.datt_token_rows(docs, tabs[0].shape[0])      # distinct-token maps, once per tower: both gates work on them
-        return torch.cat((local.encode(tabs[0:2], docs, pad, rows=rows), glob.encode(tabs[2:4], docs, pad, rows=rows)), dim=1)
+        return local.encode(tabs[0:2], docs, pad, rows=rows), glob.encode(tabs[2:4], docs, pad, rows=rows)
 
     def _fc(self, feat):
         p = self.fc[2].p
@@ -48,9 +48,10 @@ class DualAtt(nn.Module):
         # eight ops of the step produce gradient for the word table (a gate and a conv, local and global, per tower): each gets
         # its own alias, and their backwards add their rows into one buffer instead of eight dense gradients summed by autograd
         tabs = RF.table_fanout(self.word_embeddings.weight, 8)
-        u_enc = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs[0:4])
-        i_enc = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
+        u_loc, u_glo = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs[0:4])
+        i_loc, i_glo = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
         # backward) as a single 2*bz batch, user rows first
-        feats = self._fc(torch.cat((u_enc, i_enc), dim=0))                  # [2*bz, hidden_2], user rows first
+        # cat((local, global), 1) per tower (dual_att.py:50,56), user rows over item rows: one launch (RF.block_cat)
+        feats = self._fc(RF.block_cat(u_loc, u_glo, i_loc, i_glo))          # [2*bz, hidden_2], user rows first
         return RF.pair_dot(feats).view(-1)                                  # sum(u_feat * i_feat, 1)  (dual_att.py:58)
