@@ -293,6 +293,19 @@ int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float*
                         const rbr_attn_params* p, const float* drop, const float* att, const float* hid, const float* d_out,
                         const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat, float* ws,
                         void* stream);
+/* Both attention pools of a two-tower model (NARRE: user_att keyed by item ids, item_att by user ids, narre.py:177-178) in one
+ * launch per stage.  Every per-side tensor is a stacked block, side 0 first: feat [2,B,R,H], other_id [2,B,R], drop [2,B,H] or
+ * NULL, out [2,B,H], att [2,B,R], hid [2,B,R,A], d_out [2,B,H], d_att [2,B,R] or NULL, d_feat [2,B,R,H]; p0/p1, g0/g1 the sides'
+ * parameters and gradients.  The backward ZEROES g0->debd [n_ebd0, A] and g1->debd [n_ebd1, A] itself before accumulating.
+ * ws: 2 * rbr_review_attn_bwd_ws_floats(B, R, H, A) floats. */
+int rbr_review_attn2_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                         const rbr_attn_params* p0, const rbr_attn_params* p1, const float* drop, float* out, float* att,
+                         float* hid, void* stream);
+int rbr_review_attn2_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                         const rbr_attn_params* p0, const rbr_attn_params* p1, const float* drop, const float* att,
+                         const float* hid, const float* d_out, const float* d_att, int32_t pad_idx0, int32_t pad_idx1,
+                         const rbr_attn_grads* g0, const rbr_attn_grads* g1, int64_t n_ebd0, int64_t n_ebd1, float* d_feat,
+                         float* ws, void* stream);
 
 /* ---- D-ATT gates (dual_att/layers.py:34-36,50 and 65-67,84)
  * local : gate[b,l] = sigmoid(b0 + sum_{j<win} sum_e w[e,j] * x[b, l+j-(win-1)/2, e])   (zero padded)

@@ -141,6 +141,11 @@ SIGNATURES = {
     "rbr_review_attn_bwd_ws_floats": (C.c_size_t, [i32, i32, i32, i32]),
     "rbr_review_attn_bwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), c_f32p, c_f32p, c_f32p,
                                       c_f32p, c_f32p, i32, C.POINTER(AttnGrads), c_f32p, c_f32p, c_stream]),
+    "rbr_review_attn2_fwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), C.POINTER(AttnParams), c_f32p,
+                                       c_f32p, c_f32p, c_f32p, c_stream]),
+    "rbr_review_attn2_bwd": (C.c_int, [i32, i32, i32, i32, c_f32p, c_i64p, C.POINTER(AttnParams), C.POINTER(AttnParams), c_f32p,
+                                       c_f32p, c_f32p, c_f32p, c_f32p, i32, i32, C.POINTER(AttnGrads), C.POINTER(AttnGrads),
+                                       C.c_int64, C.c_int64, c_f32p, c_f32p, c_stream]),
     "rbr_datt_local_gate_fwd": (C.c_int, [i32, i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_datt_global_gate_fwd": (C.c_int, [i32, i32, i32, c_i64p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_datt_gate_bwd_ws_floats": (C.c_size_t, [i32, i32, i32, i32, i32]),

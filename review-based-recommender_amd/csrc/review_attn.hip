@@ -12,10 +12,22 @@
 
 namespace rbr {
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int A, const float* __restrict__ feat,
-                                                       const long long* __restrict__ oid, const rbr_attn_params p,
-                                                       float* __restrict__ out, float* __restrict__ att,
-                                                       float* __restrict__ hid, const float* __restrict__ drop) {
+// Every kernel of this file takes the arguments of TWO sides (blockIdx.y = 0 / 1): NARRE's user and item attention pools have
+// the same shapes and different parameters, and one launch per stage for both replaces two launches on two streams (and the
+// fork / join and the stack of the two gradients around them).  A one-sided call launches grid.y = 1.
+struct AttnFwdSide {
+    const float* feat; const long long* oid; rbr_attn_params p; float* out; float* att; float* hid; const float* drop;
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int A, const AttnFwdSide side0, const AttnFwdSide side1) {
+    const AttnFwdSide& SD = blockIdx.y ? side1 : side0;
+    const float* __restrict__ feat = SD.feat;
+    const long long* __restrict__ oid = SD.oid;
+    const rbr_attn_params p = SD.p;
+    float* __restrict__ out = SD.out;
+    float* __restrict__ att = SD.att;
+    float* __restrict__ hid = SD.hid;
+    const float* __restrict__ drop = SD.drop;
     extern __shared__ float sm[];
     float* s_hid = sm;                  // [R*A]
     float* s_e = s_hid + R * A;         // [R] exp(logit), then att
@@ -63,13 +75,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
 }
 
 // per-sample backward: d_feat, embedding-row gradient, and the per-row d_pre / d_logit the reduction needs
-__global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int H, int A, const float* __restrict__ feat,
-                                                              const long long* __restrict__ oid, const rbr_attn_params p,
-                                                              const float* __restrict__ att, const float* __restrict__ hid,
-                                                              const float* __restrict__ d_out, const float* __restrict__ drop,
-                                                              const float* __restrict__ d_att, int pad_idx,
-                                                              float* __restrict__ debd, float* __restrict__ d_feat,
-                                                              float* __restrict__ ws_dpre, float* __restrict__ ws_dl) {
+struct AttnBwdSide {
+    const float* feat; const long long* oid; rbr_attn_params p; const float* att; const float* hid; const float* d_out;
+    const float* drop; const float* d_att; int pad_idx; float* debd; float* d_feat; float* ws_dpre; float* ws_dl; float* part;
+    rbr_attn_grads g;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int H, int A, const AttnBwdSide side0,
+                                                              const AttnBwdSide side1) {
+    const AttnBwdSide& SD = blockIdx.y ? side1 : side0;
+    const float* __restrict__ feat = SD.feat;
+    const long long* __restrict__ oid = SD.oid;
+    const rbr_attn_params p = SD.p;
+    const float* __restrict__ att = SD.att;
+    const float* __restrict__ hid = SD.hid;
+    const float* __restrict__ d_out = SD.d_out;
+    const float* __restrict__ drop = SD.drop;
+    const float* __restrict__ d_att = SD.d_att;
+    const int pad_idx = SD.pad_idx;
+    float* __restrict__ debd = SD.debd;
+    float* __restrict__ d_feat = SD.d_feat;
+    float* __restrict__ ws_dpre = SD.ws_dpre;
+    float* __restrict__ ws_dl = SD.ws_dl;
     extern __shared__ float sm[];
     float* s_dpre = sm;            // [R*A]
     float* s_da = sm + R * A;      // [R] d(att)
@@ -152,10 +179,15 @@ constexpr int kRedRows = 16;      // rows per chunk: B*R = 2560 rows give 160 wo
 
 __device__ __forceinline__ int attn_n_out(int H, int A) { return H * A + A * A + 2 * A + 1; }
 
-__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(int N, int H, int A, const float* __restrict__ feat,
-                                                               const long long* __restrict__ oid, const float* __restrict__ ebd,
-                                                               const float* __restrict__ hid, const float* __restrict__ ws_dpre,
-                                                               const float* __restrict__ ws_dl, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(int N, int H, int A, const AttnBwdSide side0, const AttnBwdSide side1) {
+    const AttnBwdSide& SD = blockIdx.y ? side1 : side0;
+    const float* __restrict__ feat = SD.feat;
+    const long long* __restrict__ oid = SD.oid;
+    const float* __restrict__ ebd = SD.p.ebd;
+    const float* __restrict__ hid = SD.hid;
+    const float* __restrict__ ws_dpre = SD.ws_dpre;
+    const float* __restrict__ ws_dl = SD.ws_dl;
+    float* __restrict__ part = SD.part;
     extern __shared__ float sm[];
     float* s_dp = sm;                       // [rows][A]
     float* s_f = s_dp + kRedRows * A;       // [rows][H]
@@ -194,8 +226,11 @@ __global__ __launch_bounds__(256) void attn_bwd_partial_kernel(int N, int H, int
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_final_kernel(int n_chunks, int H, int A, const float* __restrict__ part,
-                                                             const rbr_attn_grads g) {
+__global__ __launch_bounds__(256) void attn_bwd_final_kernel(int n_chunks, int H, int A, const AttnBwdSide side0,
+                                                             const AttnBwdSide side1) {
+    const AttnBwdSide& SD = blockIdx.y ? side1 : side0;
+    const float* __restrict__ part = SD.part;
+    const rbr_attn_grads g = SD.g;
     const int n_out = attn_n_out(H, A);
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
@@ -230,13 +265,31 @@ static bool attn_args_ok(int B, int R, int H, int A) {
     return true;
 }
 
+static size_t attn_fwd_lds(int R, int H, int A) { return (size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float); }
+
 extern "C" int rbr_review_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
                                    const rbr_attn_params* p, const float* drop, float* out, float* att, float* hid, void* stream) {
     if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
     if (!feat || !other_id || !p || !out || !att || !hid) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), (size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float),
-                       (hipStream_t)stream, B, R, H, A, feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid, drop);
+    const AttnFwdSide S{feat, reinterpret_cast<const long long*>(other_id), *p, out, att, hid, drop};
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B, 1), dim3(256), attn_fwd_lds(R, H, A), (hipStream_t)stream, B, R, H, A, S, S);
     RBR_CHECK_LAUNCH("review_attn_fwd launch");
+    return 0;
+}
+
+// Both attention pools of a two-tower model in one launch: every per-side tensor is a stacked block with side 0 first --
+// feat [2,B,R,H], other_id [2,B,R], drop [2,B,H] (or NULL), out [2,B,H], att [2,B,R], hid [2,B,R,A]; p0 / p1 the sides' parameters.
+extern "C" int rbr_review_attn2_fwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                                    const rbr_attn_params* p0, const rbr_attn_params* p1, const float* drop, float* out, float* att,
+                                    float* hid, void* stream) {
+    if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
+    if (!feat || !other_id || !p0 || !p1 || !out || !att || !hid) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const long long* oid = reinterpret_cast<const long long*>(other_id);
+    const size_t nf = (size_t)B * R * H, ni = (size_t)B * R, no = (size_t)B * H, nh = (size_t)B * R * A;
+    const AttnFwdSide S0{feat, oid, *p0, out, att, hid, drop};
+    const AttnFwdSide S1{feat + nf, oid + ni, *p1, out + no, att + ni, hid + nh, drop ? drop + no : nullptr};
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B, 2), dim3(256), attn_fwd_lds(R, H, A), (hipStream_t)stream, B, R, H, A, S0, S1);
+    RBR_CHECK_LAUNCH("review_attn2_fwd launch");
     return 0;
 }
 
@@ -245,25 +298,61 @@ extern "C" size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H,
     return (size_t)B * R * A + (size_t)B * R + chunks * ((size_t)H * A + (size_t)A * A + 2 * A + 1);
 }
 
+// the three stages of the backward for `sides` (1 or 2) sides
+static int attn_bwd_launch(int B, int R, int H, int A, const AttnBwdSide& S0, const AttnBwdSide& S1, int sides, hipStream_t st) {
+    hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B, sides), dim3(256), (size_t)(R * A + 2 * R) * sizeof(float), st, B, R, H, A, S0, S1);
+    RBR_CHECK_LAUNCH("review_attn_bwd sample launch");
+    const int N = B * R, chunks = (N + kRedRows - 1) / kRedRows, n_out = H * A + A * A + 2 * A + 1;
+    hipLaunchKernelGGL(attn_bwd_partial_kernel, dim3(chunks, sides), dim3(256), (size_t)kRedRows * (3 * A + H + 1) * sizeof(float), st, N,
+                       H, A, S0, S1);
+    RBR_CHECK_LAUNCH("review_attn_bwd partial launch");
+    hipLaunchKernelGGL(attn_bwd_final_kernel, dim3((n_out + 255) / 256, sides), dim3(256), 0, st, chunks, H, A, S0, S1);
+    RBR_CHECK_LAUNCH("review_attn_bwd final launch");
+    return 0;
+}
+
+static AttnBwdSide attn_bwd_side(int B, int R, int A, const float* feat, const long long* oid, const rbr_attn_params& p, const float* att,
+                                 const float* hid, const float* d_out, const float* drop, const float* d_att, int pad_idx,
+                                 const rbr_attn_grads& g, float* d_feat, float* ws) {
+    AttnBwdSide S{};
+    S.feat = feat; S.oid = oid; S.p = p; S.att = att; S.hid = hid; S.d_out = d_out; S.drop = drop; S.d_att = d_att;
+    S.pad_idx = pad_idx; S.debd = g.debd; S.d_feat = d_feat; S.g = g;
+    S.ws_dpre = ws; S.ws_dl = ws + (size_t)B * R * A; S.part = S.ws_dl + (size_t)B * R;
+    return S;
+}
+
 extern "C" int rbr_review_attn_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
                                    const rbr_attn_params* p, const float* drop, const float* att, const float* hid,
                                    const float* d_out, const float* d_att, int32_t pad_idx, const rbr_attn_grads* g, float* d_feat,
                                    float* ws, void* stream) {
     if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
     if (!feat || !other_id || !p || !att || !hid || !d_out || !g || !d_feat || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const AttnBwdSide S = attn_bwd_side(B, R, A, feat, reinterpret_cast<const long long*>(other_id), *p, att, hid, d_out, drop, d_att,
+                                        pad_idx, *g, d_feat, ws);
+    return attn_bwd_launch(B, R, H, A, S, S, 1, (hipStream_t)stream);
+}
+
+// Backward of rbr_review_attn2_fwd (stacked blocks as there; d_out [2,B,H], d_att [2,B,R] or NULL, d_feat [2,B,R,H]).  The
+// embedding-row gradients g0->debd / g1->debd ([n0, A] / [n1, A] rows) are ZEROED here and then accumulated; every other
+// gradient is overwritten.  ws: 2 * rbr_review_attn_bwd_ws_floats(B, R, H, A) floats.
+extern "C" int rbr_review_attn2_bwd(int32_t B, int32_t R, int32_t H, int32_t A, const float* feat, const int64_t* other_id,
+                                    const rbr_attn_params* p0, const rbr_attn_params* p1, const float* drop, const float* att,
+                                    const float* hid, const float* d_out, const float* d_att, int32_t pad_idx0, int32_t pad_idx1,
+                                    const rbr_attn_grads* g0, const rbr_attn_grads* g1, int64_t n_ebd0, int64_t n_ebd1,
+                                    float* d_feat, float* ws, void* stream) {
+    if (!attn_args_ok(B, R, H, A)) return RBR_ERR_BAD_ARG;
+    if (!feat || !other_id || !p0 || !p1 || !att || !hid || !d_out || !g0 || !g1 || !d_feat || !ws || n_ebd0 <= 0 || n_ebd1 <= 0) {
+        set_error("null pointer");
+        return RBR_ERR_BAD_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
-    float* ws_dpre = ws;
-    float* ws_dl = ws + (size_t)B * R * A;
     const long long* oid = reinterpret_cast<const long long*>(other_id);
-    hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B), dim3(256), (size_t)(R * A + 2 * R) * sizeof(float), st, B, R, H, A,
-                       feat, oid, *p, att, hid, d_out, drop, d_att, pad_idx, g->debd, d_feat, ws_dpre, ws_dl);
-    RBR_CHECK_LAUNCH("review_attn_bwd sample launch");
-    float* part = ws_dl + (size_t)B * R;
-    const int N = B * R, chunks = (N + kRedRows - 1) / kRedRows, n_out = H * A + A * A + 2 * A + 1;
-    hipLaunchKernelGGL(attn_bwd_partial_kernel, dim3(chunks), dim3(256), (size_t)kRedRows * (3 * A + H + 1) * sizeof(float), st, N, H,
-                       A, feat, oid, p->ebd, hid, ws_dpre, ws_dl, part);
-    RBR_CHECK_LAUNCH("review_attn_bwd partial launch");
-    hipLaunchKernelGGL(attn_bwd_final_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, chunks, H, A, part, *g);
-    RBR_CHECK_LAUNCH("review_attn_bwd final launch");
-    return 0;
+    const size_t nf = (size_t)B * R * H, ni = (size_t)B * R, no = (size_t)B * H, nh = (size_t)B * R * A;
+    const size_t wsn = rbr_review_attn_bwd_ws_floats(B, R, H, A);
+    ZeroRegions z{{reinterpret_cast<int*>(g0->debd), reinterpret_cast<int*>(g1->debd), nullptr}, {(long)n_ebd0 * A, (long)n_ebd1 * A, 0}};
+    if (int e = zero_regions(z, st)) return e;
+    const AttnBwdSide S0 = attn_bwd_side(B, R, A, feat, oid, *p0, att, hid, d_out, drop, d_att, pad_idx0, *g0, d_feat, ws);
+    const AttnBwdSide S1 = attn_bwd_side(B, R, A, feat + nf, oid + ni, *p1, att + ni, hid + nh, d_out + no, drop ? drop + no : nullptr,
+                                         d_att ? d_att + ni : nullptr, pad_idx1, *g1, d_feat + nf, ws + wsn);
+    return attn_bwd_launch(B, R, H, A, S0, S1, 2, st);
 }

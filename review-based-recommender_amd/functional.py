@@ -782,6 +782,67 @@ class _ReviewAttn(torch.autograd.Function):
         return (d_feat, None, None, *grads, None)
 
 
+class _ReviewAttn2(torch.autograd.Function):
+    """Both LinearAttention pools of a two-tower model in one launch per stage -- rbr_review_attn2_* in rbr_hip.h.
+    feat [2,B,R,H], other_id [2,B,R], drop [2,B,H] or None, then the six parameters of side 0 and of side 1."""
+
+    NAMES = ("W_rv", "W_id", "h", "b1", "b2", "ebd")
+
+    @staticmethod
+    def forward(ctx, feat, other_id, pad0, pad1, drop, *params):
+        _, B, R, H = feat.shape
+        A = params[0].shape[1]
+        dev = feat.device
+        L_ = _lib.lib()
+        feat, other_id = feat.contiguous(), other_id.contiguous()
+        params = [t.contiguous() for t in params]
+        names = _ReviewAttn2.NAMES
+        aps = [_lib.AttnParams(*[dev_ptr(t, F32, n) for t, n in zip(params[6 * k:6 * k + 6], names)]) for k in range(2)]
+        drop = drop.contiguous() if drop is not None else None
+        if drop is not None and tuple(drop.shape) != (2, B, H):
+            raise RuntimeError(f"review_attention2: dropout multiplier {tuple(drop.shape)} is not [2, B, H] = {(2, B, H)}")
+        out = torch.empty(2, B, H, dtype=F32, device=dev)
+        att = torch.empty(2, B, R, 1, dtype=F32, device=dev)
+        hid = torch.empty(2, B, R, A, dtype=F32, device=dev)
+        check(L_.rbr_review_attn2_fwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(aps[0]),
+                                      C.byref(aps[1]), dev_ptr(drop, F32, "drop"), dev_ptr(out, F32, "out"), dev_ptr(att, F32, "att"),
+                                      dev_ptr(hid, F32, "hid"), current_stream()), "rbr_review_attn2_fwd")
+        ctx.dims = (B, R, H, A, int(pad0), int(pad1))
+        ctx.has_drop = drop is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(feat, other_id, att, hid, *params, *([drop] if drop is not None else []))
+        return out, att
+
+    @staticmethod
+    def backward(ctx, d_out, d_att):
+        B, R, H, A, pad0, pad1 = ctx.dims
+        feat, other_id, att, hid = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:16]
+        drop = ctx.saved_tensors[16] if ctx.has_drop else None
+        names = _ReviewAttn2.NAMES
+        dev = feat.device
+        L_ = _lib.lib()
+        aps = [_lib.AttnParams(*[dev_ptr(t, F32, n) for t, n in zip(params[6 * k:6 * k + 6], names)]) for k in range(2)]
+        grads = [torch.empty_like(t) for t in params]           # the embedding-row gradients are zeroed by the call
+        ags = [_lib.AttnGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads[6 * k:6 * k + 6], names)]) for k in range(2)]
+        d_feat = torch.empty_like(feat)
+        ws = torch.empty(2 * L_.rbr_review_attn_bwd_ws_floats(B, R, H, A), dtype=F32, device=dev)
+        d_out = d_out.contiguous() if d_out is not None else torch.zeros(2, B, H, dtype=F32, device=dev)
+        d_att = d_att.contiguous() if d_att is not None else None
+        check(L_.rbr_review_attn2_bwd(B, R, H, A, dev_ptr(feat, F32, "feat"), dev_ptr(other_id, I64, "other_id"), C.byref(aps[0]),
+                                      C.byref(aps[1]), dev_ptr(drop, F32, "drop"), dev_ptr(att, F32, "att"), dev_ptr(hid, F32, "hid"),
+                                      dev_ptr(d_out, F32, "d_out"), dev_ptr(d_att, F32, "d_att"), pad0, pad1, C.byref(ags[0]),
+                                      C.byref(ags[1]), params[5].shape[0], params[11].shape[0], dev_ptr(d_feat, F32, "d_feat"),
+                                      dev_ptr(ws, F32, "ws"), current_stream()), "rbr_review_attn2_bwd")
+        return (d_feat, None, None, None, None, *grads)
+
+
+def review_attention2(feat, other_id, params0, params1, *, pad_idx=(0, 0), drop=None):
+    """The user and the item LinearAttention of NARRE in one launch per stage: feat [2,B,R,H] (side 0 first), other_id [2,B,R],
+    params0 / params1 = (W_rv, W_id, h, b1, b2, ebd) of the sides, drop [2,B,H] or None.  Returns (out [2,B,H], att [2,B,R,1])."""
+    return _ReviewAttn2.apply(feat, other_id, pad_idx[0], pad_idx[1], drop, *params0, *params1)
+
+
 def review_attention(feat, other_id, W_rv, W_id, h, b1, b2, ebd, *, pad_idx=0, drop=None):
     """NARRE LinearAttention: returns (out [B,H], att [B,R,1]).  `drop` [B,H]: the multiplier of the nn.Dropout that follows
     (dropout_multiplier), applied inside the kernels -- forward and backward -- instead of by two elementwise launches."""

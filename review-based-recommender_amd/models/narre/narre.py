@@ -77,17 +77,17 @@ class NARRE(nn.Module):
             ids = RF.stack_rows(u_text.reshape(-1, T), i_text.reshape(-1, T))
         masks = RF.stack_rows(u_text_masks.reshape(-1, T), i_text_masks.reshape(-1, T))
         feats = self.ngram.encode(self.word_embeddings.weight, ids, masks, padding_idx=self.word_embeddings.padding_idx)
-        # unbind, not two slices: its backward is ONE stack of the two gradients (a slice pair costs two fills, two copies, an add)
-        u_feat, i_feat = feats.view(2, bz, R, self.hiddem_dim).unbind(0)
+        # both attention pools (user_att keyed by item ids, item_att by user ids: narre.py:177-178) in ONE launch per stage: the conv
+        # output is already the stacked [2, bz, R, H] block, the pooled features go to the rating head as one [2*bz, H] block, and
+        # so do the gradients on the way back -- no unbind / stack, no second stream
+        ua, ia = self.user_att, self.item_att
+        other = RF.stack_rows(reuid, reiid).view(2, bz, R)          # a view when the two id tensors are neighbours (sanitize_ids, the step's input block)
+        drop = RF.dropout_multiplier((2 * bz, self.hiddem_dim), ua.dropout.p, ua.training, feats.device)
+        out, att = RF.review_attention2(
+            feats.view(2, bz, R, self.hiddem_dim), other,
+            (ua.W_rv, ua.W_id, ua.h, ua.b_1, ua.b_2, ua.ebd_vals.weight), (ia.W_rv, ia.W_id, ia.h, ia.b_1, ia.b_2, ia.ebd_vals.weight),
+            pad_idx=(ua.padding_idx, ia.padding_idx), drop=None if drop is None else drop.view(2, bz, self.hiddem_dim))
+        u_att_scores, i_att_scores = att[0], att[1]
 
-        # the two attention pools share nothing: the item side runs on a second stream (forward and, through autograd's
-        # stream bookkeeping, backward)
-        side = RF.fork_tower(feats.device) if torch.is_grad_enabled() else None     # (eval: two 12-us kernels, not worth the host work)
-        self.item_att.rng_lane = 1 if side is not None else 0
-        with torch.cuda.stream(side):
-            i_feat, i_att_scores = self.item_att(i_feat, reiid)
-        u_feat, u_att_scores = self.user_att(u_feat, reuid)
-        RF.join_tower(side, i_feat, i_att_scores)
-
-        pred = rating_head(self.user_feat, self.item_feat, self.fm, u_feat, i_feat, u_id, i_id)
+        pred = rating_head(self.user_feat, self.item_feat, self.fm, out.view(2 * bz, self.hiddem_dim), None, u_id, i_id)
         return pred.view(-1), u_att_scores, i_att_scores
