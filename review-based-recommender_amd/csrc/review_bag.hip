@@ -11,6 +11,8 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace rbr {
 
@@ -147,6 +149,121 @@ __global__ __launch_bounds__(256) void bag_bwd_sorted_kernel(long n_pos, int T, 
             if (ona) atomicAdd(dtable + (long)cur * D + da, acca);
             if (onb) atomicAdd(dtable + (long)cur * D + db, accb);
         }
+    }
+}
+
+// Sort-free form (the default): one workgroup per window of kBagWin consecutive token positions buckets them by token in LDS
+// (hash table, as datt_gates.hip's gate backward), sums per distinct token the scaled gradient rows of the reviews it occurs
+// in, and adds ONE row per distinct token of the window.  f32 atomics are served per 64-byte request (~25 G/s) and requests
+// to one line queue behind each other (~35 ns): a Zipf-hot token now sends one row per window (~550 of them at the toys
+// shape), not one per occurrence -- and the 18 launches of the capture-safe merge sort are gone.
+constexpr int kBagWin = 512, kBagHash = 2048;
+
+__global__ __launch_bounds__(256) void bag_bwd_bucket_kernel(long n_pos, int T, int D, const long long* __restrict__ ids,
+                                                             const unsigned char* __restrict__ mask, int padding_idx,
+                                                             const float* __restrict__ drop, const float* __restrict__ inv_len,
+                                                             const float* __restrict__ d_out, float* __restrict__ dtable) {
+    __shared__ int s_tok[kBagWin], s_rev[kBagWin], s_fill[kBagWin];
+    __shared__ float s_inv[kBagWin];
+    __shared__ short s_leader[kBagWin], s_cnt[kBagWin], s_start[kBagWin], s_sorted[kBagWin], s_keys[kBagWin];
+    __shared__ int s_hkey[kBagHash], s_hval[kBagHash];
+    __shared__ int s_nkeys;
+    const long p0 = (long)blockIdx.x * kBagWin;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int k = tid; k < kBagHash; k += 256) { s_hkey[k] = -1; s_hval[k] = kBagWin; }
+    for (int r = tid; r < kBagWin; r += 256) {
+        const long k = p0 + r;
+        int t = -1, rev = 0;
+        float inv = 0.f;
+        if (k < n_pos) {
+            const long long id = ids[k];
+            if ((mask == nullptr || mask[k]) && id != padding_idx) { t = (int)id; rev = (int)(k / T); inv = inv_len[rev]; }
+        }
+        s_tok[r] = t; s_rev[r] = rev; s_inv[r] = inv; s_fill[r] = 0;
+    }
+    __syncthreads();
+    for (int r = tid; r < kBagWin; r += 256) {
+        const int t = s_tok[r];
+        int slot = -1;
+        if (t >= 0) {
+            unsigned hh = ((unsigned)t * 2654435761u) >> 21;              // kBagHash = 2^11
+            for (;;) {
+                const int old = atomicCAS(&s_hkey[hh], -1, t);
+                if (old == -1 || old == t) break;
+                hh = (hh + 1) & (kBagHash - 1);
+            }
+            atomicMin(&s_hval[hh], r);
+            slot = (int)hh;
+        }
+        s_leader[r] = (short)slot;
+    }
+    __syncthreads();
+    for (int r = tid; r < kBagWin; r += 256) {
+        const int slot = s_leader[r];
+        const int lead = slot >= 0 ? s_hval[slot] : -1;
+        s_leader[r] = (short)lead;
+        if (lead >= 0) atomicAdd(&s_fill[lead], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {      // exclusive scan of the per-token counts and of the leaders (dense key list)
+        int run = 0, krun = 0;
+        for (int r0 = 0; r0 < kBagWin; r0 += 64) {
+            const int r = r0 + lane;
+            const int c = s_fill[r];
+            int inc = c, kinc = c > 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o), kv = __shfl_up(kinc, o);
+                if (lane >= o) { inc += v; kinc += kv; }
+            }
+            s_start[r] = (short)(run + inc - c);
+            s_cnt[r] = (short)c;
+            s_fill[r] = 0;
+            if (c > 0) s_keys[krun + kinc - 1] = (short)r;
+            run += __shfl(inc, 63);
+            krun += __shfl(kinc, 63);
+        }
+        if (lane == 0) s_nkeys = krun;
+    }
+    __syncthreads();
+    for (int r = tid; r < kBagWin; r += 256) {
+        const int lead = s_leader[r];
+        if (lead >= 0) s_sorted[s_start[lead] + atomicAdd(&s_fill[lead], 1)] = (short)r;
+    }
+    __syncthreads();
+    const int total = s_nkeys * D;
+    constexpr int kU = 4;                            // items in flight per thread: their first gradient rows before the first atomic
+    for (int it = tid; it < total; it += 256 * kU) {
+        float sum[kU];
+        float* dst[kU];
+        int cnt[kU], base[kU], dd[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int item = it + u * 256;
+            const bool ok = item < total;
+            const int k = ok ? item / D : 0, d = ok ? item - k * D : 0;
+            const int key = s_keys[k];
+            cnt[u] = ok ? s_cnt[key] : 0;
+            base[u] = s_start[key];
+            dd[u] = d;
+            dst[u] = dtable + (long)s_tok[key] * D + d;
+            sum[u] = 0.f;
+            if (ok) {
+                const int r = s_sorted[base[u]];
+                const long o = (long)s_rev[r] * D + d;
+                sum[u] = d_out[o] * s_inv[r] * (drop != nullptr ? drop[o] : 1.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            for (int q = 1; q < cnt[u]; ++q) {
+                const int r = s_sorted[base[u] + q];
+                const long o = (long)s_rev[r] * D + dd[u];
+                sum[u] += d_out[o] * s_inv[r] * (drop != nullptr ? drop[o] : 1.f);
+            }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (cnt[u] > 0) atomicAdd(dst[u], sum[u]);
     }
 }
 
@@ -327,6 +444,13 @@ extern "C" int rbr_review_bag_bwd(int32_t n_rev, int32_t T, int32_t D, int32_t V
     const long n_pos = (long)n_rev * T;
     if (n_pos >= (1L << 31)) { set_error("too many token positions"); return RBR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
+    const char* bag_env = getenv("RBR_BAG_BWD");            // read per call: "sort" selects the sorted-run form below (kept as a cross-check)
+    if (!(bag_env && !strcmp(bag_env, "sort"))) {          // default: LDS-bucketed windows, no sort
+        hipLaunchKernelGGL(bag_bwd_bucket_kernel, dim3((unsigned)((n_pos + kBagWin - 1) / kBagWin)), dim3(256), 0, st, n_pos, T, D,
+                           reinterpret_cast<const long long*>(ids), mask, padding_idx, drop, inv_len, d_out, dtable);
+        RBR_CHECK_LAUNCH("review_bag bwd (bucketed) launch");
+        return 0;
+    }
     // rocPRIM's radix sort re-initialises its state with hipMemsetAsync (device_radix_sort.hpp:122,251) whenever it takes
     // its onesweep path, and memset NODES fault when a recorded hipGraph is replayed on this stack (DESIGN.md section 4,
     // hipGraph).  While the stream is being captured the occurrences are therefore sorted with rocprim::merge_sort, which

@@ -99,6 +99,15 @@ def test_siamese_ops_random(case):
     (out * d.to(DEV)).sum().backward()
     assert max_err(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
     _cmp_grads([gt], [ct])
+    # the sorted-run form of the backward (RBR_BAG_BWD=sort) against the same reference
+    import os
+    os.environ["RBR_BAG_BWD"] = "sort"
+    try:
+        gt2 = _leaf(table.to(DEV))
+        (RF.review_bag(gt2, ids.to(DEV), mask.to(DEV), drop=drop.to(DEV), padding_idx=0) * d.to(DEV)).sum().backward()
+    finally:
+        del os.environ["RBR_BAG_BWD"]
+    _cmp_grads([gt2], [ct])
 
     B, R, H, K = int(rng.choice([1, 6])), int(rng.integers(1, 12)), int(rng.choice([4, 27, 108])), int(rng.choice([2, 32]))
     rev = torch.randn(B, R, H, generator=g) * 0.5
