@@ -641,39 +641,6 @@ def _drop_rng(dev, lane: int = 0):
     return seed, state
 
 
-_TOWER_STREAMS: dict = {}
-
-
-def fork_tower(dev):
-    """A second HIP stream, made to wait for the current one: run the item tower of a two-tower model under
-    `with torch.cuda.stream(side):`, enqueue the user tower on the current stream, then join_tower(side, outputs).  autograd
-    replays each op's backward on its forward stream, so the towers overlap in both directions, and a captured step gets two
-    parallel branches.  Returns None with RBR_TOWER_OVERLAP=0 (torch.cuda.stream(None) is a no-op: plain sequential code).
-    Only for sub-networks that share NO parameter with the rest of the step (NARRE's two attention pools): a parameter used
-    on both streams gets its gradient accumulated across streams, which torch warns about and which crashed graph capture
-    for D-ATT's shared word table and fc."""
-    if os.environ.get("RBR_TOWER_OVERLAP", "1") == "0":
-        return None
-    dev = torch.device(dev)
-    s = _TOWER_STREAMS.get(dev)
-    if s is None:
-        s = _TOWER_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    s.wait_stream(torch.cuda.current_stream(dev))
-    return s
-
-
-def join_tower(side, *tensors) -> None:
-    """The current stream waits for `side`; `tensors` (made on `side`, used from here on) are marked as used by the current
-    stream for the caching allocator."""
-    if side is None:
-        return
-    cur = torch.cuda.current_stream(side.device)
-    cur.wait_stream(side)
-    for t in tensors:
-        if t is not None and t.is_cuda:
-            t.record_stream(cur)
-
-
 _DROP_STATE: dict = {}       # per device: [call number, workgroup ticket] (uint64 x 2), advanced on the device
 
 

@@ -27,11 +27,9 @@ class LinearAttention(nn.Module):
         self.ebd_vals = nn.Embedding(vocab_size, hidden_dim, padding_idx=padding_idx)
         self.dropout = nn.Dropout(p=dropout)
 
-    rng_lane = 0      # NARRE.forward runs the item side on a second stream and gives it its own stream of dropout draws
-
     def forward(self, feat, other_id):
         """feat [bz, dnum, hidden], other_id [bz, dnum] -> (out [bz, hidden], att_scores [bz, dnum, 1])."""
-        drop = RF.dropout_multiplier((feat.shape[0], feat.shape[2]), self.dropout.p, self.training, feat.device, lane=self.rng_lane)
+        drop = RF.dropout_multiplier((feat.shape[0], feat.shape[2]), self.dropout.p, self.training, feat.device)
         return RF.review_attention(feat, other_id, self.W_rv, self.W_id, self.h, self.b_1, self.b_2,
                                    self.ebd_vals.weight, pad_idx=self.padding_idx, drop=drop)
 
