@@ -141,38 +141,34 @@ def set_tap_sink(sink, table: Optional[torch.Tensor] = None) -> None:
 
 
 # ---- one gradient buffer for several producers of a table's gradient ------------------------------------------------------
-_TABLE_ACC: dict = {}        # table.data_ptr() -> (accumulation buffer, stream it was made on)
+def _fanout_acc(table: torch.Tensor):
+    """Called in an op's forward: the (buffer, stream) of the table_fanout `table` is an alias of, or None.  The buffer hangs on
+    the fan-out's own autograd node, so concurrent or interleaved forwards / backwards of several steps cannot meet in one."""
+    node = table.grad_fn
+    return getattr(node, "acc", None) if type(node).__name__ == "_TableFanoutBackward" else None
 
 
-def _from_fanout(table: torch.Tensor) -> bool:
-    """Called in an op's forward: is `table` one of table_fanout's aliases?  Only then may its backward use the shared buffer
-    (an op handed the bare table while a buffer of an unfinished step is still registered must not touch it)."""
-    return type(table.grad_fn).__name__ == "_TableFanoutBackward"
-
-
-def _table_acc(table: torch.Tensor, from_fanout: bool):
-    """The shared gradient buffer of `table` (see table_fanout) when this op may add its rows to it: same stream only."""
-    ent = _TABLE_ACC.get(table.data_ptr()) if from_fanout else None
-    if ent is None or ent[1] != torch.cuda.current_stream(table.device):
+def _table_acc(acc, device):
+    """In an op's backward: the shared buffer when this op may add its rows to it (same stream as the fan-out), else None."""
+    if acc is None or acc[1] != torch.cuda.current_stream(device):
         return None
-    return ent[0]
+    return acc[0]
 
 
 class _TableFanout(torch.autograd.Function):
     """n aliases of a table, one per consumer.  The consumers' backwards that support it add their rows into ONE zeroed buffer
-    (_TABLE_ACC) and each hand that same buffer back; here the duplicates are dropped, so a step with 8 producers of table
-    gradient (D-ATT: two gates and two convs per tower) pays one 20 MB fill instead of seven 60 MB autograd adds and eight
+    (kept on this node) and each hand that same buffer back; here the duplicates are dropped, so a step with 8 producers of
+    table gradient (D-ATT: two gates and two convs per tower) pays one 20 MB fill instead of seven 60 MB autograd adds and eight
     dense [V, D] outputs.  A consumer that returns a tensor of its own is added the ordinary way."""
 
     @staticmethod
     def forward(ctx, table, n):
-        ctx.key = table.data_ptr()
         ctx.set_materialize_grads(False)
+        ctx.acc = (torch.zeros_like(table), torch.cuda.current_stream(table.device))
         return tuple(table.view(table.shape) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
-        _TABLE_ACC.pop(ctx.key, None)
         total, seen = None, set()
         for g in grads:
             if g is None or g.data_ptr() in seen:
@@ -188,7 +184,6 @@ def table_fanout(table: torch.Tensor, n: int):
     dense gradient each: see _TableFanout.  Without gradients: the table itself, n times."""
     if not (torch.is_grad_enabled() and table.requires_grad and table.is_cuda):
         return (table,) * n
-    _TABLE_ACC[table.data_ptr()] = (torch.zeros_like(table), torch.cuda.current_stream(table.device))
     return _TableFanout.apply(table, n)
 
 
@@ -197,7 +192,7 @@ class _TextCNN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *wb):
-        ctx.from_fanout = _from_fanout(table)
+        ctx.fanout_acc = _fanout_acc(table)
         n = len(kernel_sizes)
         weights, biases = wb[:n], wb[n:]
         dev_ptr(table.contiguous(), F32, "word table")   # device / dtype gate before anything touches HIP
@@ -412,7 +407,7 @@ class _TextCNN(torch.autograd.Function):
                     ev.record()
                 _join(join)
                 return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-            acc = _table_acc(table, ctx.from_fanout) if need_table else None
+            acc = _table_acc(ctx.fanout_acc, dev) if need_table else None
             if acc is not None:          # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
                 dtable = acc
             fn = L_.rbr_textcnn_bwd_dtable_prod_acc if acc is not None else L_.rbr_textcnn_bwd_dtable_prod
@@ -1125,7 +1120,7 @@ class _DattGate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, table, w, b0, ids, is_global, padding_idx, rows=None):
-        ctx.from_fanout = _from_fanout(table)
+        ctx.fanout_acc = _fanout_acc(table)
         ctx.gate_ws = None
         ctx.rows = rows                              # the tower's distinct-token rows (datt_token_rows) or None
         B, L = ids.shape
@@ -1166,7 +1161,7 @@ class _DattGate(torch.autograd.Function):
         dgate = dgate.contiguous()
         dw = torch.empty_like(w)
         db0 = torch.empty(1, dtype=F32, device=dev)
-        acc = _table_acc(table, ctx.from_fanout) if ctx.needs_input_grad[0] else None      # the step's shared gradient buffer
+        acc = _table_acc(ctx.fanout_acc, dev) if ctx.needs_input_grad[0] else None      # the step's shared gradient buffer
         if ctx.gate_ws is not None:      # token-product local gate: the whole table gradient is overwritten (or its rows added)
             dtable = (acc if acc is not None else torch.empty_like(table)) if ctx.needs_input_grad[0] else None
             check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, table.shape[0], dev_ptr(ids, I64, "ids"),

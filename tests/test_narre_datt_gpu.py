@@ -155,6 +155,36 @@ def test_global_gate_backward_over_token_rows_matches_the_plain_one(L):
     assert RF.datt_token_rows(ids[:2, :64], V) is None                   # too few positions: the plain path is kept
 
 
+def test_datt_shared_table_gradient_buffer_survives_interleaved_steps():
+    """functional.table_fanout: the eight producers of word-table gradient of a D-ATT step add their rows into one buffer that
+    hangs on the step's own fan-out node.  Two micro-batches run forward, forward, backward, backward (gradient accumulation)
+    must give the sum of their separately computed gradients -- a buffer shared ACROSS the two steps would not."""
+    from review_based_recommender_amd.models.dual_att.dual_att import DualAtt
+    torch.manual_seed(11)
+    V, L, B = 2000, 512, 32
+    m = quiet(DualAtt, V, L, 5, 40, 24, 100, 64, 16, 0.0, None).to(DEV)
+    with torch.no_grad():
+        m.word_embeddings.embedding.weight.mul_(0.3)
+    gen = torch.Generator().manual_seed(3)
+    batches = [tuple((torch.rand(B, L, generator=gen) ** 3 * V).long().clamp_(1, V - 1).to(DEV) for _ in range(2)) for _ in range(2)]
+    ys = [torch.randn(B, generator=gen).to(DEV) for _ in range(2)]
+    table = m.word_embeddings.embedding.weight
+    singles = []
+    for b, y in zip(batches, ys):
+        m.zero_grad(set_to_none=True)
+        torch.nn.functional.mse_loss(m(*b), y).backward()
+        singles.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    assert float(singles[0]["word_embeddings.embedding.weight"].abs().max()) > 0
+    m.zero_grad(set_to_none=True)
+    losses = [torch.nn.functional.mse_loss(m(*b), y) for b, y in zip(batches, ys)]      # forward, forward
+    losses[0].backward()
+    losses[1].backward()                                                               # backward, backward
+    for k, p in m.named_parameters():
+        want = singles[0][k] + singles[1][k]
+        assert float((p.grad - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), k
+    assert table.grad.shape == table.shape
+
+
 def test_datt_state_dict_keys():
     cfg = synth.DATT_CFGS["tiny"]
     assert list(_datt(cfg).state_dict().keys()) == list(synth.datt_params(cfg, 0).keys())
