@@ -302,13 +302,15 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
+template <bool ACC>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
-                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable,
-                                                        int accumulate) {
-    // accumulate: dtable is a gradient buffer shared with other producers on this stream (functional.table_fanout) -- the rows
-    // of the batch's tokens are ADDED to it, nothing else is touched (no zero rows, the pad row is skipped)
+                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
+    // ACC: dtable is a gradient buffer shared with other producers on this stream (functional.table_fanout) -- the rows of the
+    // batch's tokens are ADDED to it, nothing else is touched (no zero rows, the pad row is skipped).  A template parameter: as
+    // a run-time flag it cost the plain form 12 registers and one wave per SIMD (63 -> 71 us at cfg2).
+    constexpr bool accumulate = ACC;
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* s_pc = s_dyn + wave * 2 * KGW;
@@ -1042,8 +1044,12 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     }
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    hipLaunchKernelGGL(g_times_w_kernel, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                       tok_of_row, row_of_token, d->V, dtable, (phases & kGAccumulate) ? 1 : 0);
+    if (phases & kGAccumulate)
+        hipLaunchKernelGGL(g_times_w_kernel<true>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
+                           tok_of_row, row_of_token, d->V, dtable);
+    else
+        hipLaunchKernelGGL(g_times_w_kernel<false>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
+                           tok_of_row, row_of_token, d->V, dtable);
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
