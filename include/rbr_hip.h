@@ -117,6 +117,18 @@ int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, cons
 int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream);
 int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                           float* pval, int32_t* pidx, void* ws, void* stream);
+/* Step-level fusions of the same stages (round 3; each removes a launch from a training step):
+ *   prod_prepare_ids: prepare with the model's id range check (rbr_sanitize_ids below, nn.Embedding's IndexError,
+ *            deepconn/layers.py:23) in its first launch.  `sets` (HOST array) are the forward's raw id tensors and their clean
+ *            copies; `ids` = sets[0].out must hold the conv's d->n_docs * d->L token ids (one set, or two adjacent = both towers);
+ *   prod_pool_zero: pool whose launch also clears the rows of the backward's G in `bwd_ws`
+ *            (rbr_textcnn_bwd_prod_ws_bytes(d) bytes, allocated by the forward): the backward passes RBR_G_ZEROED. */
+struct rbr_id_set;
+int rbr_textcnn_prod_prepare_ids(const rbr_textcnn_desc* d, int32_t n_sets, const struct rbr_id_set* sets, int64_t* err,
+                                 const int64_t* ids, const uint8_t* mask, const float* const* W, int32_t* pidx, void* ws,
+                                 void* stream);
+int rbr_textcnn_prod_pool_zero(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                               float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream);
 
 /* Stage 3: reduce the slabs of each document, add the conv bias, apply the activation.
  * feat[n_docs, C] (C = sum ch[w]); argmax[n_docs, C] = first position attaining the max.
@@ -174,6 +186,30 @@ int rbr_textcnn_bwd_g_build(const rbr_textcnn_desc* d, const int64_t* ids, const
                             const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                             float* dgate, void* stream);
 int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, float* dtable, void* stream);
+/* Every form of the token-product table gradient behind one entry (the four calls above are fixed-flag forms of it):
+ *   RBR_G_BUILD | RBR_G_PRODUCT  the phases to run (G from the argmax windows; dtable = G @ Wprod^T);
+ *   RBR_G_ACCUMULATE             the batch's rows are ADDED to the dense dtable [V, D];
+ *   RBR_G_ROWS                   `dtable` is the gradient in COMPACT form [list rows, D]: row r belongs to token tok_of_row[r]
+ *                                of the forward's list (rbr_textcnn_token_list), tokens the batch does not hold have no row
+ *                                (their gradient is zero and is never written: at cfg2 that is 57 % of embedding_dense_backward's
+ *                                [V, D] output, deepconn/layers.py:22-24), and sq_part[rbr_textcnn_row_grad_partials()] receives
+ *                                per-workgroup sums of squares of the rows in a fixed order (the table's share of
+ *                                clip_grad_norm_'s norm).  Consumers: rbr_clip_adam_step_rows, rbr_row_grad_to_dense;
+ *   RBR_G_ZEROED                 G's rows are already zero (rbr_textcnn_prod_pool_zero cleared them): no zero launch.
+ * sq_part is only read with RBR_G_ROWS; dgate as for rbr_textcnn_bwd_dtable_prod. */
+#define RBR_G_BUILD 1
+#define RBR_G_PRODUCT 2
+#define RBR_G_ACCUMULATE 4
+#define RBR_G_ROWS 8
+#define RBR_G_ZEROED 16
+int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                   const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                   float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream);
+size_t rbr_textcnn_row_grad_partials(void);
+/* Device addresses of the forward's token list inside `fwd_ws` (its layout is private): row_of_token [V] (list row or -1),
+ * n_rows [1] (rows in the list), tok_of_row [cap]; *cap = rows a compact gradient must have room for.  Any out-pointer may be NULL. */
+int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, const int32_t** row_of_token, const int32_t** n_rows,
+                           const int64_t** tok_of_row, int32_t* cap);
 /* Conv weight / bias gradients from the G the call above left in `bwd_ws` (dW = G^T @ table[distinct tokens] on the f32
  * MFMA pipe, split over token ranges, fixed-order reduce).  For many short documents (NARRE's reviews) this replaces
  * rbr_textcnn_bwd_dw; rbr_textcnn_bwd_dw_from_g_ws_floats(d) == 0 means "use rbr_textcnn_bwd_dw".  Needs the SAME fwd_ws /
@@ -236,6 +272,19 @@ int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const float* u_feat
                             const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, float p_drop,
                             uint64_t seed, uint64_t* rng_state, float* drop_out, float* zero_buf, int64_t zero_n,
                             float* ul, float* il, float* pred, void* stream);
+
+/* The head forward of a two-tower model whose encoder ran rbr_textcnn_prod_pool / _conv_fwd on the STACKED batch (B user
+ * documents, then B item documents; d->n_docs = 2B): rbr_textcnn_pool_finalize (deepconn/layers.py:107-109: bias, ReLU, the
+ * max over all slabs), the head above (drop: a given multiplier, or p_drop > 0: drawn in-kernel as rbr_pair_head_fwd_train
+ * does) and -- when target != NULL -- the trainers' nn.MSELoss(mean) (train_deepconn_pp.py:137,164: loss[0], d_pred_unit as
+ * rbr_mse_loss_fwd) in ONE launch instead of three.  feat / argmax [2B, C] are written for the backward.  ticket: one int32
+ * in device memory, zero before the first call (the launch re-arms it).  RBR_ERR_UNSUPPORTED when the conv has more than 256
+ * channel slots. */
+int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx, const float* const* bias,
+                           float* feat, int32_t* argmax, int32_t K, const int64_t* u_id, const int64_t* i_id,
+                           const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed, uint64_t* rng_state,
+                           float* drop_out, float* zero_buf, int64_t zero_n, float* ul, float* il, float* pred,
+                           const float* target, float* loss, float* d_pred_unit, int32_t* ticket, void* stream);
 
 /* d_ufeat/d_ifeat [B,H] overwritten; dense grads overwritten; embedding grads accumulated
  * (rows u_id==pad_u / i_id==pad_i get none: nn.Embedding padding_idx).
@@ -442,6 +491,25 @@ size_t rbr_clip_adam_ws_floats(void);
 int rbr_clip_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1, float beta2,
                        float eps, float* step, float* gnorm_out, float* ws, void* stream);
+/* The same step when ONE of the tensors is an embedding table [V, D] whose gradient arrives in compact row form (the
+ * token-product conv's backward with RBR_G_ROWS): g[v, :] = rows[row_of_token[v], :] for the tokens of the batch, exactly 0 for
+ * every other row -- the update formula is unchanged (so parameters and Adam state come out as with the dense gradient
+ * nn.Embedding's backward builds, deepconn/layers.py:22-24 + trainer/train_deepconn_pp.py:166-167, bit for bit), but the
+ * zero rows are neither read for the norm, nor read for the update, nor written back when the clip scales the gradient.
+ * grads[rg->tensor] is ignored (may be NULL); `rows` is left clipped.  D % 4 == 0, V * D < 2^32, 16-byte aligned pointers. */
+typedef struct rbr_row_grad {
+    int32_t tensor;                 /* index of the table among the n_tensors */
+    int32_t V, D;
+    const int32_t* row_of_token;    /* [V] list row or -1 */
+    float* rows;                    /* [list rows, D] */
+    const float* sq_part;           /* [n_sq] partial sums of squares of `rows` */
+    int32_t n_sq;
+} rbr_row_grad;
+int rbr_clip_adam_step_rows(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1, float beta2,
+                            float eps, float* step, float* gnorm_out, float* ws, const rbr_row_grad* rg, void* stream);
+/* dense[v, :] = rows[row_of_token[v], :] for listed tokens, 0 elsewhere: the [V, D] gradient for consumers outside the fused step */
+int rbr_row_grad_to_dense(int32_t V, int32_t D, const int32_t* row_of_token, const float* rows, float* dense, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,12 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def extra_flags():
+    """RBR_DIAG=1 in the environment builds the diagnostic library (-DRBR_DIAG: in-kernel time stamps and the RBR_DEV_*
+    ablation switches of the dev tools); the product build has neither."""
+    return ["-DRBR_DIAG"] if os.environ.get("RBR_DIAG") == "1" else []
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
@@ -39,17 +45,24 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not is_stale():
         return LIB
     hipcc = _hipcc()
-    objs = []
+    objs, todo = [], []
     for src in sources():
         obj = os.path.splitext(src)[0] + ".o"
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
                 os.path.getmtime(src), *(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))),
                 os.path.getmtime(os.path.join(HERE, "..", "include", "rbr_hip.h"))):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            todo.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *extra_flags(), "-c", src, "-o", obj])
         objs.append(obj)
+
+    def compile_one(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:      # the translation units are independent: a few at a time (each hipcc is itself single-threaded)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, min(6, (os.cpu_count() or 2) - 1)))) as ex:
+            list(ex.map(compile_one, todo))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

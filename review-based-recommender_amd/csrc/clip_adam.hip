@@ -29,6 +29,15 @@ struct OptTable {
     long n[RBR_OPT_MAX_TENSORS];
     long chunk0[RBR_OPT_MAX_TENSORS + 1];      // first global chunk of tensor k (prefix sums)
     int count;
+    // Tensor `rows_k` (-1: none) is an embedding table [V, rows_D] whose gradient arrives in COMPACT form (the token-product
+    // conv's backward, rbr_textcnn_bwd_dtable_prod_ex with RBR_G_ROWS): g[v, :] = grows[row_of_token[v], :] when the batch holds
+    // token v (row_of_token[v] >= 0), and exactly 0 otherwise -- the same update formula with g = 0, so the result is the dense
+    // path's bit for bit, without reading (or, when clipping, re-writing) the ~57 % of the dense gradient that is zeros.
+    // sq_part[n_sq]: the producer's partial sums of squares of grows (the table's share of the norm).
+    int rows_k, rows_D, n_sq;
+    const int* row_of_token;
+    float* grows;
+    const float* sq_part;
 };
 
 __device__ __forceinline__ int tensor_of_chunk(const OptTable& T, long chunk) {
@@ -54,6 +63,9 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const OptTable T, long
     float acc = 0.f;
     for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int k = tensor_of_chunk(T, c);
+        if (k == T.rows_k) {                 // compact-gradient table: its sum of squares comes as partials (below)
+            continue;
+        }
         const long e0 = (c - T.chunk0[k]) * kOptChunk;
         const long n = min((long)kOptChunk, T.n[k] - e0);
         const float* g = T.g[k] + e0;
@@ -76,6 +88,8 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const OptTable T, long
             for (long i = threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
         }
     }
+    if (T.rows_k >= 0)                       // fixed partition of the producer's partials over the grid: reproducible
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < T.n_sq; i += gridDim.x * 256) acc += T.sq_part[i];
     const float s = block_sum(acc, s_red);
     if (threadIdx.x == 0) {
         partials[blockIdx.x] = s;
@@ -99,6 +113,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
     const float step_size = lr / bc1;
     const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+#define RBR_ADAM1(G, M, V, P, c)                                       \
+            G.c *= coef;                                               \
+            M.c = M.c + w1 * (G.c - M.c);                              \
+            V.c = beta2 * V.c + w2 * G.c * G.c;                        \
+            P.c -= step_size * M.c / (sqrtf(V.c) / bc2_sqrt + eps);
     for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const int k = tensor_of_chunk(T, c);
         const long e0 = (c - T.chunk0[k]) * kOptChunk;
@@ -107,13 +126,45 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
         float* g = T.g[k] + e0;
         float* m = T.m[k] + e0;
         float* v = T.v[k] + e0;
+        if (k == T.rows_k) {                 // compact-gradient table (rows_D % 4 == 0 and 16-byte aligned pointers: checked on the host)
+            const int D = T.rows_D;
+            const long n4r = n >> 2;         // numel = V * D is a multiple of 4
+            for (long i0 = 0; i0 < n4r; i0 += 1024) {
+                constexpr int U = 4;
+                float4 G[U], M[U], V[U], P[U];
+                long goff[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long i = i0 + threadIdx.x + 256 * u;
+                    goff[u] = -1;
+                    if (i < n4r) {
+                        const unsigned e = (unsigned)(e0 + 4 * i);          // numel < 2^32: checked on the host
+                        const unsigned tok = e / (unsigned)D;
+                        const int r = T.row_of_token[tok];
+                        if (r >= 0) goff[u] = (long)r * D + (e - tok * (unsigned)D);
+                        M[u] = reinterpret_cast<float4*>(m)[i]; V[u] = reinterpret_cast<float4*>(v)[i];
+                        P[u] = reinterpret_cast<float4*>(p)[i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    G[u] = (goff[u] >= 0) ? *reinterpret_cast<const float4*>(T.grows + goff[u]) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long i = i0 + threadIdx.x + 256 * u;
+                    if (i >= n4r) continue;
+                    RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
+                    RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
+                    if (clipped && goff[u] >= 0) *reinterpret_cast<float4*>(T.grows + goff[u]) = G[u];
+                    reinterpret_cast<float4*>(m)[i] = M[u];
+                    reinterpret_cast<float4*>(v)[i] = V[u];
+                    reinterpret_cast<float4*>(p)[i] = P[u];
+                }
+            }
+            continue;
+        }
         const bool al = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
         const long n4 = al ? (n >> 2) : 0;
-#define RBR_ADAM1(G, M, V, P, c)                                       \
-            G.c *= coef;                                               \
-            M.c = M.c + w1 * (G.c - M.c);                              \
-            V.c = beta2 * V.c + w2 * G.c * G.c;                        \
-            P.c -= step_size * M.c / (sqrtf(V.c) / bc2_sqrt + eps);
         if (al && n == kOptChunk) {          // whole chunk: all 16 loads of a thread in flight before the first use
             constexpr int U = kOptChunk / 1024;
             float4 G[U], M[U], V[U], P[U];
@@ -162,16 +213,27 @@ using namespace rbr;
 
 extern "C" size_t rbr_clip_adam_ws_floats(void) { return kOptMaxPartials; }
 
-extern "C" int rbr_clip_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                                  float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1,
-                                  float beta2, float eps, float* step, float* gnorm_out, float* ws, void* stream) {
+static int clip_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                          float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1,
+                          float beta2, float eps, float* step, float* gnorm_out, float* ws, void* stream, const rbr_row_grad* rg) {
     if (n_tensors <= 0 || n_tensors > RBR_OPT_MAX_TENSORS) { set_error("n_tensors=%d (1..%d)", n_tensors, RBR_OPT_MAX_TENSORS); return RBR_ERR_BAD_ARG; }
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     OptTable T{};
     T.count = n_tensors;
+    T.rows_k = -1;
+    if (rg != nullptr) {
+        const int k = rg->tensor;
+        if (k < 0 || k >= n_tensors || rg->D <= 0 || rg->D % 4 != 0 || rg->V <= 0 || (int64_t)rg->V * rg->D != numel[k] || numel[k] >= ((int64_t)1 << 32) || !rg->row_of_token ||
+            !rg->rows || !rg->sq_part || rg->n_sq <= 0 || ((((uintptr_t)rg->rows) | ((uintptr_t)params[k]) | ((uintptr_t)exp_avg[k]) |
+                                                            ((uintptr_t)exp_avg_sq[k])) & 15) != 0) {
+            set_error("clip_adam_step_rows: malformed row gradient (tensor %d, V=%d, D=%d)", k, rg->V, rg->D);
+            return RBR_ERR_BAD_ARG;
+        }
+        T.rows_k = k; T.rows_D = rg->D; T.n_sq = rg->n_sq; T.row_of_token = rg->row_of_token; T.grows = rg->rows; T.sq_part = rg->sq_part;
+    }
     long chunks = 0;
     for (int k = 0; k < n_tensors; ++k) {
-        if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] <= 0) { set_error("tensor %d: null pointer or empty", k); return RBR_ERR_BAD_ARG; }
+        if (!params[k] || (!grads[k] && k != T.rows_k) || !exp_avg[k] || !exp_avg_sq[k] || numel[k] <= 0) { set_error("tensor %d: null pointer or empty", k); return RBR_ERR_BAD_ARG; }
         T.p[k] = params[k]; T.g[k] = grads[k]; T.m[k] = exp_avg[k]; T.v[k] = exp_avg_sq[k]; T.n[k] = numel[k];
         T.chunk0[k] = chunks;
         chunks += (numel[k] + kOptChunk - 1) / kOptChunk;
@@ -185,5 +247,47 @@ extern "C" int rbr_clip_adam_step(int32_t n_tensors, float* const* params, float
     hipLaunchKernelGGL(clip_adam_kernel, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step,
                        gnorm_out);
     RBR_CHECK_LAUNCH("clip_adam launch");
+    return 0;
+}
+
+extern "C" int rbr_clip_adam_step(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1,
+                                  float beta2, float eps, float* step, float* gnorm_out, float* ws, void* stream) {
+    return clip_adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, max_norm, lr, beta1, beta2, eps, step, gnorm_out, ws,
+                          stream, nullptr);
+}
+
+extern "C" int rbr_clip_adam_step_rows(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                                       float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1,
+                                       float beta2, float eps, float* step, float* gnorm_out, float* ws, const rbr_row_grad* rg,
+                                       void* stream) {
+    if (!rg) { set_error("clip_adam_step_rows: null row gradient"); return RBR_ERR_BAD_ARG; }
+    return clip_adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, max_norm, lr, beta1, beta2, eps, step, gnorm_out, ws,
+                          stream, rg);
+}
+
+// dense[v, :] = rows[row_of_token[v], :] for the tokens the batch holds, 0 elsewhere: the [V, D] gradient nn.Embedding's backward
+// would have produced, for whoever wants it outside the fused optimizer step (tests, logging, a dense all-reduce).
+namespace rbr {
+__global__ __launch_bounds__(256) void rows_to_dense_kernel(int V, int D4, const int* __restrict__ row_of_token,
+                                                            const float4* __restrict__ rows, float4* __restrict__ dense) {
+    const long n = (long)V * D4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int v = (int)(i / D4);
+        const int r = row_of_token[v];
+        dense[i] = (r >= 0) ? rows[(long)r * D4 + (i - (long)v * D4)] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+}  // namespace rbr
+
+extern "C" int rbr_row_grad_to_dense(int32_t V, int32_t D, const int32_t* row_of_token, const float* rows, float* dense, void* stream) {
+    if (V <= 0 || D <= 0 || D % 4 != 0 || !row_of_token || !rows || !dense || ((((uintptr_t)rows) | ((uintptr_t)dense)) & 15) != 0) {
+        set_error("row_grad_to_dense: bad arguments (V=%d, D=%d)", V, D);
+        return RBR_ERR_BAD_ARG;
+    }
+    const long n = (long)V * (D / 4);
+    hipLaunchKernelGGL(rows_to_dense_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, V,
+                       D / 4, row_of_token, reinterpret_cast<const float4*>(rows), reinterpret_cast<float4*>(dense));
+    RBR_CHECK_LAUNCH("rows_to_dense launch");
     return 0;
 }

@@ -345,39 +345,14 @@ namespace rbr {
 // (err[0] bad ids so far, err[1] one offending value, err[2] its set), which the host turns into the IndexError at its
 // next synchronisation point (functional.check_id_errors).  Up to 8 tensors per launch; the outputs may be adjacent slices
 // of one buffer, which also stacks the two towers' token ids for free.
-struct IdSets {
-    const long long* in[RBR_MAX_ID_SETS];
-    long long* out[RBR_MAX_ID_SETS];
-    long long n[RBR_MAX_ID_SETS], limit[RBR_MAX_ID_SETS], replace[RBR_MAX_ID_SETS];
-    long long first[RBR_MAX_ID_SETS + 1];     // prefix of n: element k of the launch belongs to the set with first[s] <= k < first[s+1]
-    int count;
-};
-
 __global__ __launch_bounds__(256) void sanitize_ids_kernel(const IdSets S, long long* __restrict__ err) {
     const long long total = S.first[S.count];
-    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
-        int s = 0;
-#pragma unroll
-        for (int q = 1; q < RBR_MAX_ID_SETS; ++q)
-            if (q < S.count && k >= S.first[q]) s = q;
-        const long long e = k - S.first[s];
-        long long v = S.in[s][e];
-        const bool bad = (unsigned long long)v >= (unsigned long long)S.limit[s];
-        if (bad) {
-            err[1] = v; err[2] = s;                       // any one offender (benign race)
-            atomicAdd(reinterpret_cast<unsigned long long*>(err), 1ull);
-            v = S.replace[s];
-        }
-        S.out[s][e] = v;
-    }
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) sanitize_id(S, k, err);
 }
 
-}  // namespace rbr
-
-extern "C" int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t* err, void* stream) {
-    using namespace rbr;
-    if (n_sets <= 0 || n_sets > RBR_MAX_ID_SETS || !sets || !err) { set_error("rbr_sanitize_ids: n_sets=%d", n_sets); return RBR_ERR_BAD_ARG; }
-    IdSets S{};
+int fill_id_sets(int n_sets, const rbr_id_set* sets, IdSets& S) {
+    if (n_sets <= 0 || n_sets > RBR_MAX_ID_SETS || !sets) { set_error("rbr_sanitize_ids: n_sets=%d", n_sets); return RBR_ERR_BAD_ARG; }
+    memset(&S, 0, sizeof(S));
     S.count = n_sets;
     long long total = 0;
     for (int s = 0; s < n_sets; ++s) {
@@ -392,6 +367,17 @@ extern "C" int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t*
         total += sets[s].n;
     }
     S.first[n_sets] = total;
+    return 0;
+}
+
+}  // namespace rbr
+
+extern "C" int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t* err, void* stream) {
+    using namespace rbr;
+    if (!err) { set_error("rbr_sanitize_ids: null err"); return RBR_ERR_BAD_ARG; }
+    IdSets S;
+    if (int e = fill_id_sets(n_sets, sets, S)) return e;
+    const long long total = S.first[n_sets];
     if (total == 0) return 0;
     hipLaunchKernelGGL(sanitize_ids_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0,
                        (hipStream_t)stream, S, reinterpret_cast<long long*>(err));

@@ -37,26 +37,29 @@ __device__ __forceinline__ void head_rng_ticket(const HeadTrain& tr, unsigned lo
     (void)call;
 }
 
+// MSE of the trainers folded into the head's training launch (rbr_pair_head_fwd_pool): the pair block that arrives LAST at
+// the ticket sees every prediction and computes nn.MSELoss(mean) and d loss / d pred exactly as mse_fwd_kernel does (same
+// thread -> element mapping, same reduction order: the same bits), then re-arms the ticket.
+struct HeadMse {
+    const float* target;       // [B] or NULL: no loss in this launch
+    float* loss;               // [1]
+    float* d_unit;             // [B] d loss / d pred for an upstream gradient of 1 (may be NULL)
+    int* ticket;               // zero between launches
+};
+
 // one workgroup per pair: threads [0,128) run the user tower, [128,256) the item tower; inside a tower 4 thread groups
 // split the H-long dots by h mod 4 and 32 lanes cover k (looped for K > 32).  A thread's loads are issued 8 at a time.
-__global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
-                                                       const float* __restrict__ itf, const long long* __restrict__ uid,
-                                                       const long long* __restrict__ iid, const rbr_head_params p,
-                                                       const float* __restrict__ drop, float* __restrict__ ul,
-                                                       float* __restrict__ il, float* __restrict__ pred,
-                                                       const HeadTrain tr) {
-    __shared__ float s_part[2][4][32];
-    __shared__ float s_l[2][32];
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (b >= B) {                 // training launch only: blocks past the pairs clear the buffer the backward accumulates into
-        for (long k = (long)(b - B) * 256 + t; k < tr.zero_n; k += (long)(gridDim.x - B) * 256) tr.zero_buf[k] = 0.f;
-        if (t == 0) head_rng_ticket(tr, 0);
-        return;
-    }
+// ft0 / ft1: this pair's user / item feature vectors (global memory, or the LDS copy the fused pool epilogue leaves).
+__device__ __forceinline__ void head_pair(int b, int B, int H, int K, const float* ft0, const float* ft1,
+                                          const long long* __restrict__ uid, const long long* __restrict__ iid,
+                                          const rbr_head_params& p, const float* __restrict__ drop, float* __restrict__ ul,
+                                          float* __restrict__ il, float* __restrict__ pred, const HeadTrain& tr,
+                                          float (*s_part)[4][32], float (*s_l)[32]) {
+    const int t = threadIdx.x;
     const unsigned long long call = (tr.p_drop > 0.f) ? tr.rng_state[0] : 0;
     const int side = t >> 7, hp = (t >> 5) & 3, kk = t & 31;
     const long id = side ? iid[b] : uid[b];
-    const float* ft = (side ? itf : uf) + (long)b * H;
+    const float* ft = side ? ft1 : ft0;
     const float* W = side ? p.Wi : p.Wu;
     const float* bias = side ? p.bi : p.bu;
     const float* E = side ? p.Ei : p.Eu;
@@ -105,6 +108,118 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, cons
         if (t == 0) pred[b] = part + p.ub[uid[b]] + p.ib[iid[b]] + p.g[0];
     }
     if (t == 0 && tr.rng_state != nullptr) head_rng_ticket(tr, call);
+    (void)B;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(int B, int H, int K, const float* __restrict__ uf,
+                                                       const float* __restrict__ itf, const long long* __restrict__ uid,
+                                                       const long long* __restrict__ iid, const rbr_head_params p,
+                                                       const float* __restrict__ drop, float* __restrict__ ul,
+                                                       float* __restrict__ il, float* __restrict__ pred,
+                                                       const HeadTrain tr) {
+    __shared__ float s_part[2][4][32];
+    __shared__ float s_l[2][32];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= B) {                 // training launch only: blocks past the pairs clear the buffer the backward accumulates into
+        for (long k = (long)(b - B) * 256 + t; k < tr.zero_n; k += (long)(gridDim.x - B) * 256) tr.zero_buf[k] = 0.f;
+        if (t == 0) head_rng_ticket(tr, 0);
+        return;
+    }
+    head_pair(b, B, H, K, uf + (long)b * H, itf + (long)b * H, uid, iid, p, drop, ul, il, pred, tr, s_part, s_l);
+}
+
+// The head forward with the encoder's pool epilogue in front and the trainer's loss behind (one launch instead of
+// pool_finalize + head_fwd + mse_fwd): block b first reduces the slab partials of ITS two documents (rows b and B + b of the
+// stacked encoder batch) exactly as pool_finalize_kernel does -- slabs in position order, first maximum wins, bias,
+// activation -- writes feat / argmax for the backward and keeps the two feature vectors in LDS for the head.
+struct HeadPool {
+    const float* pval;
+    const int* pidx;
+    PtrArray bias;
+    float* feat;               // [2B, C]
+    int* argmax;               // [2B, C]
+};
+
+__global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, const HeadPool hp, int B, int K,
+                                                            const long long* __restrict__ uid, const long long* __restrict__ iid,
+                                                            const rbr_head_params p, const float* __restrict__ drop,
+                                                            float* __restrict__ ul, float* __restrict__ il, float* __restrict__ pred,
+                                                            const HeadTrain tr, const HeadMse mse) {
+    __shared__ float s_part[2][4][32];
+    __shared__ float s_l[2][32];
+    __shared__ int s_last;
+    extern __shared__ __attribute__((aligned(16))) float s_feat[];      // [2][C]
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (b >= B) {
+        for (long k = (long)(b - B) * 256 + t; k < tr.zero_n; k += (long)(gridDim.x - B) * 256) tr.zero_buf[k] = 0.f;
+        if (t == 0) head_rng_ticket(tr, 0);
+        return;
+    }
+    const int* flags = hp.pidx + (long)P.total_wt * P.nslots_total;
+    const int nslots = P.ntiles * kTile;
+    for (int idx = t; idx < 2 * nslots; idx += 256) {
+        const int side = idx >= nslots, ls = side ? idx - nslots : idx;
+        const int doc = side * B + b;
+        const int chan = P.slot_chan[ls];
+        if (chan < 0) continue;
+        const long base = (long)doc * P.wpd * P.nslots_total + (long)P.tile_base * kTile + ls;
+        float best = -__builtin_huge_valf();
+        int bw_tile = -1;
+        const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
+        for (int w0 = 0; w0 < P.wpd; w0 += 8) {
+            int fl[8];
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) fl[q] = (w0 + q < P.wpd) ? flags[doc * P.wpd + w0 + q] : 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fl[q] ? hp.pval[base + (long)(w0 + q) * P.nslots_total] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int w = w0 + q;
+                if (w >= P.wpd) break;
+                if (fl[q]) {
+                    if (v[q] > best) { best = v[q]; bw_tile = w; }
+                } else if (w * kTile < Lv && 0.f > best) {
+                    best = 0.f;
+                    bw_tile = -2 - w;
+                }
+            }
+        }
+        int bidx = 0;
+        if (bw_tile >= 0) bidx = hp.pidx[base + (long)bw_tile * P.nslots_total];
+        else if (bw_tile <= -2) bidx = (-2 - bw_tile) * kTile;
+        const int bw = P.slot_w[ls];
+        const float y = best + hp.bias.p[bw][chan - P.ch_off[bw]];
+        const float f = (P.act == RBR_ACT_RELU) ? fmaxf(y, 0.f) : tanhf(y);
+        hp.feat[(long)doc * P.C + chan] = f;
+        hp.argmax[(long)doc * P.C + chan] = bidx;
+        s_feat[side * P.C + chan] = f;
+    }
+    __syncthreads();
+    head_pair(b, B, P.C, K, s_feat, s_feat + P.C, uid, iid, p, drop, ul, il, pred, tr, s_part, s_l);
+    if (mse.target == nullptr) return;
+    if (t == 0) {
+        __threadfence();                                        // pred[b] is visible before the ticket is taken
+        s_last = atomicAdd(mse.ticket, 1) == B - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;                                        // workgroup-uniform
+    __threadfence();
+    float acc = 0.f;
+    for (int i = t; i < B; i += 256) {                          // as mse_fwd_kernel; the other blocks' preds via agent-scope loads
+        const float d = __hip_atomic_load(pred + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mse.target[i];
+        acc += d * d;
+        if (mse.d_unit != nullptr) mse.d_unit[i] = d * (2.f / (float)B);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __syncthreads();
+    if ((t & 63) == 0) s_l[0][t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+        *mse.loss = (s_l[0][0] + s_l[0][1] + s_l[0][2] + s_l[0][3]) / (float)B;
+        *mse.ticket = 0;
+    }
 }
 
 // The backward in ONE launch.  Blocks [0, B): one workgroup per pair -- embedding-row grads (atomics), then d_feat with all
@@ -313,6 +428,41 @@ extern "C" int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const fl
                        reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p,
                        static_cast<const float*>(nullptr), ul, il, pred, tr);
     RBR_CHECK_LAUNCH("pair_head_fwd_train launch");
+    return 0;
+}
+
+// Head forward with the encoder's pool epilogue (rbr_textcnn_pool_finalize) in front and, optionally, the trainers' MSELoss
+// behind: one launch.  The encoder batch holds the B user documents, then the B item documents.
+extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx, const float* const* bias,
+                                      float* feat, int32_t* argmax, int32_t K, const int64_t* u_id, const int64_t* i_id,
+                                      const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed, uint64_t* rng_state,
+                                      float* drop_out, float* zero_buf, int64_t zero_n, float* ul, float* il, float* pred,
+                                      const float* target, float* loss, float* d_pred_unit, int32_t* ticket, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    const int ng = build_plans(d, plans, kMaxTiles);
+    if (!ng) return RBR_ERR_BAD_ARG;
+    if (ng != 1) { set_error("pair_head_fwd_pool: %d channel groups (one launch covers %d slots)", ng, kMaxSlots); return RBR_ERR_UNSUPPORTED; }
+    if (d->n_docs % 2) { set_error("pair_head_fwd_pool: odd document count %d", d->n_docs); return RBR_ERR_BAD_ARG; }
+    const int B = d->n_docs / 2, C = plans[0].C;
+    if (!head_args_ok(B, C, K)) return RBR_ERR_BAD_ARG;
+    if (!pval || !pidx || !bias || !feat || !argmax || !u_id || !i_id || !p || !ul || !il || !pred) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if (!(p_drop >= 0.f && p_drop < 1.f)) { set_error("pair_head_fwd_pool: p_drop=%f outside [0,1)", (double)p_drop); return RBR_ERR_BAD_ARG; }
+    if (p_drop > 0.f && (!rng_state || !drop_out)) { set_error("pair_head_fwd_pool: dropout needs rng_state and drop_out"); return RBR_ERR_BAD_ARG; }
+    if (zero_n < 0 || (zero_n > 0 && !zero_buf)) { set_error("pair_head_fwd_pool: bad zero buffer"); return RBR_ERR_BAD_ARG; }
+    if (target != nullptr && (!loss || !ticket)) { set_error("pair_head_fwd_pool: the loss needs loss and ticket"); return RBR_ERR_BAD_ARG; }
+    HeadTrain tr{};
+    tr.p_drop = p_drop; tr.seed = seed;
+    tr.rng_state = (p_drop > 0.f) ? reinterpret_cast<unsigned long long*>(rng_state) : nullptr;
+    tr.drop_out = drop_out; tr.zero_buf = zero_buf; tr.zero_n = zero_n;
+    HeadPool hp{};
+    hp.pval = pval; hp.pidx = pidx; hp.feat = feat; hp.argmax = argmax;
+    for (int w = 0; w < d->n_widths; ++w) hp.bias.p[w] = bias[w];
+    HeadMse mse{target, loss, d_pred_unit, ticket};
+    const int zblocks = zero_n > 0 ? (int)std::min<long>((zero_n + 1023) / 1024, 256) : 0;
+    hipLaunchKernelGGL(head_fwd_pool_kernel, dim3(B + zblocks), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
+                       plans[0], hp, B, K, reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p,
+                       (p_drop > 0.f) ? nullptr : drop, ul, il, pred, tr, mse);
+    RBR_CHECK_LAUNCH("pair_head_fwd_pool launch");
     return 0;
 }
 

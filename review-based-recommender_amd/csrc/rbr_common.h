@@ -102,6 +102,33 @@ inline int zero_words(void* p, size_t bytes, hipStream_t st) {
     return zero_regions(r, st);
 }
 
+// Id range check (dense_misc.hip: rbr_sanitize_ids; textcnn_prod.hip: the same job inside the prepare stage's first launch).
+struct IdSets {
+    const long long* in[RBR_MAX_ID_SETS];
+    long long* out[RBR_MAX_ID_SETS];
+    long long n[RBR_MAX_ID_SETS], limit[RBR_MAX_ID_SETS], replace[RBR_MAX_ID_SETS];
+    long long first[RBR_MAX_ID_SETS + 1];     // prefix of n: element k of the launch belongs to the set with first[s] <= k < first[s+1]
+    int count;
+};
+// host: rbr_id_set[] -> IdSets (validated); returns 0 or RBR_ERR_BAD_ARG
+int fill_id_sets(int n_sets, const rbr_id_set* sets, IdSets& S);
+// element k of the launch: out = in where 0 <= in < limit, else `replace` + a record in err (err[0] count, err[1] value, err[2] set)
+__device__ __forceinline__ void sanitize_id(const IdSets& S, long long k, long long* __restrict__ err) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < RBR_MAX_ID_SETS; ++q)
+        if (q < S.count && k >= S.first[q]) s = q;
+    const long long e = k - S.first[s];
+    long long v = S.in[s][e];
+    const bool bad = (unsigned long long)v >= (unsigned long long)S.limit[s];
+    if (bad) {
+        err[1] = v; err[2] = s;                       // any one offender (benign race)
+        atomicAdd(reinterpret_cast<unsigned long long*>(err), 1ull);
+        v = S.replace[s];
+    }
+    S.out[s][e] = v;
+}
+
 // Work-list scan of 256 wave-tiles (block `blk` of the scan grid): flags[wt], and the active tiles appended to the
 // list in any order.  sched = flags[total_wt] | list[total_wt] | counters; the counters must be zero beforehand.
 __device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigned char* __restrict__ mask,

@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
         }
         __syncthreads();
         // ---- one wave per token: register accumulation, then one row of atomics -------------------
+#ifdef RBR_DIAG
         if (A.dev_flags & 2) continue;
+#endif
         if (vec4) {
             // lanes own float4 columns (D/4 of them, kMaxQ4 per lane); 4 items are loaded together
             const int nq4 = D >> 2, qpc = DC >> 2;
@@ -557,8 +559,16 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
                             }
                         }
                     }
+#ifdef RBR_DIAG
                     if (A.dev_flags & 1) { if (sum[0].x == 1.2345f) dtable[0] = sum[1].y; }
-                    if (to_table && !(A.dev_flags & 1)) {
+    #ifdef RBR_DIAG
+                if (to_table && !(A.dev_flags & 1)) {
+#else
+                if (to_table) {
+#endif
+#else
+                    if (to_table) {
+#endif
                         // transpose through the wave's LDS strip so each atomic wave-instruction covers 256
                         // contiguous bytes of the table row
                         float* strip = s_strip + wave * (64 * kMaxQ4 * 4);
@@ -611,7 +621,11 @@ __global__ __launch_bounds__(256) void dx_window_kernel(const BwdArgs A, const i
                         if (lane == 0) atomicAdd(dgate + tok, dot);
                     }
                 }
+#ifdef RBR_DIAG
                 if (to_table && !(A.dev_flags & 1)) {
+#else
+                if (to_table) {
+#endif
 #pragma unroll
                     for (int u = 0; u < kMaxDI; ++u)
                         if (doff[u] >= 0) atomicAdd(dtable + trow + dblk + lane + 64 * u, sum[u]);
@@ -645,8 +659,12 @@ static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
     }
     A.DPC = (d->n_docs + A.NCH - 1) / A.NCH;
     A.NCH = (d->n_docs + A.DPC - 1) / A.DPC;
+#ifdef RBR_DIAG      // diagnostic build only (RBR_DIAG=1 python build.py): the product library has no wrong-result switches
     static const int flags = getenv("RBR_DEV_DX_ABLATE") ? atoi(getenv("RBR_DEV_DX_ABLATE")) : 0;
     A.dev_flags = flags;
+#else
+    A.dev_flags = 0;
+#endif
     return 0;
 }
 
@@ -710,7 +728,11 @@ extern "C" int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* 
     if (int e = fill_args(d, A)) return e;
     if (!ids || !table || !packed || !feat || !argmax || !d_feat) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     if (dtable == nullptr && !(dgate != nullptr && gate != nullptr)) return 0;
+#ifdef RBR_DIAG
     static const int win_env = getenv("RBR_DEV_DX_WIN") ? atoi(getenv("RBR_DEV_DX_WIN")) : 0;   // tuning aid
+#else
+    constexpr int win_env = 0;
+#endif
     int kWin = win_env > 0 ? std::min(win_env, kWinMax) : 256;
     kWin = std::min(kWin, ((A.L + 63) / 64) * 64);
     const int nwin = (A.L + kWin - 1) / kWin;

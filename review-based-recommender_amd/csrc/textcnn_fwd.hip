@@ -709,7 +709,11 @@ template <int NT, int DC, bool VEC>
 static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigned char* mask, const float* gate,
                           const float* table, const float* packed, float* pval, int* pidx, const int* sched, hipStream_t st) {
     const int XR = kTile + p.KF - 1;
+#ifdef RBR_DIAG
     static const size_t extra_lds = getenv("RBR_DEV_CONV_EXTRA_LDS") ? (size_t)atol(getenv("RBR_DEV_CONV_EXTRA_LDS")) : 0;  // tuning aid
+#else
+    constexpr size_t extra_lds = 0;
+#endif
     const size_t smem = (size_t)(4 * kTile * DC + kWavesPerWG * XR * DC) * sizeof(float) +
                         (size_t)kWavesPerWG * (kTile + kMaxKF) * sizeof(long) + 16 + extra_lds;
     static int occ[2] = {0, 0};   // per instantiation; resident workgroups per CU for this LDS/VGPR footprint
@@ -725,7 +729,11 @@ static int launch_conv_nt(const ConvPlan& p, const long long* ids, const unsigne
     const dim3 grid(std::min(nitems, num_cus() * occ[sm])), block(256);
     if (p.store_rows) {
         if (gate != nullptr) { set_error("store mode takes no gate"); return RBR_ERR_UNSUPPORTED; }
+#ifdef RBR_DIAG
         static const bool generic_only = getenv("RBR_DEV_GENERIC_GEMM") != nullptr;      // tuning aid
+#else
+        constexpr bool generic_only = false;
+#endif
         if constexpr (NT == 8 && VEC && DC >= 36 && (DC / 4) % 2 == 1) if (p.KF == 1 && p.n_docs == 1 && !generic_only) {
             const size_t smem2 = (size_t)(4 * kTile * DC + kWavesPerWG * kTile * DC) * sizeof(float) +
                                  (size_t)kWavesPerWG * kTile * sizeof(long) + 16;

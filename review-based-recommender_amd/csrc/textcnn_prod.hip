@@ -54,6 +54,22 @@ __global__ __launch_bounds__(256) void mark_scan_kernel(const ConvPlan P, int nb
         if (mask == nullptr || mask[k]) used[ids[k]] = 1;      // benign race: everyone stores 1 (one byte per token id)
 }
 
+// Launch 1 of the prepare stage when the caller's raw id tensors come along (rbr_textcnn_prod_prepare_ids): the id range check of
+// rbr_sanitize_ids and the zero-fill of the list state, two independent jobs that were two launches.
+__global__ __launch_bounds__(256) void prep_kernel(const IdSets S, long long* __restrict__ err, const ZeroRegions R, int nb_ids) {
+    if ((int)blockIdx.x < nb_ids) {
+        const long long total = S.first[S.count];
+        for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)nb_ids * 256) sanitize_id(S, k, err);
+        return;
+    }
+    const long nz = R.n[0] + R.n[1] + R.n[2], nb = gridDim.x - nb_ids;
+    for (long k = (long)(blockIdx.x - nb_ids) * 256 + threadIdx.x; k < nz; k += nb * 256) {
+        if (k < R.n[0]) R.p[0][k] = 0;
+        else if (k < R.n[0] + R.n[1]) R.p[1][k - R.n[0]] = 0;
+        else R.p[2][k - R.n[0] - R.n[1]] = 0;
+    }
+}
+
 struct PackJob {        // weight images of the product formulation, both derived from the torch-layout conv weights
     ConvPlan P;         // plan of the token pseudo-document (one kz = 1 bank of Cp channels): forward image [dc][tile][slot][dd]
     int n_widths, D, cp_real;
@@ -149,16 +165,24 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // segments start at any float
 
+// The first `nb_zero` workgroups of the launch (training forwards) clear the rows of the backward's G instead: the gather is
+// bound by L2 requests and leaves HBM idle, so the 64 MB of zeroes ride along (they were a launch of their own, zero_g_rows).
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
                                                           const int* __restrict__ row_of_token, const float* __restrict__ T,
                                                           const int* __restrict__ sched, float* __restrict__ pval,
-                                                          int* __restrict__ pidx) {
+                                                          int* __restrict__ pidx, int nb_zero, const int* __restrict__ counter,
+                                                          int KG4, f32x4* __restrict__ Gz) {
     __shared__ int s_row[kWavesPerWG][kTile + kMaxKF];
     __shared__ float s_gate[kWavesPerWG][kTile + kMaxKF];
+    if ((int)blockIdx.x < nb_zero) {
+        const long n = (long)min(*counter, A.cap) * KG4;
+        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)nb_zero * 256) Gz[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_active = sched[2 * (long)P.total_wt];
-    const int slot_in_list = blockIdx.x * kWavesPerWG + wave;
+    const int slot_in_list = ((int)blockIdx.x - nb_zero) * kWavesPerWG + wave;
     if (slot_in_list >= n_active) return;                       // wave-uniform; no block barrier below
     const int wt = sched[P.total_wt + slot_in_list];
     const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
@@ -302,15 +326,23 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // columns, the four partial rows meet in LDS.  A Zipf-hot token ("the": every one of the sum(kz*ch) columns is
 // non-zero) would otherwise keep a single wave busy longer than the rest of the kernel takes.
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
-template <bool ACC>
+enum { kGtwDense = 0, kGtwAccumulate = 1, kGtwRows = 2 };
+constexpr int kGtwMaxBlocks = 8192;      // workgroups of g_times_w = entries of its sq_part
+template <int MODE>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
-                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable) {
-    // ACC: dtable is a gradient buffer shared with other producers on this stream (functional.table_fanout) -- the rows of the
-    // batch's tokens are ADDED to it, nothing else is touched (no zero rows, the pad row is skipped).  A template parameter: as
-    // a run-time flag it cost the plain form 12 registers and one wave per SIMD (63 -> 71 us at cfg2).
-    constexpr bool accumulate = ACC;
+                                                        const int* __restrict__ row_of_token, int V, float* __restrict__ dtable,
+                                                        float* __restrict__ sq_part) {
+    // kGtwAccumulate: dtable is a gradient buffer shared with other producers on this stream (functional.table_fanout) -- the
+    // rows of the batch's tokens are ADDED to it, nothing else is touched (no zero rows, the pad row is skipped).  A template
+    // parameter: as a run-time flag it cost the plain form 12 registers and one wave per SIMD (63 -> 71 us at cfg2).
+    // kGtwRows: the gradient in COMPACT form -- row r of `dtable` is the gradient of token tok_of_row[r] (the rows of absent
+    // tokens are not written anywhere: rbr_clip_adam_step_rows takes them as zero), and sq_part[workgroup] = the sum of squares
+    // of the rows this workgroup wrote (static row -> workgroup -> thread mapping: the same bits on every run).
+    constexpr bool accumulate = MODE == kGtwAccumulate;
+    constexpr bool compact = MODE == kGtwRows;
+    float sq = 0.f;
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* s_pc = s_dyn + wave * 2 * KGW;
@@ -322,14 +354,14 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
     const int kbeg = wave * KGW, kend = min(A.KG, kbeg + KGW);      // this wave's columns (KGW % 4 == 0)
     for (int row = blockIdx.x; row < n; row += gridDim.x) {
         if (tok_of_row[row] == A.padding_idx) {             // nn.Embedding(padding_idx): that row gets no gradient
-            float* dst = dtable + (long)A.padding_idx * D;
+            float* dst = dtable + (long)(compact ? row : A.padding_idx) * D;
             if (!accumulate)
                 for (int q4 = threadIdx.x; q4 < nq4; q4 += 256) *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{0.f, 0.f, 0.f, 0.f};
             continue;                                        // workgroup-uniform
         }
         // accumulate mode: what the shared buffer holds for this row is requested now and added at the end (a read in front
         // of the store would put one more memory latency on every row)
-        const long trow = (long)tok_of_row[row] * D;
+        const long trow = compact ? (long)row * D : (long)tok_of_row[row] * D;
         f32x4 old = {0.f, 0.f, 0.f, 0.f};
         if (accumulate && (int)threadIdx.x < nq4) old = *reinterpret_cast<const f32x4*>(dtable + trow + 4 * threadIdx.x);
         // 1. non-zeros of this wave's quarter of the row -> (weight-row offset, value) list
@@ -390,9 +422,19 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
 #pragma unroll
             for (int w = 1; w < kWavesPerWG; ++w) r += *reinterpret_cast<const f32x4*>(s_part + w * D + 4 * q4);
             if (accumulate) r += (q4 == (int)threadIdx.x) ? old : *reinterpret_cast<const f32x4*>(dtable + trow + 4 * q4);   // D > 1024: later quads read late
+            if (compact) sq += (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w);
             *reinterpret_cast<f32x4*>(dtable + trow + 4 * q4) = r;
         }
         __syncthreads();      // lists and partial rows are rewritten for the next row
+    }
+    if (compact) {            // every workgroup writes its partial (zero when it had no rows): fixed-order reduction later
+        __shared__ float s_sq[kWavesPerWG];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (lane == 0) s_sq[wave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) sq_part[blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
+        return;
     }
     // rows of tokens the batch does not contain: zero (the caller need not pre-fill dtable); one wave per row
     if (row_of_token != nullptr && !accumulate) {
@@ -945,10 +987,12 @@ extern "C" size_t rbr_textcnn_bwd_prod_ws_bytes(const rbr_textcnn_desc* d) {
     return B.total;
 }
 
-enum { kGBuild = 1, kGProduct = 2, kGAccumulate = 4 };     // phases of dtable_through_list (+ dtable is added to, not overwritten)
+// phases of dtable_through_list: build G | multiply it out | ... adding to dtable instead of overwriting it | ... into compact
+// rows + sq_part (kGtwRows) | G's rows are already zero (the forward's gather_pool launch cleared them: no zero_g_rows launch)
+enum { kGBuild = 1, kGProduct = 2, kGAccumulate = 4, kGRows = 8, kGZeroed = 16 };
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                               float* dtable, float* dgate, hipStream_t st, int phases = kGBuild | kGProduct);
+                               float* dtable, float* dgate, hipStream_t st, int phases = kGBuild | kGProduct, float* sq_part = nullptr);
 
 extern "C" int rbr_textcnn_bwd_dtable_prod(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                            const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws,
@@ -999,11 +1043,50 @@ extern "C" int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws
                                (hipStream_t)stream, kGProduct);
 }
 
+// Every form of the token-product table gradient behind one entry (the calls above are its fixed-flag forms):
+//   RBR_G_BUILD | RBR_G_PRODUCT   the phases to run;
+//   RBR_G_ACCUMULATE              the rows are added to the dense `dtable`;
+//   RBR_G_ROWS                    `dtable` is the COMPACT gradient [list rows, D] (row r = token tok_of_row[r]; absent tokens have
+//                                 no row) and sq_part[rbr_textcnn_row_grad_partials()] receives per-workgroup sums of squares;
+//   RBR_G_ZEROED                  G's rows are zero already (rbr_textcnn_prod_pool_zero cleared them in the forward).
+extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                              const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
+                                              float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream) {
+    ConvPlan plans[kMaxGroups];
+    if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
+    if (dgate != nullptr && gate == nullptr) dgate = nullptr;
+    if (!fwd_ws || !bwd_ws) { set_error("null workspace"); return RBR_ERR_BAD_ARG; }
+    if ((flags & RBR_G_BUILD) && (!ids || !feat || !argmax || !d_feat)) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    if ((flags & RBR_G_PRODUCT) && !dtable) { set_error("null dtable"); return RBR_ERR_BAD_ARG; }
+    if ((flags & RBR_G_ROWS) && ((flags & RBR_G_ACCUMULATE) || !sq_part)) { set_error("RBR_G_ROWS needs sq_part and excludes RBR_G_ACCUMULATE"); return RBR_ERR_BAD_ARG; }
+    if (!prod_applicable(d)) { set_error("token-product path does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    static_assert(RBR_G_BUILD == kGBuild && RBR_G_PRODUCT == kGProduct && RBR_G_ACCUMULATE == kGAccumulate && RBR_G_ROWS == kGRows &&
+                  RBR_G_ZEROED == kGZeroed, "public flags = internal phases");
+    return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream,
+                               flags & (kGBuild | kGProduct | kGAccumulate | kGRows | kGZeroed), sq_part);
+}
+
+extern "C" size_t rbr_textcnn_row_grad_partials(void) { return kGtwMaxBlocks; }
+
+// Where the forward left the token list inside `fwd_ws` (the layout is private): row_of_token [V] (dense row or -1), the
+// device count of listed rows, tok_of_row [cap]; cap = rows the compact gradient must have room for.
+extern "C" int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, const int32_t** row_of_token, const int32_t** n_rows,
+                                      const int64_t** tok_of_row, int32_t* cap) {
+    ProdLayout Lo;
+    if (!fwd_ws || !prod_applicable(d) || !prod_layout(d, Lo)) { set_error("no token list for this shape"); return RBR_ERR_UNSUPPORTED; }
+    char* base = static_cast<char*>(fwd_ws);
+    if (row_of_token) *row_of_token = reinterpret_cast<const int32_t*>(base + Lo.row_of_token);
+    if (n_rows) *n_rows = reinterpret_cast<const int32_t*>(base + Lo.counter);
+    if (tok_of_row) *tok_of_row = reinterpret_cast<const int64_t*>(base + Lo.tok_of_row);
+    if (cap) *cap = Lo.cap;
+    return 0;
+}
+
 // G over the token list in `fwd_ws` (ProdLayout), then dtable = G @ Wprod^T; shared by the token-product backward (the
 // forward's list) and by the dense formulation's backward (a list built for the purpose, rbr_textcnn_bwd_dtable_list)
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
-                               float* dtable, float* dgate, hipStream_t st, int phases) {
+                               float* dtable, float* dgate, hipStream_t st, int phases, float* sq_part) {
     ProdLayout Lo;
     ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
@@ -1031,9 +1114,10 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     // kGBuild alone (rbr_textcnn_bwd_g_build) always builds G: its caller multiplies it out later (rbr_textcnn_bwd_g_product)
     const bool want_g = dtable != nullptr || !(phases & kGProduct);
     if (phases & kGBuild) {
-        if (want_g || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
+        if ((want_g && !(phases & kGZeroed)) || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
             hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4,
-                               want_g ? reinterpret_cast<f32x4*>(G) : nullptr, dgate, dgate != nullptr ? (long)d->n_docs * d->L : 0L);
+                               (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate,
+                               dgate != nullptr ? (long)d->n_docs * d->L : 0L);
             RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;
@@ -1044,12 +1128,18 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     }
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    if (phases & kGAccumulate)
-        hipLaunchKernelGGL(g_times_w_kernel<true>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                           tok_of_row, row_of_token, d->V, dtable);
-    else
-        hipLaunchKernelGGL(g_times_w_kernel<false>, dim3((unsigned)std::min(Lo.cap, 8192)), dim3(256), lds, st, A, B.KGW, counter, G, WT,
-                           tok_of_row, row_of_token, d->V, dtable);
+    const dim3 grid((unsigned)std::min(Lo.cap, kGtwMaxBlocks));
+    if (phases & kGRows) {
+        if (sq_part == nullptr) { set_error("compact row gradient needs sq_part"); return RBR_ERR_BAD_ARG; }
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwRows>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V,
+                           dtable, sq_part);
+    } else if (phases & kGAccumulate) {
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwAccumulate>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
+                           d->V, dtable, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwDense>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
+                           d->V, dtable, (float*)nullptr);
+    }
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
@@ -1104,8 +1194,8 @@ int prod_state(const rbr_textcnn_desc* d, void* ws, ProdState& S) {
 
 // Stage 1: work list of the real documents (tail of `pidx`), distinct-token list of the batch, product weight
 // images.  Three launches: zero the state | mark + scan | compact + pack.
-extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
-                                        const float* const* W, int32_t* pidx, void* ws, void* stream) {
+static int prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* const* W, int32_t* pidx,
+                        void* ws, void* stream, const IdSets* id_sets, int64_t* err) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
     if (!ids || !W || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
@@ -1117,7 +1207,16 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
     ZeroRegions zr{{reinterpret_cast<int*>(S.base + S.Lo.used), S.sched_p + 2 * (size_t)S.pp[0].total_wt,
                     sched + 2 * (size_t)plans[0].total_wt},
                    {(long)((S.Lo.row_of_token - S.Lo.used) / sizeof(int)), kSchedCounters, kSchedCounters}};
-    if (int e = zero_regions(zr, st)) return e;
+    if (id_sets != nullptr) {
+        const long long total = id_sets->first[id_sets->count];
+        const int nb_ids = (int)std::min<long long>((total + 255) / 256, 2048);
+        const long nz = zr.n[0] + zr.n[1] + zr.n[2];
+        const int nb_zero = (int)std::min<long>((nz + 255) / 256, 256);
+        hipLaunchKernelGGL(prep_kernel, dim3(nb_ids + nb_zero), dim3(256), 0, st, *id_sets, reinterpret_cast<long long*>(err), zr, nb_ids);
+        RBR_CHECK_LAUNCH("textcnn prep launch");
+    } else if (int e = zero_regions(zr, st)) {
+        return e;
+    }
     const long n_tok = (long)d->n_docs * d->L;
     const int nb_scan = (plans[0].total_wt + 255) / 256;
     const int nb_mark = (int)std::min<long>((n_tok + 255) / 256, 2048);
@@ -1142,6 +1241,27 @@ extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t
                        b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
     return 0;
+}
+
+extern "C" int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask,
+                                        const float* const* W, int32_t* pidx, void* ws, void* stream) {
+    return prod_prepare(d, ids, mask, W, pidx, ws, stream, nullptr, nullptr);
+}
+
+// rbr_textcnn_prod_prepare with the model's id range check (rbr_sanitize_ids) folded into its first launch: `sets` are the raw
+// id tensors of the forward and where their clean copies go; the conv's token ids are the clean copies of the first set(s):
+// `ids` must point at sets[0].out and hold d->n_docs * d->L ids (one set, or two adjacent ones = the stacked towers).
+extern "C" int rbr_textcnn_prod_prepare_ids(const rbr_textcnn_desc* d, int32_t n_sets, const rbr_id_set* sets, int64_t* err,
+                                            const int64_t* ids, const uint8_t* mask, const float* const* W, int32_t* pidx, void* ws,
+                                            void* stream) {
+    if (!err) { set_error("null err"); return RBR_ERR_BAD_ARG; }
+    IdSets S;
+    if (int e = fill_id_sets(n_sets, sets, S)) return e;
+    const long long n_tok = (long long)d->n_docs * d->L;
+    const bool one = sets[0].out == ids && sets[0].n == n_tok;
+    const bool two = n_sets >= 2 && sets[0].out == ids && sets[1].out == sets[0].out + sets[0].n && sets[0].n + sets[1].n == n_tok;
+    if (!one && !two) { set_error("prod_prepare_ids: `ids` is not the clean copy of the first id set(s)"); return RBR_ERR_BAD_ARG; }
+    return prod_prepare(d, ids, mask, W, pidx, ws, stream, &S, err);
 }
 
 // ---- dense formulation's table gradient through a token list built for the purpose (no product table T: un-gated convs)
@@ -1219,8 +1339,8 @@ extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* ta
 
 // Stage 3 (one kernel): per active wave-tile of the real documents (work list in the tail of `pidx`, built by stage 1),
 // add the kz rows of T per position, max / first argmax.
-extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                     float* pval, int32_t* pidx, void* ws, void* stream) {
+static int prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                     float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream) {
     ConvPlan plans[kMaxGroups];
     const int ngroups = build_plans(d, plans);
     if (!ngroups) return RBR_ERR_BAD_ARG;
@@ -1230,10 +1350,33 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     hipStream_t st = (hipStream_t)stream;
     const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
-                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
+    int nb_zero = 0, KG4 = 0;
+    f32x4* Gz = nullptr;
+    if (bwd_ws != nullptr) {
+        ProdBwdLayout B;
+        if (!prod_bwd_layout(d, S.Lo, B)) { set_error("token-product backward does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+        Gz = reinterpret_cast<f32x4*>(static_cast<char*>(bwd_ws) + B.G);
+        KG4 = B.KG / 4;
+        nb_zero = 512;
+    }
+    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items + nb_zero), dim3(256), 0, st, plans[0], S.A,
+                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx, nb_zero,
+                       S.counter, KG4, Gz);
     RBR_CHECK_LAUNCH("textcnn gather_pool launch");
     return 0;
+}
+
+extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                     float* pval, int32_t* pidx, void* ws, void* stream) {
+    return prod_pool(d, ids, mask, gate, pval, pidx, ws, nullptr, stream);
+}
+
+// rbr_textcnn_prod_pool whose launch also clears the rows of G in `bwd_ws` (rbr_textcnn_bwd_prod_ws_bytes(d) bytes, allocated by
+// the forward of a training step): the backward then passes RBR_G_ZEROED and has no zero_g_rows launch.
+extern "C" int rbr_textcnn_prod_pool_zero(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                          float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream) {
+    if (!bwd_ws) { set_error("null bwd_ws"); return RBR_ERR_BAD_ARG; }
+    return prod_pool(d, ids, mask, gate, pval, pidx, ws, bwd_ws, stream);
 }
 
 // ---- conv weight / bias gradient from G (see dw_from_g_kernel): after rbr_textcnn_bwd_dtable_prod built G in `bwd_ws`

@@ -169,6 +169,12 @@ class GradAllReduce:
         self.world = dist.get_world_size(group)
         self.comm_dtype = comm_dtype   # e.g. torch.bfloat16 halves the table bucket; None = exact fp32
         params = [p for p in model.parameters() if p.requires_grad]
+        if self.world > 1:
+            # the exchange reads every gradient as a dense .grad: an optimizer's compact row-gradient hand-off
+            # (train_step.HipClipAdam) is switched off for this model's tables
+            from . import functional as RF
+            for p in params:
+                RF.set_row_grad_sink(p, None)
         self.big: List[nn.Parameter] = [p for p in params if p.numel() >= BIG_BUCKET_ELEMS]
         self.small: List[nn.Parameter] = [p for p in params if p.numel() < BIG_BUCKET_ELEMS]
 

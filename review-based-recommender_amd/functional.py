@@ -286,8 +286,6 @@ class _TextCNN(torch.autograd.Function):
     def backward(ctx, d_feat, _d_argmax):
         saved = list(ctx.saved_tensors)
         table, ids, packed, feat, argmax = saved[:5]
-        if d_feat is None:
-            d_feat = torch.zeros_like(feat)
         k = 5
         mask8 = None
         gate = None
@@ -295,151 +293,223 @@ class _TextCNN(torch.autograd.Function):
             mask8 = saved[k]; k += 1
         if ctx.has_gate:
             gate = saved[k]; k += 1
-        ws = saved[k:]
-        desc = ctx.desc
-        L_ = _lib.lib()
-        dev = table.device
-        need_table = ctx.needs_input_grad[0]
-        need_gate = ctx.has_gate and ctx.needs_input_grad[1]
-        d_feat = d_feat.contiguous()
-        dWs = [torch.empty_like(w) for w in ws]
-        dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
-        sink = _TAP_SINKS.get(table.data_ptr())          # only the sink installed for THIS table ever sees the call
-        use_taps = (sink is not None and need_table and gate is None and sink.accepts(table, desc, L_))
-        if use_taps:
-            need_table = False          # table.grad is produced by the exchange, after the all-gather of the taps
-        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if ctx.prod_ws is not None else 0
-        # dense forward (no token list of its own), un-gated: the table gradient still goes through a distinct-token list built
-        # here (16 us) instead of the window scatter's row of f32 atomics per (document, channel, tap)
-        list_bytes = (L_.rbr_textcnn_bwd_dtable_list_ws_bytes(C.byref(desc))
-                      if (need_table and not bws_bytes and gate is None) else 0)
-        # the token-list backwards overwrite the whole table gradient; the window scatter accumulates into zeros
-        dtable = (torch.empty_like(table) if (bws_bytes or list_bytes) else torch.zeros_like(table)) if need_table else None
-        # the token-product backward zeroes dgate in the launch that zeroes its G rows; the window scatter accumulates into zeros
-        dgate = (torch.empty_like(gate) if bws_bytes else torch.zeros_like(gate)) if need_gate else None
-        wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
-        wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
-        st = current_stream()
-        common = (C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(gate, F32, "gate"),
-                  dev_ptr(table, F32, "table"))
-        # many short documents (NARRE's reviews): dW = G^T @ table[distinct tokens] on the MFMA pipe, from the G the
-        # table-gradient call builds anyway (0 floats of workspace = not this shape: the window-row kernels below)
-        dwg_floats = L_.rbr_textcnn_bwd_dw_from_g_ws_floats(C.byref(desc)) if (need_table and bws_bytes) else 0
-        join = None
-        fork = None
-        side = None
-        if not dwg_floats:
-            # the weight-gradient kernels and the table-gradient kernels below both start from d_feat and share nothing
-            # else: the former go to a second stream (fork here, join before returning), so the two chains overlap --
-            # also inside a captured graph, where the fork becomes two parallel branches
-            side = _side_stream(dev) if (need_table or need_gate or use_taps) else None
-            if side is not None:
-                fork = torch.cuda.Event()
-                fork.record()
+        S = _ConvSaved(table=table, ids=ids, packed=packed, feat=feat, argmax=argmax, mask8=mask8, gate=gate, ws=list(saved[k:]),
+                       desc=ctx.desc, prod_ws=ctx.prod_ws, fanout_acc=ctx.fanout_acc, bws=None)
+        dtable, dgate, dWs, dbs = _textcnn_backward(S, d_feat, ctx.needs_input_grad[0], ctx.has_gate and ctx.needs_input_grad[1])
+        return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
 
-        def run_dw():
-            """The weight-gradient chain, enqueued AFTER the table-gradient chain: in a replayed graph the branch captured first
-            keeps the queue of the nodes before and after the fork, and the join of the other branch into that queue costs
-            ~10 us -- so the longer (table) branch goes first and the step's next kernel follows it without a gap."""
-            if dwg_floats:
-                return join
-            j = None
-            if side is not None:
-                side.wait_event(fork)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                ev_dw = TIMER.record("textcnn_bwd_dw")
-                check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                            dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
-                                            ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"), current_stream()),
-                      "rbr_textcnn_bwd_dw")
-                if ev_dw is not None:
-                    ev_dw.record()
-                if side is not None:
-                    j = torch.cuda.Event()
-                    j.record()
-            return j
 
-        ev = TIMER.record("textcnn_bwd_dtable")
-        if use_taps:
-            tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
-            check(L_.rbr_textcnn_bwd_taps(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                          dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                          dev_ptr(d_feat, F32, "d_feat"), dev_ptr(tok, I32, "tap tokens"),
-                                          dev_ptr(val, F32, "tap values"), st), "rbr_textcnn_bwd_taps")
-            sink.record(desc, list(ws))
-            if ev is not None:
-                ev.record()
-            _join(run_dw())
-            return (None, dgate, None, None, None, None, None, None, *dWs, *dbs)
-        if (need_table or need_gate) and bws_bytes:
-            # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
-            # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
-            bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
-            if dwg_floats:
-                # G first; then its two consumers side by side: dtable = G @ Wprod^T on this stream, dW = G^T @ table rows on the
-                # second one (fork after the build, join before returning; two parallel branches in a captured graph)
-                check(L_.rbr_textcnn_bwd_g_build(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                 dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
-                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                                                 ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dgate, F32, "dgate"), st),
-                      "rbr_textcnn_bwd_g_build")
-                dwg_ws = torch.empty(dwg_floats, dtype=F32, device=dev)
-                side = _side_stream(dev)
-                if side is not None:
-                    fork = torch.cuda.Event()
-                    fork.record()
-                    side.wait_event(fork)
-                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                    ev2 = TIMER.record("textcnn_bwd_dw")
-                    check(L_.rbr_textcnn_bwd_dw_from_g(C.byref(desc), dev_ptr(table, F32, "table"), dev_ptr(feat, F32, "feat"),
-                                                       dev_ptr(d_feat, F32, "d_feat"), ctx.prod_ws.data_ptr(), bws.data_ptr(),
-                                                       ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
-                                                       dev_ptr(dwg_ws, F32, "ws"), current_stream()), "rbr_textcnn_bwd_dw_from_g")
-                    if ev2 is not None:
-                        ev2.record()
-                    if side is not None:
-                        join = torch.cuda.Event()
-                        join.record()
-                if need_table:
-                    check(L_.rbr_textcnn_bwd_g_product(C.byref(desc), ctx.prod_ws.data_ptr(), bws.data_ptr(),
-                                                       dev_ptr(dtable, F32, "dtable"), st), "rbr_textcnn_bwd_g_product")
-                if ev is not None:
-                    ev.record()
-                _join(join)
-                return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-            acc = _table_acc(ctx.fanout_acc, dev) if need_table else None
-            if acc is not None:          # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
-                dtable = acc
-            fn = L_.rbr_textcnn_bwd_dtable_prod_acc if acc is not None else L_.rbr_textcnn_bwd_dtable_prod
-            check(fn(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                     dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
-                     dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                     ctx.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(dtable, F32, "dtable"),
-                     dev_ptr(dgate, F32, "dgate"), st), "rbr_textcnn_bwd_dtable_prod")
-            if ev is not None:
-                ev.record()
-            _join(run_dw())
-            return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-        if list_bytes:
-            lws = torch.empty(list_bytes, dtype=torch.uint8, device=dev)
-            check(L_.rbr_textcnn_bwd_dtable_list(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                 ptr_array(ws, F32, "conv weight"), dev_ptr(feat, F32, "feat"),
-                                                 dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"), lws.data_ptr(),
-                                                 dev_ptr(dtable, F32, "dtable"), st), "rbr_textcnn_bwd_dtable_list")
-            if ev is not None:
-                ev.record()
-            _join(run_dw())
-            return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
-        if packed is None:
-            packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
-        check(L_.rbr_textcnn_bwd_dtable(*common, dev_ptr(packed, F32, "packed"), dev_ptr(feat, F32, "feat"),
-                                        dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                                        dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st),
-              "rbr_textcnn_bwd_dtable")
+class _ConvSaved:
+    """What a conv forward leaves for its backward (a plain record: the fused encoder + head function shares the backward)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
+    """Backward of the fused encoder from d_feat [n_docs, C]: returns (dtable, dgate, dWs, dbs).  dtable is None when the table
+    gradient left through a side channel instead: the data-parallel tap sink, or -- compact row form -- the optimizer that
+    registered for it (set_row_grad_sink).  S.bws: the G workspace the forward allocated and cleared (or None)."""
+    table, ids, packed, feat, argmax, mask8, gate, ws, desc = (S.table, S.ids, S.packed, S.feat, S.argmax, S.mask8, S.gate,
+                                                               S.ws, S.desc)
+    if d_feat is None:
+        d_feat = torch.zeros_like(feat)
+    L_ = _lib.lib()
+    dev = table.device
+    d_feat = d_feat.contiguous()
+    dWs = [torch.empty_like(w) for w in ws]
+    dbs = [torch.empty(w.shape[0], dtype=F32, device=dev) for w in ws]
+    sink = _TAP_SINKS.get(table.data_ptr())          # only the sink installed for THIS table ever sees the call
+    use_taps = (sink is not None and need_table and gate is None and sink.accepts(table, desc, L_))
+    if use_taps:
+        need_table = False          # table.grad is produced by the exchange, after the all-gather of the taps
+    bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if S.prod_ws is not None else 0
+    # dense forward (no token list of its own), un-gated: the table gradient still goes through a distinct-token list built
+    # here (16 us) instead of the window scatter's row of f32 atomics per (document, channel, tap)
+    list_bytes = (L_.rbr_textcnn_bwd_dtable_list_ws_bytes(C.byref(desc))
+                  if (need_table and not bws_bytes and gate is None) else 0)
+    acc = _table_acc(S.fanout_acc, dev) if (need_table and bws_bytes) else None
+    # compact row gradient: the optimizer that asked for it takes the rows of the batch's tokens, nobody writes (or later
+    # reads) the zero rows of a dense [V, D] gradient
+    row_sink = _ROW_GRAD_SINKS.get(table.data_ptr()) if (need_table and bws_bytes and gate is None and acc is None) else None
+    if row_sink is not None and not row_sink.wants_row_grad(table):
+        row_sink = None
+    # the token-list backwards overwrite the whole table gradient; the window scatter accumulates into zeros
+    dtable = None
+    if need_table and row_sink is None:
+        dtable = torch.empty_like(table) if (bws_bytes or list_bytes) else torch.zeros_like(table)
+    # the token-product backward zeroes dgate in the launch that zeroes its G rows; the window scatter accumulates into zeros
+    dgate = (torch.empty_like(gate) if bws_bytes else torch.zeros_like(gate)) if need_gate else None
+    wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
+    wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
+    st = current_stream()
+    common = (C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(gate, F32, "gate"),
+              dev_ptr(table, F32, "table"))
+    # many short documents (NARRE's reviews): dW = G^T @ table[distinct tokens] on the MFMA pipe, from the G the
+    # table-gradient call builds anyway (0 floats of workspace = not this shape: the window-row kernels below)
+    dwg_floats = L_.rbr_textcnn_bwd_dw_from_g_ws_floats(C.byref(desc)) if (need_table and bws_bytes) else 0
+    join = None
+    fork = None
+    side = None
+    if not dwg_floats:
+        # the weight-gradient kernels and the table-gradient kernels below both start from d_feat and share nothing
+        # else: the former go to a second stream (fork here, join before returning), so the two chains overlap --
+        # also inside a captured graph, where the fork becomes two parallel branches
+        side = _side_stream(dev) if (need_table or need_gate or use_taps) else None
+        if side is not None:
+            fork = torch.cuda.Event()
+            fork.record()
+
+    def run_dw():
+        """The weight-gradient chain, enqueued AFTER the table-gradient chain: in a replayed graph the branch captured first
+        keeps the queue of the nodes before and after the fork, and the join of the other branch into that queue costs
+        ~10 us -- so the longer (table) branch goes first and the step's next kernel follows it without a gap."""
+        if dwg_floats:
+            return join
+        j = None
+        if side is not None:
+            side.wait_event(fork)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            ev_dw = TIMER.record("textcnn_bwd_dw")
+            check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                        dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
+                                        ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"), current_stream()),
+                  "rbr_textcnn_bwd_dw")
+            if ev_dw is not None:
+                ev_dw.record()
+            if side is not None:
+                j = torch.cuda.Event()
+                j.record()
+        return j
+
+    ev = TIMER.record("textcnn_bwd_dtable")
+    if use_taps:
+        tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
+        check(L_.rbr_textcnn_bwd_taps(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                      dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                      dev_ptr(d_feat, F32, "d_feat"), dev_ptr(tok, I32, "tap tokens"),
+                                      dev_ptr(val, F32, "tap values"), st), "rbr_textcnn_bwd_taps")
+        sink.record(desc, list(ws))
         if ev is not None:
             ev.record()
         _join(run_dw())
-        return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
+        return None, dgate, dWs, dbs
+    if (need_table or need_gate) and bws_bytes:
+        # token-product backward: dtable = G @ Wprod^T over the forward's distinct-token list (no atomics on the
+        # table); d(gate) of gated convs (D-ATT) is read off the forward's product table
+        zeroed = S.bws is not None                    # the forward's gather launch cleared G's rows
+        bws = S.bws if zeroed else torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+        flags = _lib.G_ZEROED if zeroed else 0
+        rows = sq = None
+        if row_sink is not None:
+            cap = C.c_int32(0)
+            rot = C.c_void_p()
+            check(L_.rbr_textcnn_token_list(C.byref(desc), S.prod_ws.data_ptr(), C.byref(rot), None, None, C.byref(cap)),
+                  "rbr_textcnn_token_list")
+            rows = torch.empty(cap.value, table.shape[1], dtype=F32, device=dev)
+            sq = torch.empty(L_.rbr_textcnn_row_grad_partials(), dtype=F32, device=dev)
+            flags |= _lib.G_ROWS
+        out = rows if rows is not None else dtable
+        if dwg_floats:
+            # G first; then its two consumers side by side: dtable = G @ Wprod^T on this stream, dW = G^T @ table rows on the
+            # second one (fork after the build, join before returning; two parallel branches in a captured graph)
+            check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                    dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                    dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                    S.prod_ws.data_ptr(), bws.data_ptr(), None, dev_ptr(dgate, F32, "dgate"), None,
+                                                    _lib.G_BUILD | (flags & _lib.G_ZEROED), st), "rbr_textcnn_bwd_g_build")
+            dwg_ws = torch.empty(dwg_floats, dtype=F32, device=dev)
+            side = _side_stream(dev)
+            if side is not None:
+                fork = torch.cuda.Event()
+                fork.record()
+                side.wait_event(fork)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ev2 = TIMER.record("textcnn_bwd_dw")
+                check(L_.rbr_textcnn_bwd_dw_from_g(C.byref(desc), dev_ptr(table, F32, "table"), dev_ptr(feat, F32, "feat"),
+                                                   dev_ptr(d_feat, F32, "d_feat"), S.prod_ws.data_ptr(), bws.data_ptr(),
+                                                   ptr_array(dWs, F32, "dW"), ptr_array(dbs, F32, "dbias"),
+                                                   dev_ptr(dwg_ws, F32, "ws"), current_stream()), "rbr_textcnn_bwd_dw_from_g")
+                if ev2 is not None:
+                    ev2.record()
+                if side is not None:
+                    join = torch.cuda.Event()
+                    join.record()
+            if need_table:
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), None, None, None, None, None, None, S.prod_ws.data_ptr(),
+                                                        bws.data_ptr(), dev_ptr(out, F32, "dtable"), None, dev_ptr(sq, F32, "sq_part"),
+                                                        _lib.G_PRODUCT | (flags & _lib.G_ROWS), st), "rbr_textcnn_bwd_g_product")
+            if ev is not None:
+                ev.record()
+            _join(join)
+        else:
+            if acc is not None:          # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
+                dtable = out = acc
+                flags |= _lib.G_ACCUMULATE
+            check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                    dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                    dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                    S.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(out, F32, "dtable"),
+                                                    dev_ptr(dgate, F32, "dgate"), dev_ptr(sq, F32, "sq_part"),
+                                                    _lib.G_BUILD | _lib.G_PRODUCT | flags, st), "rbr_textcnn_bwd_dtable_prod")
+            if ev is not None:
+                ev.record()
+            _join(run_dw())
+        if rows is not None:
+            row_sink.put_row_grad(table, RowGradient(table, rows, sq, rot.value, S.prod_ws))
+            return None, dgate, dWs, dbs
+        return dtable, dgate, dWs, dbs
+    if list_bytes:
+        lws = torch.empty(list_bytes, dtype=torch.uint8, device=dev)
+        check(L_.rbr_textcnn_bwd_dtable_list(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                             ptr_array(ws, F32, "conv weight"), dev_ptr(feat, F32, "feat"),
+                                             dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"), lws.data_ptr(),
+                                             dev_ptr(dtable, F32, "dtable"), st), "rbr_textcnn_bwd_dtable_list")
+        if ev is not None:
+            ev.record()
+        _join(run_dw())
+        return dtable, dgate, dWs, dbs
+    if packed is None:
+        packed = _TextCNN._pack(L_, desc, ws, L_.rbr_textcnn_packed_floats(C.byref(desc)), dev, st)
+    check(L_.rbr_textcnn_bwd_dtable(*common, dev_ptr(packed, F32, "packed"), dev_ptr(feat, F32, "feat"),
+                                    dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                    dev_ptr(dtable, F32, "dtable"), dev_ptr(dgate, F32, "dgate"), st),
+          "rbr_textcnn_bwd_dtable")
+    if ev is not None:
+        ev.record()
+    _join(run_dw())
+    return dtable, dgate, dWs, dbs
+
+
+# ---- compact row gradient of an embedding table (consumer: train_step.HipClipAdam) ------------------------------------------
+_ROW_GRAD_SINKS: dict = {}      # word-table data_ptr -> sink (wants_row_grad(table) -> bool, put_row_grad(table, RowGradient))
+
+
+def set_row_grad_sink(table: torch.Tensor, sink) -> None:
+    """Registers `sink` (None: removes it) for the gradient of `table` in compact row form: the token-product conv's backward
+    then hands sink.put_row_grad(table, RowGradient) the rows of the batch's tokens and returns no dense [V, D] gradient
+    (table.grad stays None until someone calls RowGradient.to_dense())."""
+    if sink is None:
+        _ROW_GRAD_SINKS.pop(table.data_ptr(), None)
+    else:
+        _ROW_GRAD_SINKS[table.data_ptr()] = sink
+
+
+class RowGradient:
+    """Gradient of an embedding table as the rows of the tokens one batch holds (rbr_textcnn_bwd_dtable_prod_ex, RBR_G_ROWS):
+    rows [cap, D] (row r = token tok_of_row[r] of the forward's list), sq [partials] = sums of squares of the rows, and the
+    list's inverse map row_of_token [V] inside the forward's workspace (kept alive here).  Every other row of the dense
+    gradient nn.Embedding's backward would build is exactly zero."""
+
+    def __init__(self, table, rows, sq, row_of_token_ptr, keep_alive):
+        self.V, self.D = int(table.shape[0]), int(table.shape[1])
+        self.rows, self.sq, self.row_of_token_ptr, self._keep = rows, sq, int(row_of_token_ptr), keep_alive
+
+    def to_dense(self) -> torch.Tensor:
+        dense = torch.empty(self.V, self.D, dtype=F32, device=self.rows.device)
+        check(_lib.lib().rbr_row_grad_to_dense(self.V, self.D, self.row_of_token_ptr, dev_ptr(self.rows, F32, "rows"),
+                                               dev_ptr(dense, F32, "dense"), current_stream()), "rbr_row_grad_to_dense")
+        return dense
 
 
 _SIDE_STREAMS: dict = {}
@@ -571,6 +641,247 @@ def pair_head(u_feat, i_feat, u_id, i_id, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib, 
     ids [B] int64; returns pred [B].  drop: None, a [B,K] multiplier tensor, or a float = dropout probability of a
     TRAINING forward (the kernel draws the multiplier itself: one launch less than dropout_multiplier + pair_head)."""
     return _PairHead.apply(u_feat, i_feat, u_id, i_id, drop, pad_u, pad_i, Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib)
+
+
+# --------------------------------------------------------------------------- encoder + head of a two-tower model, fused
+class _LossRequest:
+    """fused_loss(target): the trainer's nn.MSELoss target, announced to the model's forward so that a fused head launch can
+    compute the loss as well; loss_for(pred) hands it out (None: the forward did not take the offer)."""
+
+    def __init__(self, target):
+        self.target, self.pred_ptr, self.loss = target, None, None
+
+    def loss_for(self, pred: torch.Tensor):
+        if self.loss is not None and self.pred_ptr == pred.data_ptr() and pred.numel() == self.target.numel():
+            return self.loss
+        return None
+
+
+_LOSS_REQUEST: list = []
+
+
+@contextlib.contextmanager
+def fused_loss(target: torch.Tensor):
+    """with fused_loss(ratings) as fl: pred = model(*batch); loss = fl.loss_for(pred) -- the mean-squared error against
+    `target` (trainer/train_deepconn_pp.py:164) out of the model's last launch when the model supports it (DeepCoNN's fused
+    encoder + head), else None and the caller computes mse_loss(pred, target) itself."""
+    req = _LossRequest(target)
+    _LOSS_REQUEST.append(req)
+    try:
+        yield req
+    finally:
+        _LOSS_REQUEST.remove(req)
+
+
+_TICKETS: dict = {}
+
+
+def _ticket(dev) -> torch.Tensor:
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _TICKETS.get(idx)
+    if t is None:
+        t = _TICKETS[idx] = torch.zeros(4, dtype=I32, device=dev)
+    return t
+
+
+def encode_head_applicable(table, n_docs, L, kernel_sizes, channels, padding_idx) -> bool:
+    """True when the fused encoder + head function serves this conv: the token-product formulation applies and one
+    pool-epilogue launch covers every channel slot."""
+    if not table.is_cuda or table.dtype != F32 or n_docs % 2 or os.environ.get("RBR_FUSED_STEP", "1") == "0":
+        return False
+    if (sum(channels) + 31) // 32 > 8:
+        return False
+    desc = _lib.make_desc(n_docs, L, table.shape[1], table.shape[0], kernel_sizes, channels, PAD_SAME, ACT_RELU, padding_idx)
+    return _lib.lib().rbr_textcnn_fwd_ws_bytes(C.byref(desc)) > 0
+
+
+class _EncodeHead(torch.autograd.Function):
+    """pred[B] (and the MSE loss against `target`) = rating head(TextCNN(user docs), TextCNN(item docs), ids): the training /
+    eval forward of DeepCoNN++ (deepconn.py:43-53) as 6 launches -- id check + list state | token marks + slab scan | token list
+    + weight images | distinct-token GEMM | gather + max-pool (+ clearing the backward's G) | pool epilogue + LastFeat x2 + FM
+    (+ MSELoss) -- and its backward as head_bwd, then [G build, G @ Wprod^T] beside [dW] (see _textcnn_backward)."""
+
+    @staticmethod
+    def forward(ctx, table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i, n_widths, *params):
+        ws_, bs_ = [w.contiguous() for w in params[:n_widths]], [b.contiguous() for b in params[n_widths:2 * n_widths]]
+        head = [t.contiguous() for t in params[2 * n_widths:]]
+        L_ = _lib.lib()
+        dev = table.device
+        table_c = table.contiguous()
+        dev_ptr(table_c, F32, "word table")
+        V, D = table.shape
+        kernel_sizes = [int(w.shape[2]) for w in ws_]
+        channels = [int(w.shape[0]) for w in ws_]
+        Ctot = sum(channels)
+        st = current_stream()
+        # ---- clean id tensors: token ids of both towers first (the conv's [2B, L] batch), then the rest
+        if id_sets is not None:
+            tens = [t.contiguous() for t, _, _ in id_sets]
+            flat = torch.empty(sum(t.numel() for t in tens), dtype=I64, device=dev)
+            arr = (_lib.IdSet * len(tens))()
+            outs, o = [], 0
+            for k, (t, (_, rows, rep)) in enumerate(zip(tens, id_sets)):
+                dev_ptr(t, I64, "ids")
+                v = flat[o:o + t.numel()].view(t.shape)
+                outs.append(v)
+                o += t.numel()
+                arr[k] = _lib.IdSet(t.data_ptr(), v.data_ptr(), t.numel(), int(rows), 0 if rep is None or rep < 0 else int(rep))
+            n_tok = tens[0].numel() + tens[1].numel()
+            ids = flat[:n_tok].view(2 * tens[0].shape[0], tens[0].shape[1])
+            u_id, i_id = outs[2], outs[3]
+        else:
+            ids, u_id, i_id = ids.contiguous(), u_id.contiguous(), i_id.contiguous()
+        n_docs, L = ids.shape
+        B = n_docs // 2
+        mask8 = _mask_u8(mask)
+        if mask8 is not None and mask8.shape != ids.shape:
+            raise AssertionError("inputs.shape[:-1] == masks.shape")   # deepconn/utils.py:58
+        desc = _lib.make_desc(n_docs, L, D, V, kernel_sizes, channels, PAD_SAME, ACT_RELU, padding_idx)
+        n_part = L_.rbr_textcnn_partial_elems(C.byref(desc))
+        ws_bytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))
+        if not n_part or not ws_bytes:
+            check(-1, "encode_head plan (encode_head_applicable() was not consulted)")
+        pval = torch.empty(n_part, dtype=F32, device=dev)
+        pidx = torch.empty(n_part, dtype=I32, device=dev)
+        feat = torch.empty(n_docs, Ctot, dtype=F32, device=dev)
+        argmax = torch.empty(n_docs, Ctot, dtype=I32, device=dev)
+        prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        wsp = prod_ws.data_ptr()
+        training = any(ctx.needs_input_grad)          # (grad mode itself is off inside forward)
+        ev = TIMER.record("textcnn_prod_prepare")
+        if id_sets is not None:
+            check(L_.rbr_textcnn_prod_prepare_ids(C.byref(desc), len(tens), arr, _id_err(dev).data_ptr(), dev_ptr(ids, I64, "ids"),
+                                                  dev_ptr(mask8, U8, "mask"), ptr_array(ws_, F32, "conv weight"),
+                                                  dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_prepare_ids")
+        else:
+            check(L_.rbr_textcnn_prod_prepare(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                              ptr_array(ws_, F32, "conv weight"), dev_ptr(pidx, I32, "pidx"), wsp, st),
+                  "rbr_textcnn_prod_prepare")
+        if ev is not None:
+            ev.record()
+        ev = TIMER.record("textcnn_prod_table")
+        check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
+        if ev is not None:
+            ev.record()
+        # the backward's G: allocated now so that the gather launch clears its rows (no zero launch in the backward)
+        bws = None
+        if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS:
+            bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc))
+            if bws_bytes:
+                bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+        ev = TIMER.record("textcnn_prod_pool")
+        if bws is not None:
+            check(L_.rbr_textcnn_prod_pool_zero(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,
+                                                dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, bws.data_ptr(), st),
+                  "rbr_textcnn_prod_pool_zero")
+        else:
+            check(L_.rbr_textcnn_prod_pool(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,
+                                           dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
+        if ev is not None:
+            ev.record()
+        # ---- pool epilogue + rating head (+ loss)
+        K = head[0].shape[1]
+        hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(head, _HEAD_NAMES)])
+        ul = torch.empty(B, K, dtype=F32, device=dev)
+        il = torch.empty(B, K, dtype=F32, device=dev)
+        pred = torch.empty(B, dtype=F32, device=dev)
+        p_drop, drop_t, flat_zero, acc_n = 0.0, None, None, 0
+        seed, state = 0, None
+        if isinstance(drop, float):
+            if drop >= 1.0:
+                raise RuntimeError("pair_head: drop probability must be < 1 on the fused path")
+            p_drop = drop
+            acc_n = sum(t.numel() for t, n in zip(head, _HEAD_NAMES) if n in _HEAD_ACC) if training else 0
+            flat_zero = torch.empty(acc_n, dtype=F32, device=dev) if acc_n else None
+            if p_drop > 0.0:
+                seed, state = _drop_rng(dev)
+                drop_t = torch.empty(B, K, dtype=F32, device=dev)
+        elif drop is not None:
+            drop_t = drop.contiguous()
+        loss = d_unit = None
+        if target is not None:
+            target = target.contiguous()
+            loss = torch.empty((), dtype=F32, device=dev)
+            d_unit = torch.empty(B, dtype=F32, device=dev)
+        ev = TIMER.record("pair_head_fwd_pool")
+        check(L_.rbr_pair_head_fwd_pool(C.byref(desc), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
+                                        ptr_array(bs_, F32, "conv bias"), dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                        K, dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                        dev_ptr(drop_t, F32, "drop") if p_drop == 0.0 else None, float(p_drop), seed,
+                                        state.data_ptr() if state is not None else None,
+                                        dev_ptr(drop_t, F32, "drop") if p_drop > 0.0 else None, dev_ptr(flat_zero, F32, "zero_buf"),
+                                        acc_n, dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"), dev_ptr(pred, F32, "pred"),
+                                        dev_ptr(target, F32, "target"), dev_ptr(loss, F32, "loss"), dev_ptr(d_unit, F32, "d_unit"),
+                                        _ticket(dev).data_ptr() if target is not None else None, st), "rbr_pair_head_fwd_pool")
+        if ev is not None:
+            ev.record()
+        ctx.conv = _ConvSaved(table=table_c, ids=ids, packed=None, feat=feat, argmax=argmax, mask8=mask8, gate=None, ws=ws_,
+                              desc=desc, prod_ws=prod_ws, fanout_acc=None, bws=bws)
+        ctx.head = (u_id, i_id, ul, il, head, drop_t, flat_zero, d_unit)
+        ctx.dims = (B, Ctot, K, int(pad_u), int(pad_i), n_widths)
+        ctx.set_materialize_grads(False)
+        if loss is None:
+            loss = torch.empty((), dtype=F32, device=dev)      # no target: an unwritten placeholder nobody reads
+            ctx.mark_non_differentiable(loss)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, d_pred, d_loss):
+        B, H, K, pad_u, pad_i, n_widths = ctx.dims
+        u_id, i_id, ul, il, head, drop_t, flat, d_unit = ctx.head
+        S = ctx.conv
+        dev = S.table.device
+        L_ = _lib.lib()
+        if d_loss is not None:                  # the fused loss: d loss / d pred was written by the forward launch
+            unit = _UNIT.get(dev)
+            g = d_unit if (unit is not None and d_loss.data_ptr() == unit.data_ptr()) else d_unit * d_loss
+            d_pred = g if d_pred is None else d_pred + g
+        if d_pred is None:
+            d_pred = torch.zeros(B, dtype=F32, device=dev)
+        d_pred = d_pred.contiguous()
+        hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(head, _HEAD_NAMES)])
+        accs = [t for t, n in zip(head, _HEAD_NAMES) if n in _HEAD_ACC]
+        if flat is None:
+            flat = torch.zeros(sum(t.numel() for t in accs), dtype=F32, device=dev)
+        ctx.head = (u_id, i_id, ul, il, head, drop_t, None, d_unit)      # a second backward gets a fresh accumulation buffer
+        zeroed = iter(v.view_as(t) for v, t in zip(flat.split([t.numel() for t in accs]), accs))
+        grads = [next(zeroed) if n in _HEAD_ACC else torch.empty_like(t) for t, n in zip(head, _HEAD_NAMES)]
+        hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, _HEAD_NAMES)])
+        d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
+        feat = S.feat
+        check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
+                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                   dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                   dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
+                                   dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), None,
+                                   current_stream()), "rbr_pair_head_bwd")
+        need_conv = any(ctx.needs_input_grad[12:12 + 2 * n_widths]) or ctx.needs_input_grad[0]
+        if need_conv:
+            dtable, _, dWs, dbs = _textcnn_backward(S, d_pair, ctx.needs_input_grad[0], False)
+        else:
+            dtable, dWs, dbs = None, [None] * n_widths, [None] * n_widths
+        return (dtable, None, None, None, None, None, None, None, None, None, None, None, *dWs, *dbs, *grads)
+
+
+def encode_head(table, ids, mask, u_id, i_id, conv_weights, conv_biases, head_params, *, id_sets=None, drop=None,
+                padding_idx=0, pad_u=0, pad_i=0):
+    """DeepCoNN++'s forward from token ids to predictions in one autograd function (see _EncodeHead).  ids / mask: the stacked
+    [2B, L] towers (user rows first) -- or id_sets = [(u_docs, V, pad), (i_docs, V, pad), (u_ids, U, 0), (i_ids, I, 0)], the raw
+    id tensors, whose range check then rides in the prepare stage's first launch (ids / u_id / i_id are ignored).
+    head_params: (Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib).  drop: None, a [B, K] multiplier, or the dropout probability of a
+    training forward.  Inside `with fused_loss(target)` the MSE against target is computed by the head launch as well."""
+    req = _LOSS_REQUEST[-1] if _LOSS_REQUEST else None
+    target = None
+    if req is not None and req.loss is None and req.target.is_cuda and req.target.dtype == F32 and req.target.dim() == 1 \
+            and torch.is_grad_enabled():
+        B = (id_sets[0][0].shape[0] if id_sets is not None else ids.shape[0] // 2)
+        if req.target.shape[0] == B:
+            target = req.target
+    pred, loss = _EncodeHead.apply(table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i,
+                                   len(conv_weights), *conv_weights, *conv_biases, *head_params)
+    if target is not None:
+        req.pred_ptr, req.loss = pred.data_ptr(), loss
+    return pred
 
 
 def stack_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

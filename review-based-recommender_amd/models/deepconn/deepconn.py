@@ -30,6 +30,13 @@ class DeepCoNNpp(nn.Module):
         # synchronisation point.  False: the caller guarantees the ranges (a dataset validated at load time).
         self.validate_ids = True
 
+    def _fused_ok(self, u_revs, i_revs) -> bool:
+        if self.dedup_by_id or self.ngram.arch != "CNN" or u_revs.shape != i_revs.shape or u_revs.dim() != 2:
+            return False
+        conv = self.ngram.feature_layer[0]
+        return RF.encode_head_applicable(self.word_embeddings.weight, 2 * u_revs.shape[0], u_revs.shape[1], conv.kernel_sizes,
+                                         [conv.out_features_per_kz] * len(conv.kernel_sizes), self.word_embeddings.padding_idx)
+
     def forward(self, u_revs, i_revs, u_rev_masks, i_rev_masks, u_ids, i_ids):
         """u_revs/i_revs [bz, doc_len] int64, masks [bz, doc_len] bool, ids [bz] -> preds [bz].
 
@@ -37,6 +44,29 @@ class DeepCoNNpp(nn.Module):
         documents go through ONE launch of the fused gather+conv+pool kernel as a 2*bz batch."""
         bz = u_revs.shape[0]
         stacked = None
+        if self._fused_ok(u_revs, i_revs):
+            # encoder + rating head as ONE autograd function (functional.encode_head): the id check rides in the conv's
+            # prepare launch, the pool epilogue and -- inside train_step's fused_loss -- the MSE ride in the head launch
+            pad = self.word_embeddings.padding_idx
+            conv = self.ngram.feature_layer[0]
+            uf, itf, fm = self.user_feat, self.item_feat, self.fm
+            training = fm.training and torch.is_grad_enabled()
+            if training and fm.dropout.p < 1.0:
+                drop = float(fm.dropout.p)
+            else:
+                drop = RF.dropout_multiplier((bz, fm.h.shape[0]), fm.dropout.p, fm.training, u_revs.device)
+            head = (uf.W, uf.b, uf.ebd.weight, itf.W, itf.b, itf.ebd.weight, fm.h, fm.g_bias, fm.user_bias.weight, fm.item_bias.weight)
+            masks = RF.stack_rows(u_rev_masks, i_rev_masks)
+            if self.validate_ids:
+                sets = [(u_revs, self.vocab_size, pad), (i_revs, self.vocab_size, pad), (u_ids, self.user_size, 0),
+                        (i_ids, self.item_size, 0)]
+                preds = RF.encode_head(self.word_embeddings.weight, None, masks, None, None, conv.weights(), conv.biases(), head,
+                                       id_sets=sets, drop=drop, padding_idx=pad, pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)
+            else:
+                preds = RF.encode_head(self.word_embeddings.weight, RF.stack_rows(u_revs, i_revs), masks, u_ids, i_ids,
+                                       conv.weights(), conv.biases(), head, drop=drop, padding_idx=pad,
+                                       pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)
+            return preds.view(bz)
         if self.validate_ids:
             pad = self.word_embeddings.padding_idx
             stacked, u_ids, i_ids = RF.sanitize_ids([(u_revs, self.vocab_size, pad), (i_revs, self.vocab_size, pad),

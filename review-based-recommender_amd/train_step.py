@@ -11,6 +11,8 @@ loss.item() calls per step, :171-172, are logging, not part of the math).
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -51,10 +53,61 @@ class HipClipAdam(torch.optim.Optimizer):
 
     MAX_TENSORS = 64      # RBR_OPT_MAX_TENSORS
 
-    def __init__(self, params, lr: float = LR, betas=(0.9, 0.999), eps: float = 1e-8):
+    ROW_GRAD_MIN_ROWS = 4096      # tables at least this tall take their gradient in compact row form
+
+    def __init__(self, params, lr: float = LR, betas=(0.9, 0.999), eps: float = 1e-8, row_grads: bool = True):
+        """row_grads: embedding tables among the parameters (2-D, >= ROW_GRAD_MIN_ROWS rows, row length % 4 == 0) receive the
+        gradient of a token-product conv as the rows of the batch's tokens (functional.RowGradient) instead of a dense
+        [V, D] tensor whose other rows are zeros: `.grad` of such a table stays None after backward -- call
+        materialize_grads() to see the dense gradient -- and the clip + Adam launches neither read nor re-write the zero rows.
+        Same parameters and state as with the dense gradient, bit for bit."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._ws = None
         self._gnorm = None
+        self._row_grads = {}          # parameter -> functional.RowGradient of the last backward
+        self._row_tables = []
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            row_grads = False         # a data-parallel exchange reads every gradient as a dense .grad
+        if row_grads:
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.is_cuda and p.dim() == 2 and p.shape[0] >= self.ROW_GRAD_MIN_ROWS and p.shape[1] % 4 == 0 \
+                            and p.dtype == torch.float32 and p.numel() < (1 << 32):
+                        RF.set_row_grad_sink(p, self)
+                        self._row_tables.append(p)
+
+    # ---- functional.set_row_grad_sink protocol
+    def wants_row_grad(self, table) -> bool:
+        return any(table.data_ptr() == p.data_ptr() for p in self._row_tables)
+
+    def put_row_grad(self, table, rg) -> None:
+        p = next(q for q in self._row_tables if q.data_ptr() == table.data_ptr())
+        old = self._row_grads.pop(p, None)
+        if old is not None:               # a second backward before the step: accumulate the ordinary way
+            dense = old.to_dense()
+            p.grad = dense if p.grad is None else p.grad + dense
+        self._row_grads[p] = rg
+
+    def close(self) -> None:
+        """Unregisters the row-gradient hand-off (the tables get dense gradients again)."""
+        for p in self._row_tables:
+            RF.set_row_grad_sink(p, None)
+        self._row_tables = []
+        self.materialize_grads()
+
+    @torch.no_grad()
+    def materialize_grads(self) -> None:
+        """Turns every pending compact row gradient into the dense `.grad` nn.Embedding's backward would have left (after a
+        clipping step: the clipped gradient, as clip_grad_norm_ leaves it)."""
+        for p, rg in list(self._row_grads.items()):
+            dense = rg.to_dense()
+            p.grad = dense if p.grad is None else p.grad + dense
+        self._row_grads.clear()
+
+    def zero_grad(self, set_to_none: bool = True):
+        self._row_grads.clear()
+        super().zero_grad(set_to_none=set_to_none)
 
     def _state_of(self, p):
         st = self.state[p]
@@ -71,7 +124,9 @@ class HipClipAdam(torch.optim.Optimizer):
         import ctypes as C
         from . import _lib
         L_ = _lib.lib()
-        todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        for p in [q for q in self._row_grads if q.grad is not None]:      # mixed: a dense gradient exists too -> dense path
+            p.grad = p.grad + self._row_grads.pop(p).to_dense()
+        todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None or p in self._row_grads]
         if not todo:
             raise RuntimeError("HipClipAdam.clip_and_step: no gradients")
         dev = todo[0][1].device
@@ -87,6 +142,8 @@ class HipClipAdam(torch.optim.Optimizer):
             ps = [p for gg, p in todo if gg is g]
             for k in range(0, len(ps), self.MAX_TENSORS):
                 batches.append((g, ps[k:k + self.MAX_TENSORS]))
+        if self._row_grads and (len(batches) > 1 or len(self._row_grads) > 1):
+            self.materialize_grads()          # one compact table per launch pair: anything else takes the dense path
         if len(batches) > 1 and max_grad_norm is not None:
             # the fused clip needs every gradient in ONE launch pair; beyond 64 tensors (or with several parameter groups) the
             # norm and the in-place scaling are torch's clip_grad_norm_ (same maths, device-side, capturable) and the launch
@@ -100,22 +157,27 @@ class HipClipAdam(torch.optim.Optimizer):
             for s_ in states[1:]:          # the tensors of a batch step together: one shared device counter
                 if s_["step"] is not step:
                     s_["step"] = step
-            grads = [p.grad for p in ps]
+            grads = [p.grad for p in ps]          # None for the table whose gradient is in row form
             for p, gr in zip(ps, grads):
-                if not (p.is_contiguous() and gr.is_contiguous()):
+                if not (p.is_contiguous() and (gr is None or gr.is_contiguous())):
                     raise RuntimeError("HipClipAdam needs contiguous parameters and gradients")
             numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
             b1, b2 = g["betas"]
             ev = _lib.TIMER.record("clip_adam_step")
-            _lib.check(L_.rbr_clip_adam_step(len(ps), _lib.ptr_array(ps, torch.float32, "param"),
-                                             _lib.ptr_array(grads, torch.float32, "grad"),
-                                             _lib.ptr_array([s_["exp_avg"] for s_ in states], torch.float32, "exp_avg"),
-                                             _lib.ptr_array([s_["exp_avg_sq"] for s_ in states], torch.float32, "exp_avg_sq"),
-                                             numel, float(max_grad_norm) if max_grad_norm is not None else 0.0,
-                                             float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                             _lib.dev_ptr(step, torch.float32, "step"),
-                                             _lib.dev_ptr(self._gnorm, torch.float32, "gnorm") if len(batches) == 1 else None,
-                                             _lib.dev_ptr(self._ws, torch.float32, "ws"), st), "rbr_clip_adam_step")
+            args = (len(ps), _lib.ptr_array(ps, torch.float32, "param"), _lib.ptr_array(grads, torch.float32, "grad"),
+                    _lib.ptr_array([s_["exp_avg"] for s_ in states], torch.float32, "exp_avg"),
+                    _lib.ptr_array([s_["exp_avg_sq"] for s_ in states], torch.float32, "exp_avg_sq"),
+                    numel, float(max_grad_norm) if max_grad_norm is not None else 0.0,
+                    float(g["lr"]), float(b1), float(b2), float(g["eps"]), _lib.dev_ptr(step, torch.float32, "step"),
+                    _lib.dev_ptr(self._gnorm, torch.float32, "gnorm") if len(batches) == 1 else None,
+                    _lib.dev_ptr(self._ws, torch.float32, "ws"))
+            rowp = [k for k, p in enumerate(ps) if p in self._row_grads]
+            if rowp:
+                rg = self._row_grads[ps[rowp[0]]]
+                crg = _lib.RowGrad(rowp[0], rg.V, rg.D, rg.row_of_token_ptr, rg.rows.data_ptr(), rg.sq.data_ptr(), rg.sq.numel())
+                _lib.check(L_.rbr_clip_adam_step_rows(*args, C.byref(crg), st), "rbr_clip_adam_step_rows")
+            else:
+                _lib.check(L_.rbr_clip_adam_step(*args, st), "rbr_clip_adam_step")
             if ev is not None:
                 ev.record()
         return self._gnorm
@@ -144,13 +206,27 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     (NARRE: pred, u_att, i_att) contribute their first element.  `grad_sync(model)` is the
     data-parallel gradient all-reduce hook (None on one GPU).  Returns (loss, gnorm, pred) tensors."""
     optimizer.zero_grad()
-    out = model(*batch)
-    pred = out[0] if isinstance(out, tuple) else out
-    loss = _loss_and_backward(pred, ratings)
+    pred, loss = _forward_loss_backward(model, batch, ratings)
     if grad_sync is not None:
+        if isinstance(optimizer, HipClipAdam):
+            optimizer.materialize_grads()        # the all-reduce wants every gradient as a dense .grad
         grad_sync(model)
     gnorm = clip_and_step(model, optimizer, max_grad_norm)
     return loss.detach(), gnorm, pred.detach()
+
+
+def _forward_loss_backward(model: nn.Module, batch, ratings: torch.Tensor):
+    """y = model(*batch); loss = MSELoss()(y, ratings); loss.backward()  (train_deepconn_pp.py:162-165).  The target is
+    announced to the forward (functional.fused_loss): a model whose last launch can compute the loss takes it along."""
+    fusable = ratings.is_cuda and ratings.dtype == torch.float32
+    with (RF.fused_loss(ratings) if fusable else contextlib.nullcontext()) as req:
+        out = model(*batch)
+        pred = out[0] if isinstance(out, tuple) else out
+        loss = req.loss_for(pred) if req is not None else None
+    if loss is not None:
+        loss.backward(RF.unit_scalar(pred.device))
+        return pred, loss
+    return pred, _loss_and_backward(pred, ratings)
 
 
 def _loss_and_backward(pred: torch.Tensor, ratings: torch.Tensor) -> torch.Tensor:
@@ -306,10 +382,10 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
                 optimizer.zero_grad()
-                out = model(*self.batch)
-                pred = out[0] if isinstance(out, tuple) else out
-                loss = _loss_and_backward(pred, self.ratings)
+                pred, loss = _forward_loss_backward(model, self.batch, self.ratings)
                 self.loss, self.pred = loss.detach(), pred.detach()
+                if isinstance(optimizer, HipClipAdam):
+                    optimizer.materialize_grads()
             grad_sync(model)
             self._static_grads = [(p, p.grad) for p in model.parameters()]
             self.g_update = torch.cuda.CUDAGraph()
