@@ -504,10 +504,21 @@ typedef struct rbr_row_grad {
     float* rows;                    /* [list rows, D] */
     const float* sq_part;           /* [n_sq] partial sums of squares of `rows` */
     int32_t n_sq;
+    int32_t absent_rows_done;       /* 1: rbr_adam_absent_rows already updated the rows of absent tokens in this step */
+    const int64_t* tok_of_row;      /* [list rows] (needed with absent_rows_done) */
+    const int32_t* n_rows;          /* [1] device count of list rows (needed with absent_rows_done) */
 } rbr_row_grad;
 int rbr_clip_adam_step_rows(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1, float beta2,
                             float eps, float* step, float* gnorm_out, float* ws, const rbr_row_grad* rg, void* stream);
+/* The part of that step that does not wait for the backward: Adam's update of the rows of the tokens the batch does NOT hold
+ * (g = 0: m, v decay and p moves by the momentum term; no dependence on the clip coefficient).  Call it once the forward's
+ * token list exists (rbr_textcnn_token_list), on any stream, BEFORE rbr_clip_adam_step_rows of the same step, which must
+ * then be told absent_rows_done = 1 and walks only the listed rows.  `step`: the count of steps taken before this one (not
+ * advanced here).  Same bits as the one-launch form.  Caveat: a non-finite gradient norm (clip_grad_norm_ would turn every
+ * element into NaN) no longer reaches these rows. */
+int rbr_adam_absent_rows(int32_t V, int32_t D, const int32_t* row_of_token, float* param, float* exp_avg, float* exp_avg_sq,
+                         float lr, float beta1, float beta2, float eps, const float* step, void* stream);
 /* dense[v, :] = rows[row_of_token[v], :] for listed tokens, 0 elsewhere: the [V, D] gradient for consumers outside the fused step */
 int rbr_row_grad_to_dense(int32_t V, int32_t D, const int32_t* row_of_token, const float* rows, float* dense, void* stream);
 

@@ -58,7 +58,8 @@ MAX_ID_SETS = 8
 
 class RowGrad(C.Structure):       # rbr_row_grad
     _fields_ = [("tensor", C.c_int32), ("V", C.c_int32), ("D", C.c_int32), ("row_of_token", C.c_void_p), ("rows", C.c_void_p),
-                ("sq_part", C.c_void_p), ("n_sq", C.c_int32)]
+                ("sq_part", C.c_void_p), ("n_sq", C.c_int32), ("absent_rows_done", C.c_int32), ("tok_of_row", C.c_void_p),
+                ("n_rows", C.c_void_p)]
 
 
 G_BUILD, G_PRODUCT, G_ACCUMULATE, G_ROWS, G_ZEROED = 1, 2, 4, 8, 16      # RBR_G_* of rbr_hip.h
@@ -114,6 +115,8 @@ SIGNATURES = {
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
     "rbr_clip_adam_step_rows": (C.c_int, [i32, _PP, _PP, _PP, _PP, C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, C.POINTER(RowGrad), c_stream]),
+    "rbr_adam_absent_rows": (C.c_int, [i32, i32, c_i32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float, C.c_float, c_f32p,
+                                       c_stream]),
     "rbr_row_grad_to_dense": (C.c_int, [i32, i32, c_i32p, c_f32p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_dtable_list_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dtable_list": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_f32p, c_i32p, c_f32p, C.c_void_p, c_f32p, c_stream]),

@@ -482,7 +482,8 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
 
 
 # ---- compact row gradient of an embedding table (consumer: train_step.HipClipAdam) ------------------------------------------
-_ROW_GRAD_SINKS: dict = {}      # word-table data_ptr -> sink (wants_row_grad(table) -> bool, put_row_grad(table, RowGradient))
+# word-table data_ptr -> sink: wants_row_grad(table) -> bool, put_row_grad(table, RowGradient), on_token_list(table, desc, fwd_ws)
+_ROW_GRAD_SINKS: dict = {}
 
 
 def set_row_grad_sink(table: torch.Tensor, sink) -> None:
@@ -504,6 +505,7 @@ class RowGradient:
     def __init__(self, table, rows, sq, row_of_token_ptr, keep_alive):
         self.V, self.D = int(table.shape[0]), int(table.shape[1])
         self.rows, self.sq, self.row_of_token_ptr, self._keep = rows, sq, int(row_of_token_ptr), keep_alive
+        self.fwd_ws = keep_alive          # the forward's workspace: identifies the token list the rows belong to
 
     def to_dense(self) -> torch.Tensor:
         dense = torch.empty(self.V, self.D, dtype=F32, device=self.rows.device)
@@ -759,16 +761,21 @@ class _EncodeHead(torch.autograd.Function):
                   "rbr_textcnn_prod_prepare")
         if ev is not None:
             ev.record()
-        ev = TIMER.record("textcnn_prod_table")
-        check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
-        if ev is not None:
-            ev.record()
         # the backward's G: allocated now so that the gather launch clears its rows (no zero launch in the backward)
         bws = None
         if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS:
             bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc))
             if bws_bytes:
                 bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+                # the token list exists: an optimizer that takes this table's gradient in row form may start on the rows of the
+                # tokens the batch does NOT hold right away, beside the GEMM (train_step.HipClipAdam.on_token_list)
+                row_sink = _ROW_GRAD_SINKS.get(table_c.data_ptr())
+                if row_sink is not None and row_sink.wants_row_grad(table_c):
+                    row_sink.on_token_list(table_c, desc, prod_ws)
+        ev = TIMER.record("textcnn_prod_table")
+        check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
+        if ev is not None:
+            ev.record()
         ev = TIMER.record("textcnn_prod_pool")
         if bws is not None:
             check(L_.rbr_textcnn_prod_pool_zero(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,

@@ -46,13 +46,17 @@ class _env:
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("early", [False, True])
 @pytest.mark.parametrize("cfgname", ["small", "cfg1", "cfg2"])
-def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
-    """HipClipAdam(row_grads=True) takes the table gradient as the rows of the batch's tokens; the parameters, the Adam state
-    and the norm after three clipped steps are the dense path's bits, and materialize_grads() rebuilds the dense .grad
-    (clipped, as clip_grad_norm_ leaves it)."""
+def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname, early):
+    """HipClipAdam(row_grads=True) takes the table gradient as the rows of the batch's tokens.  Fed the SAME gradient in dense
+    form (the rows scattered into a zero [V, D] tensor), a second optimizer on a copy of the model ends three clipped steps
+    with the same bits: parameters, Adam state, the norm, and the clipped gradient clip_grad_norm_ would have left.
+    (Two separate backwards cannot be compared bit for bit: G is built with f32 atomics.)  early: the optimizer is armed as
+    train_step() arms it, so the rows of the batch's absent tokens are updated beside the forward (rbr_adam_absent_rows) and
+    clip_and_step walks the listed rows only -- still the same bits."""
     from review_based_recommender_amd import _lib
-    from review_based_recommender_amd.train_step import HipClipAdam, train_step
+    from review_based_recommender_amd.train_step import HipClipAdam, _forward_loss_backward
     _lib.lib().rbr_set_conv_mode(2)
     try:
         cfg = synth.DEEPCONN_CFGS[cfgname]
@@ -65,13 +69,25 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
         finally:
             HipClipAdam.ROW_GRAD_MIN_ROWS = keep
         ob = HipClipAdam(list(mb.parameters()), lr=2e-3, row_grads=False)
-        used_rows = False
         for step in range(3):
             args, r = _batch(cfg, 3 + step, edge=(cfgname == "small"))
-            la, ga, _ = train_step(ma, oa, args, r, max_grad_norm=0.05)       # small enough to clip every step
-            used_rows |= table_a.grad is None and table_a in oa._row_grads
-            lb, gb, _ = train_step(mb, ob, args, r, max_grad_norm=0.05)
-            assert float(la) == float(lb)
+            oa.zero_grad()
+            if early:
+                oa.arm()
+            _forward_loss_backward(ma, args, r)
+            assert bool(oa._early) == early
+            assert table_a.grad is None and table_a in oa._row_grads, "the compact row gradient was not handed over"
+            dense = oa._row_grads[table_a].to_dense()
+            # what the dense backward computes: the same rows, zeros elsewhere (checked against a second, dense backward)
+            ob.zero_grad()
+            _forward_loss_backward(mb, args, r)
+            ref = mb.word_embeddings.embedding.weight.grad
+            assert float((dense - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1e-30)
+            assert torch.equal(dense == 0, ref == 0) or float(((dense == 0) != (ref == 0)).float().mean()) < 1e-3
+            for pa, pb in zip(ma.parameters(), mb.parameters()):
+                pb.grad = dense.clone() if pa is table_a else pa.grad.clone()
+            ga = oa.clip_and_step(0.05).clone()          # small enough to clip every step
+            gb = ob.clip_and_step(0.05).clone()
             assert float(ga) == float(gb), (step, float(ga), float(gb))
             oa.materialize_grads()
             for (k, pa), pb in zip(ma.named_parameters(), mb.parameters()):
@@ -79,7 +95,6 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
                 assert torch.equal(pa.grad, pb.grad), (step, k, "clipped gradient")
                 assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]), (step, k)
                 assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), (step, k)
-        assert used_rows, "the compact row gradient was never handed over (D % 4 or the product path not taken?)"
         oa.close()
     finally:
         _lib.lib().rbr_set_conv_mode(0)
