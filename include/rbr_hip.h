@@ -192,7 +192,7 @@ int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd
  *   RBR_G_ROWS                   `dtable` is the gradient in COMPACT form [list rows, D]: row r belongs to token tok_of_row[r]
  *                                of the forward's list (rbr_textcnn_token_list), tokens the batch does not hold have no row
  *                                (their gradient is zero and is never written: at cfg2 that is 57 % of embedding_dense_backward's
- *                                [V, D] output, deepconn/layers.py:22-24), and sq_part[rbr_textcnn_row_grad_partials()] receives
+ *                                [V, D] output, deepconn/layers.py:22-24), and sq_part[rbr_textcnn_row_grad_partials(d)] receives
  *                                per-workgroup sums of squares of the rows in a fixed order (the table's share of
  *                                clip_grad_norm_'s norm).  Consumers: rbr_clip_adam_step_rows, rbr_row_grad_to_dense;
  *   RBR_G_ZEROED                 G's rows are already zero (rbr_textcnn_prod_pool_zero cleared them): no zero launch.
@@ -205,7 +205,7 @@ int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd
 int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                    const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                    float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream);
-size_t rbr_textcnn_row_grad_partials(void);
+size_t rbr_textcnn_row_grad_partials(const rbr_textcnn_desc* d);
 /* Device addresses of the forward's token list inside `fwd_ws` (its layout is private): row_of_token [V] (list row or -1),
  * n_rows [1] (rows in the list), tok_of_row [cap]; *cap = rows a compact gradient must have room for.  Any out-pointer may be NULL. */
 int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, const int32_t** row_of_token, const int32_t** n_rows,

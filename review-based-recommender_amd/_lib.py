@@ -105,7 +105,7 @@ SIGNATURES = {
     "rbr_textcnn_bwd_g_product": (C.c_int, [_DESC, C.c_void_p, C.c_void_p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_dtable_prod_ex": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_i32p, c_f32p, C.c_void_p, C.c_void_p,
                                                  c_f32p, c_f32p, c_f32p, i32, c_stream]),
-    "rbr_textcnn_row_grad_partials": (C.c_size_t, []),
+    "rbr_textcnn_row_grad_partials": (C.c_size_t, [_DESC]),
     "rbr_textcnn_token_list": (C.c_int, [_DESC, C.c_void_p, _PP, _PP, _PP, C.POINTER(i32)]),
     "rbr_textcnn_prod_prepare_ids": (C.c_int, [_DESC, i32, C.POINTER(IdSet), C.c_void_p, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p,
                                                c_stream]),

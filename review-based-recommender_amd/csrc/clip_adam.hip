@@ -50,6 +50,7 @@ struct OptTable {
 // early update of the batch's absent rows (g = 0) must produce the same bits for the same inputs.
 struct AdamK { float coef, w1, beta2, w2, step_size, bc2_sqrt, eps; };
 __device__ __forceinline__ void adam1(const AdamK& K, float& g, float& m, float& v, float& p) {
+#pragma clang fp contract(off)      // HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler fuses them per call site
     g = __fmul_rn(g, K.coef);
     m = __fadd_rn(m, __fmul_rn(K.w1, __fsub_rn(g, m)));
     v = __fadd_rn(__fmul_rn(K.beta2, v), __fmul_rn(__fmul_rn(K.w2, g), g));

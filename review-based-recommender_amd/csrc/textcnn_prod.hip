@@ -1047,7 +1047,7 @@ extern "C" int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws
 //   RBR_G_BUILD | RBR_G_PRODUCT   the phases to run;
 //   RBR_G_ACCUMULATE              the rows are added to the dense `dtable`;
 //   RBR_G_ROWS                    `dtable` is the COMPACT gradient [list rows, D] (row r = token tok_of_row[r]; absent tokens have
-//                                 no row) and sq_part[rbr_textcnn_row_grad_partials()] receives per-workgroup sums of squares;
+//                                 no row) and sq_part[rbr_textcnn_row_grad_partials(d)] receives per-workgroup sums of squares;
 //   RBR_G_ZEROED                  G's rows are zero already (rbr_textcnn_prod_pool_zero cleared them in the forward).
 extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
@@ -1066,7 +1066,12 @@ extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const i
                                flags & (kGBuild | kGProduct | kGAccumulate | kGRows | kGZeroed), sq_part);
 }
 
-extern "C" size_t rbr_textcnn_row_grad_partials(void) { return kGtwMaxBlocks; }
+// = the grid of the product kernel: one partial per workgroup, every one of them written
+extern "C" size_t rbr_textcnn_row_grad_partials(const rbr_textcnn_desc* d) {
+    ProdLayout Lo;
+    if (!prod_applicable(d) || !prod_layout(d, Lo)) return 0;
+    return (size_t)std::min(Lo.cap, kGtwMaxBlocks);
+}
 
 // Where the forward left the token list inside `fwd_ws` (the layout is private): row_of_token [V] (dense row or -1), the
 // device count of listed rows, tok_of_row [cap]; cap = rows the compact gradient must have room for.

@@ -407,7 +407,7 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
             check(L_.rbr_textcnn_token_list(C.byref(desc), S.prod_ws.data_ptr(), C.byref(rot), None, None, C.byref(cap)),
                   "rbr_textcnn_token_list")
             rows = torch.empty(cap.value, table.shape[1], dtype=F32, device=dev)
-            sq = torch.empty(L_.rbr_textcnn_row_grad_partials(), dtype=F32, device=dev)
+            sq = torch.empty(L_.rbr_textcnn_row_grad_partials(C.byref(desc)), dtype=F32, device=dev)   # one per workgroup
             flags |= _lib.G_ROWS
         out = rows if rows is not None else dtable
         if dwg_floats:

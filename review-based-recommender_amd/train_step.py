@@ -72,6 +72,8 @@ class HipClipAdam(torch.optim.Optimizer):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             row_grads = False         # a data-parallel exchange reads every gradient as a dense .grad
+        if os.environ.get("RBR_ROW_GRADS", "1") == "0":
+            row_grads = False
         if row_grads:
             for g in self.param_groups:
                 for p in g["params"]:

@@ -141,21 +141,25 @@ def test_fused_encoder_head_equals_the_separate_functions(cfgname, edge):
 
 def test_fused_path_reports_out_of_range_ids():
     """The id range check that rides in the fused prepare launch raises the same IndexError at the next check point."""
-    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd import _lib, functional as RF
     cfg = synth.DEEPCONN_CFGS["cfg1"]
     m = _deepconn(cfg).eval()
     args, _ = _batch(cfg, 1)
-    assert m._fused_ok(args[0], args[1])
-    bad = list(args)
-    bad[0] = bad[0].clone()
-    bad[0][0, 0] = cfg["V"]                    # one past the table
-    with torch.no_grad():
-        m(*bad)
-    with pytest.raises(IndexError):
-        RF.check_id_errors()
-    with torch.no_grad():
-        m(*args)
-    RF.check_id_errors()                       # clean again
+    _lib.lib().rbr_set_conv_mode(2)
+    try:
+        assert m._fused_ok(args[0], args[1])
+        bad = list(args)
+        bad[0] = bad[0].clone()
+        bad[0][0, 0] = cfg["V"]                    # one past the table
+        with torch.no_grad():
+            m(*bad)
+        with pytest.raises(IndexError):
+            RF.check_id_errors()
+        with torch.no_grad():
+            m(*args)
+        RF.check_id_errors()                       # clean again
+    finally:
+        _lib.lib().rbr_set_conv_mode(0)
 
 
 def _graphed_vs_golden(model, g, args, ratings, cap_args, cap_ratings, tol_max=1e-3):
