@@ -117,18 +117,15 @@ int rbr_textcnn_prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, cons
 int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream);
 int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                           float* pval, int32_t* pidx, void* ws, void* stream);
-/* Step-level fusions of the same stages (round 3; each removes a launch from a training step):
+/* Step-level fusion of the prepare stage (round 3; removes a launch from a training step):
  *   prod_prepare_ids: prepare with the model's id range check (rbr_sanitize_ids below, nn.Embedding's IndexError,
  *            deepconn/layers.py:23) in its first launch.  `sets` (HOST array) are the forward's raw id tensors and their clean
  *            copies; `ids` = sets[0].out must hold the conv's d->n_docs * d->L token ids (one set, or two adjacent = both towers);
- *   prod_pool_zero: pool whose launch also clears the rows of the backward's G in `bwd_ws`
- *            (rbr_textcnn_bwd_prod_ws_bytes(d) bytes, allocated by the forward): the backward passes RBR_G_ZEROED. */
+ */
 struct rbr_id_set;
 int rbr_textcnn_prod_prepare_ids(const rbr_textcnn_desc* d, int32_t n_sets, const struct rbr_id_set* sets, int64_t* err,
                                  const int64_t* ids, const uint8_t* mask, const float* const* W, int32_t* pidx, void* ws,
                                  void* stream);
-int rbr_textcnn_prod_pool_zero(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                               float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream);
 
 /* Stage 3: reduce the slabs of each document, add the conv bias, apply the activation.
  * feat[n_docs, C] (C = sum ch[w]); argmax[n_docs, C] = first position attaining the max.
@@ -195,7 +192,8 @@ int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd
  *                                [V, D] output, deepconn/layers.py:22-24), and sq_part[rbr_textcnn_row_grad_partials(d)] receives
  *                                per-workgroup sums of squares of the rows in a fixed order (the table's share of
  *                                clip_grad_norm_'s norm).  Consumers: rbr_clip_adam_step_rows, rbr_row_grad_to_dense;
- *   RBR_G_ZEROED                 G's rows are already zero (rbr_textcnn_prod_pool_zero cleared them): no zero launch.
+ *   RBR_G_ZEROED                 G's rows are already zero (the caller cleared them in a launch of its own -- rbr_textcnn_bwd_g_rows
+ *                                says where they are; rbr_pair_head_bwd has a zero job for it): no zero launch here.
  * sq_part is only read with RBR_G_ROWS; dgate as for rbr_textcnn_bwd_dtable_prod. */
 #define RBR_G_BUILD 1
 #define RBR_G_PRODUCT 2
@@ -206,6 +204,8 @@ int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids
                                    const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                    float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream);
 size_t rbr_textcnn_row_grad_partials(const rbr_textcnn_desc* d);
+int rbr_textcnn_bwd_g_rows(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, const int32_t** n_rows, int32_t* max_rows,
+                           int32_t* row_f4, float** G);
 /* Device addresses of the forward's token list inside `fwd_ws` (its layout is private): row_of_token [V] (list row or -1),
  * n_rows [1] (rows in the list), tok_of_row [cap]; *cap = rows a compact gradient must have room for.  Any out-pointer may be NULL. */
 int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, const int32_t** row_of_token, const int32_t** n_rows,
@@ -294,6 +294,13 @@ int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                       const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
                       const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream);
+/* The same launch with a zero job for extra workgroups: zero_base[0 .. min(*zero_rows, zero_max_rows) * zero_row_f4) float4 are
+ * cleared -- the encoder backward's G (rbr_textcnn_bwd_g_rows), which runs next and would otherwise need a launch for it. */
+int rbr_pair_head_bwd_zero(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                           const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                           const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                           const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, const int32_t* zero_rows,
+                           int32_t zero_max_rows, int32_t zero_row_f4, float* zero_base, void* stream);
 
 /* ---- nn.Dropout multiplier (deepconn/layers.py:202, narre.py:73, dual_att/dual_att.py:33, simple_siamese/layers.py:7-68):
  *   out[i] = 0 with probability p, else 1/(1-p), i < n.  Philox4x32-10 keyed by `seed`, counter (i/4, call number).

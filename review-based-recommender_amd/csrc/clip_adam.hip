@@ -50,11 +50,13 @@ struct OptTable {
 // early update of the batch's absent rows (g = 0) must produce the same bits for the same inputs.
 struct AdamK { float coef, w1, beta2, w2, step_size, bc2_sqrt, eps; };
 __device__ __forceinline__ void adam1(const AdamK& K, float& g, float& m, float& v, float& p) {
-#pragma clang fp contract(off)      // HIP's __fmul_rn / __fadd_rn are plain operators: without this the compiler fuses them per call site
-    g = __fmul_rn(g, K.coef);
-    m = __fadd_rn(m, __fmul_rn(K.w1, __fsub_rn(g, m)));
-    v = __fadd_rn(__fmul_rn(K.beta2, v), __fmul_rn(__fmul_rn(K.w2, g), g));
-    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(K.step_size, m), __fadd_rn(__fdiv_rn(__fsqrt_rn(v), K.bc2_sqrt), K.eps)));
+    // plain operators under contract(off): every operation rounds on its own at every call site (HIP's __fmul_rn / __fadd_rn are
+    // ordinary inline functions whose operators carry the header's contraction permission -- they still fuse after inlining)
+#pragma clang fp contract(off)
+    g = g * K.coef;
+    m = m + K.w1 * (g - m);
+    v = K.beta2 * v + (K.w2 * g) * g;
+    p = p - (K.step_size * m) / (sqrtf(v) / K.bc2_sqrt + K.eps);
 }
 __device__ __forceinline__ AdamK adam_constants(float coef, float lr, float beta1, float beta2, float eps, double t) {
     const float bc1 = (float)(1.0 - pow((double)beta1, t));
@@ -119,6 +121,10 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const OptTable T, long
     }
 }
 
+// MODE: 0 no row-gradient tensor (every tensor dense), 1 one table with a compact row gradient (all its rows updated here),
+// 2 the same with the absent rows already updated (touched_only).  Template parameter: as run-time branches of one kernel the
+// three forms cost the dense one half its occupancy (226 VGPRs against 104).
+template <int MODE>
 __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long nchunks, const float* __restrict__ partials,
                                                         int npartials, float max_norm, float lr, float beta1, float beta2,
                                                         float eps, const float* __restrict__ step, float* __restrict__ gnorm_out) {
@@ -140,77 +146,76 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
         float* g = T.g[k] + e0;
         float* m = T.m[k] + e0;
         float* v = T.v[k] + e0;
-        if (k == T.rows_k && T.touched_only) {      // chunk = 4096 elements of the COMPACT gradient: rows of listed tokens only
+        if (MODE == 2 && k == T.rows_k) {      // chunk = 4096 elements of the COMPACT gradient: rows of listed tokens only
             const int D = T.rows_D;
             const long n_el = (long)min(*T.n_rows, (int)(T.n[k] / D)) * D;
             if (e0 >= n_el) continue;
-            const long n4r = (min((long)kOptChunk, n_el - e0)) >> 2;
+            const int n4r = (int)((min((long)kOptChunk, n_el - e0)) >> 2);
             constexpr int U = 4;
             float4 G[U], M[U], V[U], P[U];
             long poff[U];
+            unsigned ge[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long i = threadIdx.x + 256 * u;
-                poff[u] = -1;
-                if (i < n4r) {
-                    const unsigned e = (unsigned)(e0 + 4 * i);
-                    const unsigned r = e / (unsigned)D;
-                    poff[u] = (long)T.tok_of_row[r] * D + (e - r * (unsigned)D);
-                    G[u] = *reinterpret_cast<const float4*>(T.grows + e);
-                }
+            for (int u = 0; u < U; ++u) {                    // unconditional loads (see above): past the end repeats the last float4
+                const int i = min((int)threadIdx.x + 256 * u, n4r - 1);
+                ge[u] = (unsigned)(e0 + 4 * i);
+                const unsigned r = ge[u] / (unsigned)D;
+                poff[u] = (long)T.tok_of_row[r] * D + (ge[u] - r * (unsigned)D);
+                G[u] = *reinterpret_cast<const float4*>(T.grows + ge[u]);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (poff[u] >= 0) {
-                    M[u] = *reinterpret_cast<const float4*>(T.m[k] + poff[u]); V[u] = *reinterpret_cast<const float4*>(T.v[k] + poff[u]);
-                    P[u] = *reinterpret_cast<const float4*>(T.p[k] + poff[u]);
-                }
+            for (int u = 0; u < U; ++u) {
+                M[u] = *reinterpret_cast<const float4*>(T.m[k] + poff[u]); V[u] = *reinterpret_cast<const float4*>(T.v[k] + poff[u]);
+                P[u] = *reinterpret_cast<const float4*>(T.p[k] + poff[u]);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (poff[u] < 0) continue;
+                if ((int)threadIdx.x + 256 * u >= n4r) continue;
                 RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
                 RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
-                if (clipped) *reinterpret_cast<float4*>(T.grows + e0 + 4 * (threadIdx.x + 256 * u)) = G[u];
+                if (clipped) *reinterpret_cast<float4*>(T.grows + ge[u]) = G[u];
                 *reinterpret_cast<float4*>(T.m[k] + poff[u]) = M[u];
                 *reinterpret_cast<float4*>(T.v[k] + poff[u]) = V[u];
                 *reinterpret_cast<float4*>(T.p[k] + poff[u]) = P[u];
             }
             continue;
         }
-        if (k == T.rows_k) {                 // compact-gradient table (rows_D % 4 == 0 and 16-byte aligned pointers: checked on the host)
+        if (MODE == 1 && k == T.rows_k) {                 // compact-gradient table (rows_D % 4 == 0 and 16-byte aligned pointers: checked on the host)
+            // every load is UNCONDITIONAL (an index past the chunk repeats its last float4, an absent token reads row 0 of the
+            // compact gradient and discards it): a load behind a branch makes the compiler drain all loads in flight first
             const int D = T.rows_D;
-            const long n4r = n >> 2;         // numel = V * D is a multiple of 4
-            for (long i0 = 0; i0 < n4r; i0 += 1024) {
-                constexpr int U = 4;
-                float4 G[U], M[U], V[U], P[U];
-                long goff[U];
+            const int n4r = (int)(n >> 2);   // numel = V * D is a multiple of 4
+            constexpr int U = 4;
+            float4 G[U], M[U], V[U], P[U];
+            long goff[U];
+            int idx[U];
+            bool have[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const long i = i0 + threadIdx.x + 256 * u;
-                    goff[u] = -1;
-                    if (i < n4r) {
-                        const unsigned e = (unsigned)(e0 + 4 * i);          // numel < 2^32: checked on the host
-                        const unsigned tok = e / (unsigned)D;
-                        const int r = T.row_of_token[tok];
-                        if (r >= 0) goff[u] = (long)r * D + (e - tok * (unsigned)D);
-                        M[u] = reinterpret_cast<float4*>(m)[i]; V[u] = reinterpret_cast<float4*>(v)[i];
-                        P[u] = reinterpret_cast<float4*>(p)[i];
-                    }
-                }
+            for (int u = 0; u < U; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                idx[u] = min(i, n4r - 1);
+                const unsigned e = (unsigned)(e0 + 4 * idx[u]);              // numel < 2^32: checked on the host
+                const unsigned tok = e / (unsigned)D;
+                const int r = T.row_of_token[tok];
+                have[u] = r >= 0;
+                goff[u] = (long)max(r, 0) * D + (e - tok * (unsigned)D);
+                M[u] = reinterpret_cast<float4*>(m)[idx[u]]; V[u] = reinterpret_cast<float4*>(v)[idx[u]];
+                P[u] = reinterpret_cast<float4*>(p)[idx[u]];
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    G[u] = (goff[u] >= 0) ? *reinterpret_cast<const float4*>(T.grows + goff[u]) : float4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < U; ++u) {
+                G[u] = *reinterpret_cast<const float4*>(T.grows + goff[u]);
+                if (!have[u]) G[u] = float4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const long i = i0 + threadIdx.x + 256 * u;
-                    if (i >= n4r) continue;
-                    RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
-                    RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
-                    if (clipped && goff[u] >= 0) *reinterpret_cast<float4*>(T.grows + goff[u]) = G[u];
-                    reinterpret_cast<float4*>(m)[i] = M[u];
-                    reinterpret_cast<float4*>(v)[i] = V[u];
-                    reinterpret_cast<float4*>(p)[i] = P[u];
-                }
+            for (int u = 0; u < U; ++u) {
+                if ((int)threadIdx.x + 256 * u >= n4r) continue;
+                RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
+                RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
+                if (clipped && have[u]) *reinterpret_cast<float4*>(T.grows + goff[u]) = G[u];
+                reinterpret_cast<float4*>(m)[idx[u]] = M[u];
+                reinterpret_cast<float4*>(v)[idx[u]] = V[u];
+                reinterpret_cast<float4*>(p)[idx[u]] = P[u];
             }
             continue;
         }
@@ -296,8 +301,12 @@ static int clip_adam_step(int32_t n_tensors, float* const* params, float* const*
     hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(nb1), dim3(256), 0, st, T, chunks, ws, step);
     RBR_CHECK_LAUNCH("grad_sqnorm launch");
     const int nb2 = (int)std::min<long>(chunks, 4096);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step,
-                       gnorm_out);
+    if (T.rows_k < 0)
+        hipLaunchKernelGGL(clip_adam_kernel<0>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
+    else if (!T.touched_only)
+        hipLaunchKernelGGL(clip_adam_kernel<1>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
+    else
+        hipLaunchKernelGGL(clip_adam_kernel<2>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
     RBR_CHECK_LAUNCH("clip_adam launch");
     return 0;
 }

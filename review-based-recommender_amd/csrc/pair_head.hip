@@ -155,39 +155,47 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
         if (t == 0) head_rng_ticket(tr, 0);
         return;
     }
+    // Pool epilogue of this pair's two documents in three memory round trips: (1) the slabs' activity flags, (2) EVERY slab
+    // partial of every channel slot at once (2 x wpd x nslots independent loads, ~20 per thread) into LDS, (3) the position of
+    // each slot's winning slab.  An inactive slab (all tokens masked) stands for a conv sum of exactly 0 at its first position.
     const int* flags = hp.pidx + (long)P.total_wt * P.nslots_total;
-    const int nslots = P.ntiles * kTile;
+    const int nslots = P.ntiles * kTile, wpd = P.wpd;
+    float* s_val = s_feat + 2 * P.C;                                   // [2][wpd][nslots]
+    int* s_flag = reinterpret_cast<int*>(s_val + 2 * wpd * nslots);    // [2][wpd]
+    for (int i = t; i < 2 * wpd; i += 256) {
+        const int side = i >= wpd, w = side ? i - wpd : i;
+        s_flag[i] = flags[(side * B + b) * wpd + w];
+    }
+    __syncthreads();
+    const float NEG = -__builtin_huge_valf();
+    for (int i = t; i < 2 * wpd * nslots; i += 256) {
+        const int side = i >= wpd * nslots, r = side ? i - wpd * nslots : i;
+        const int w = r / nslots, ls = r - w * nslots;
+        const long base = ((long)(side * B + b) * wpd + w) * P.nslots_total + (long)P.tile_base * kTile + ls;
+        float v = NEG;
+        if (P.slot_chan[ls] >= 0) {
+            const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
+            v = s_flag[side * wpd + w] ? hp.pval[base] : ((w * kTile < Lv) ? 0.f : NEG);
+        }
+        s_val[i] = v;
+    }
+    __syncthreads();
     for (int idx = t; idx < 2 * nslots; idx += 256) {
         const int side = idx >= nslots, ls = side ? idx - nslots : idx;
         const int doc = side * B + b;
         const int chan = P.slot_chan[ls];
         if (chan < 0) continue;
-        const long base = (long)doc * P.wpd * P.nslots_total + (long)P.tile_base * kTile + ls;
-        float best = -__builtin_huge_valf();
+        float best = NEG;
         int bw_tile = -1;
-        const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
-        for (int w0 = 0; w0 < P.wpd; w0 += 8) {
-            int fl[8];
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) fl[q] = (w0 + q < P.wpd) ? flags[doc * P.wpd + w0 + q] : 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fl[q] ? hp.pval[base + (long)(w0 + q) * P.nslots_total] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int w = w0 + q;
-                if (w >= P.wpd) break;
-                if (fl[q]) {
-                    if (v[q] > best) { best = v[q]; bw_tile = w; }
-                } else if (w * kTile < Lv && 0.f > best) {
-                    best = 0.f;
-                    bw_tile = -2 - w;
-                }
-            }
+        for (int w = 0; w < wpd; ++w) {                                // slabs in position order, first maximum wins
+            const float v = s_val[(side * wpd + w) * nslots + ls];
+            if (v > best) { best = v; bw_tile = w; }
         }
         int bidx = 0;
-        if (bw_tile >= 0) bidx = hp.pidx[base + (long)bw_tile * P.nslots_total];
-        else if (bw_tile <= -2) bidx = (-2 - bw_tile) * kTile;
+        if (bw_tile >= 0) {
+            if (s_flag[side * wpd + bw_tile]) bidx = hp.pidx[((long)doc * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
+            else bidx = bw_tile * kTile;
+        }
         const int bw = P.slot_w[ls];
         const float y = best + hp.bias.p[bw][chan - P.ch_off[bw]];
         const float f = (P.act == RBR_ACT_RELU) ? fmaxf(y, 0.f) : tanhf(y);
@@ -241,9 +249,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int K, cons
                                                        const float* __restrict__ drop, const float* __restrict__ ul,
                                                        const float* __restrict__ il, const float* __restrict__ d_pred,
                                                        int pad_u, int pad_i, const rbr_head_grads g,
-                                                       float* __restrict__ d_uf, float* __restrict__ d_if) {
+                                                       float* __restrict__ d_uf, float* __restrict__ d_if, int nb_work,
+                                                       const int* __restrict__ zero_rows, int zero_max_rows, int zero_row_f4,
+                                                       float4* __restrict__ zero_base) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // pair role: [2][K4]; reduce role: [3][8][32]
     const int t = threadIdx.x;
+    if ((int)blockIdx.x >= nb_work) {           // zero job (rbr_pair_head_bwd_zero): the workgroups behind the head's own
+        const long n = (long)min(*zero_rows, zero_max_rows) * zero_row_f4, nb = gridDim.x - nb_work;
+        for (long k = (long)(blockIdx.x - nb_work) * 256 + t; k < n; k += nb * 256) zero_base[k] = float4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     if ((int)blockIdx.x < B) {
         const int K4 = (K + 3) & ~3;
         const int b = blockIdx.x;
@@ -459,7 +474,9 @@ extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pv
     for (int w = 0; w < d->n_widths; ++w) hp.bias.p[w] = bias[w];
     HeadMse mse{target, loss, d_pred_unit, ticket};
     const int zblocks = zero_n > 0 ? (int)std::min<long>((zero_n + 1023) / 1024, 256) : 0;
-    hipLaunchKernelGGL(head_fwd_pool_kernel, dim3(B + zblocks), dim3(256), (size_t)2 * C * sizeof(float), (hipStream_t)stream,
+    const size_t lds = ((size_t)2 * C + (size_t)2 * plans[0].wpd * plans[0].ntiles * kTile + (size_t)2 * plans[0].wpd) * sizeof(float);
+    if (lds > 60 * 1024) { set_error("pair_head_fwd_pool: %zu bytes of LDS for the slab partials (documents too long)", lds); return RBR_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(head_fwd_pool_kernel, dim3(B + zblocks), dim3(256), lds, (hipStream_t)stream,
                        plans[0], hp, B, K, reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p,
                        (p_drop > 0.f) ? nullptr : drop, ul, il, pred, tr, mse);
     RBR_CHECK_LAUNCH("pair_head_fwd_pool launch");
@@ -468,22 +485,39 @@ extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pv
 
 extern "C" size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K) { (void)B; (void)K; return 0; }
 
-extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
-                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
-                                 const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
-                                 const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
+extern "C" int rbr_pair_head_bwd_zero(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                      const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                                      const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                                      const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, const int32_t* zero_rows,
+                                      int32_t zero_max_rows, int32_t zero_row_f4, float* zero_base, void* stream) {
     if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
     if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !d_pred || !g || !d_ufeat || !d_ifeat) {
         set_error("null pointer");
         return RBR_ERR_BAD_ARG;
     }
-    (void)ws;      // no longer needed: the reduction blocks recompute d_l instead of reading it back
+    const bool zero = zero_base != nullptr;
+    if (zero && (!zero_rows || zero_max_rows <= 0 || zero_row_f4 <= 0 || (((uintptr_t)zero_base) & 15) != 0)) {
+        set_error("pair_head_bwd_zero: malformed zero job");
+        return RBR_ERR_BAD_ARG;
+    }
     const size_t lds = std::max((size_t)2 * ((K + 3) & ~3), (size_t)3 * 8 * 32) * sizeof(float);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(B + 2 * (H + 1))), dim3(256), lds, (hipStream_t)stream, B, H, K, u_feat,
+    const int nb_work = B + 2 * (H + 1);
+    const int nb_zero = zero ? (int)std::min<long>(((long)zero_max_rows * zero_row_f4 + 1023) / 1024, 2048) : 0;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nb_work + nb_zero)), dim3(256), lds, (hipStream_t)stream, B, H, K, u_feat,
                        i_feat, reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop,
-                       ul, il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat);
+                       ul, il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, nb_work, zero_rows, zero_max_rows, zero_row_f4,
+                       reinterpret_cast<float4*>(zero_base));
     RBR_CHECK_LAUNCH("pair_head_bwd launch");
     return 0;
+}
+
+extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                                 const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                                 const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
+    (void)ws;      // no longer needed: the reduction blocks recompute d_l instead of reading it back
+    return rbr_pair_head_bwd_zero(B, H, K, u_feat, i_feat, u_id, i_id, p, drop, ul, il, d_pred, pad_u, pad_i, g, d_ufeat, d_ifeat, nullptr,
+                                  0, 0, nullptr, stream);
 }
 
 // ---- D-ATT's rating: ratings[b] = sum_k u[b,k] * i[b,k] (dual_att.py:58) over a STACKED [2B, K] feature block (user rows

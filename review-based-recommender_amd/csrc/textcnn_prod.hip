@@ -165,24 +165,18 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // segments start at any float
 
-// The first `nb_zero` workgroups of the launch (training forwards) clear the rows of the backward's G instead: the gather is
-// bound by L2 requests and leaves HBM idle, so the 64 MB of zeroes ride along (they were a launch of their own, zero_g_rows).
+// (Measured and dropped in round 3: clearing the backward's G with extra workgroups of this launch -- 59.6 us against 42.7 + 10.9
+// for the separate zero launch, and, worse, G is then cold when the backward reads it: g_times_w 59 -> 72 us.)
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
                                                           const int* __restrict__ row_of_token, const float* __restrict__ T,
                                                           const int* __restrict__ sched, float* __restrict__ pval,
-                                                          int* __restrict__ pidx, int nb_zero, const int* __restrict__ counter,
-                                                          int KG4, f32x4* __restrict__ Gz) {
+                                                          int* __restrict__ pidx) {
     __shared__ int s_row[kWavesPerWG][kTile + kMaxKF];
     __shared__ float s_gate[kWavesPerWG][kTile + kMaxKF];
-    if ((int)blockIdx.x < nb_zero) {
-        const long n = (long)min(*counter, A.cap) * KG4;
-        for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)nb_zero * 256) Gz[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_active = sched[2 * (long)P.total_wt];
-    const int slot_in_list = ((int)blockIdx.x - nb_zero) * kWavesPerWG + wave;
+    const int slot_in_list = blockIdx.x * kWavesPerWG + wave;
     if (slot_in_list >= n_active) return;                       // wave-uniform; no block barrier below
     const int wt = sched[P.total_wt + slot_in_list];
     const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
@@ -1048,7 +1042,7 @@ extern "C" int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws
 //   RBR_G_ACCUMULATE              the rows are added to the dense `dtable`;
 //   RBR_G_ROWS                    `dtable` is the COMPACT gradient [list rows, D] (row r = token tok_of_row[r]; absent tokens have
 //                                 no row) and sq_part[rbr_textcnn_row_grad_partials(d)] receives per-workgroup sums of squares;
-//   RBR_G_ZEROED                  G's rows are zero already (rbr_textcnn_prod_pool_zero cleared them in the forward).
+//   RBR_G_ZEROED                  G's rows are zero already (the caller cleared them: rbr_textcnn_bwd_g_rows).
 extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                               float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream) {
@@ -1064,6 +1058,23 @@ extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const i
                   RBR_G_ZEROED == kGZeroed, "public flags = internal phases");
     return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream,
                                flags & (kGBuild | kGProduct | kGAccumulate | kGRows | kGZeroed), sq_part);
+}
+
+// Where the backward's G lives inside `bwd_ws`, for a caller that clears its rows in a launch of its own (the rating head's
+// backward: rbr_pair_head_bwd's zero job) and then passes RBR_G_ZEROED: rows to clear = min(*n_rows, max_rows), row_f4 float4 each.
+extern "C" int rbr_textcnn_bwd_g_rows(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, const int32_t** n_rows, int32_t* max_rows,
+                                      int32_t* row_f4, float** G) {
+    ProdLayout Lo;
+    ProdBwdLayout B;
+    if (!fwd_ws || !bwd_ws || !prod_applicable(d) || !prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) {
+        set_error("no token-product backward for this shape");
+        return RBR_ERR_UNSUPPORTED;
+    }
+    if (n_rows) *n_rows = reinterpret_cast<const int32_t*>(static_cast<char*>(fwd_ws) + Lo.counter);
+    if (max_rows) *max_rows = Lo.cap;
+    if (row_f4) *row_f4 = B.KG / 4;
+    if (G) *G = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + B.G);
+    return 0;
 }
 
 // = the grid of the product kernel: one partial per workgroup, every one of them written
@@ -1344,8 +1355,8 @@ extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* ta
 
 // Stage 3 (one kernel): per active wave-tile of the real documents (work list in the tail of `pidx`, built by stage 1),
 // add the kz rows of T per position, max / first argmax.
-static int prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                     float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream) {
+extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
+                                     float* pval, int32_t* pidx, void* ws, void* stream) {
     ConvPlan plans[kMaxGroups];
     const int ngroups = build_plans(d, plans);
     if (!ngroups) return RBR_ERR_BAD_ARG;
@@ -1355,33 +1366,10 @@ static int prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_
     hipStream_t st = (hipStream_t)stream;
     const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
-    int nb_zero = 0, KG4 = 0;
-    f32x4* Gz = nullptr;
-    if (bwd_ws != nullptr) {
-        ProdBwdLayout B;
-        if (!prod_bwd_layout(d, S.Lo, B)) { set_error("token-product backward does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
-        Gz = reinterpret_cast<f32x4*>(static_cast<char*>(bwd_ws) + B.G);
-        KG4 = B.KG / 4;
-        nb_zero = 512;
-    }
-    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items + nb_zero), dim3(256), 0, st, plans[0], S.A,
-                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx, nb_zero,
-                       S.counter, KG4, Gz);
+    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
+                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
     RBR_CHECK_LAUNCH("textcnn gather_pool launch");
     return 0;
-}
-
-extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                     float* pval, int32_t* pidx, void* ws, void* stream) {
-    return prod_pool(d, ids, mask, gate, pval, pidx, ws, nullptr, stream);
-}
-
-// rbr_textcnn_prod_pool whose launch also clears the rows of G in `bwd_ws` (rbr_textcnn_bwd_prod_ws_bytes(d) bytes, allocated by
-// the forward of a training step): the backward then passes RBR_G_ZEROED and has no zero_g_rows launch.
-extern "C" int rbr_textcnn_prod_pool_zero(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                          float* pval, int32_t* pidx, void* ws, void* bwd_ws, void* stream) {
-    if (!bwd_ws) { set_error("null bwd_ws"); return RBR_ERR_BAD_ARG; }
-    return prod_pool(d, ids, mask, gate, pval, pidx, ws, bwd_ws, stream);
 }
 
 // ---- conv weight / bias gradient from G (see dw_from_g_kernel): after rbr_textcnn_bwd_dtable_prod built G in `bwd_ws`

@@ -691,7 +691,8 @@ def encode_head_applicable(table, n_docs, L, kernel_sizes, channels, padding_idx
     pool-epilogue launch covers every channel slot."""
     if not table.is_cuda or table.dtype != F32 or n_docs % 2 or os.environ.get("RBR_FUSED_STEP", "1") == "0":
         return False
-    if (sum(channels) + 31) // 32 > 8:
+    ntiles, wpd = (sum(channels) + 31) // 32, (L + 31) // 32
+    if ntiles > 8 or (2 * sum(channels) + 2 * wpd * ntiles * 32 + 2 * wpd) * 4 > 60 * 1024:      # rbr_pair_head_fwd_pool's limits
         return False
     desc = _lib.make_desc(n_docs, L, table.shape[1], table.shape[0], kernel_sizes, channels, PAD_SAME, ACT_RELU, padding_idx)
     return _lib.lib().rbr_textcnn_fwd_ws_bytes(C.byref(desc)) > 0
@@ -761,29 +762,20 @@ class _EncodeHead(torch.autograd.Function):
                   "rbr_textcnn_prod_prepare")
         if ev is not None:
             ev.record()
-        # the backward's G: allocated now so that the gather launch clears its rows (no zero launch in the backward)
-        bws = None
-        if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS:
-            bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc))
-            if bws_bytes:
-                bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
-                # the token list exists: an optimizer that takes this table's gradient in row form may start on the rows of the
-                # tokens the batch does NOT hold right away, beside the GEMM (train_step.HipClipAdam.on_token_list)
-                row_sink = _ROW_GRAD_SINKS.get(table_c.data_ptr())
-                if row_sink is not None and row_sink.wants_row_grad(table_c):
-                    row_sink.on_token_list(table_c, desc, prod_ws)
+        # the token list exists: an optimizer that takes this table's gradient in row form may start on the rows of the tokens
+        # the batch does NOT hold right away, beside the GEMM (train_step.HipClipAdam.on_token_list)
+        if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS \
+                and L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)):
+            row_sink = _ROW_GRAD_SINKS.get(table_c.data_ptr())
+            if row_sink is not None and row_sink.wants_row_grad(table_c):
+                row_sink.on_token_list(table_c, desc, prod_ws)
         ev = TIMER.record("textcnn_prod_table")
         check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
         if ev is not None:
             ev.record()
         ev = TIMER.record("textcnn_prod_pool")
-        if bws is not None:
-            check(L_.rbr_textcnn_prod_pool_zero(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,
-                                                dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, bws.data_ptr(), st),
-                  "rbr_textcnn_prod_pool_zero")
-        else:
-            check(L_.rbr_textcnn_prod_pool(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,
-                                           dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
+        check(L_.rbr_textcnn_prod_pool(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), None,
+                                       dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
         if ev is not None:
             ev.record()
         # ---- pool epilogue + rating head (+ loss)
@@ -823,7 +815,7 @@ class _EncodeHead(torch.autograd.Function):
         if ev is not None:
             ev.record()
         ctx.conv = _ConvSaved(table=table_c, ids=ids, packed=None, feat=feat, argmax=argmax, mask8=mask8, gate=None, ws=ws_,
-                              desc=desc, prod_ws=prod_ws, fanout_acc=None, bws=bws)
+                              desc=desc, prod_ws=prod_ws, fanout_acc=None, bws=None)
         ctx.head = (u_id, i_id, ul, il, head, drop_t, flat_zero, d_unit)
         ctx.dims = (B, Ctot, K, int(pad_u), int(pad_i), n_widths)
         ctx.set_materialize_grads(False)
@@ -856,13 +848,22 @@ class _EncodeHead(torch.autograd.Function):
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, _HEAD_NAMES)])
         d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
         feat = S.feat
-        check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
-                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
-                                   dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
-                                   dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
-                                   dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), None,
-                                   current_stream()), "rbr_pair_head_bwd")
         need_conv = any(ctx.needs_input_grad[12:12 + 2 * n_widths]) or ctx.needs_input_grad[0]
+        # the conv backward's G is cleared by extra workgroups of THIS launch (it was a launch of its own): right in front of its
+        # use, so that its lines are still in the Infinity Cache when build_g and g_times_w come for them
+        zrows, zmax, zf4, zbase = C.c_void_p(), C.c_int32(0), C.c_int32(0), C.c_void_p()
+        if ctx.needs_input_grad[0] and S.table.data_ptr() not in _TAP_SINKS:
+            bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(S.desc))
+            if bws_bytes:
+                S.bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+                check(L_.rbr_textcnn_bwd_g_rows(C.byref(S.desc), S.prod_ws.data_ptr(), S.bws.data_ptr(), C.byref(zrows), C.byref(zmax),
+                                                C.byref(zf4), C.byref(zbase)), "rbr_textcnn_bwd_g_rows")
+        check(L_.rbr_pair_head_bwd_zero(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
+                                        dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                        dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                        dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
+                                        dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), zrows.value,
+                                        zmax.value, zf4.value, zbase.value, current_stream()), "rbr_pair_head_bwd")
         if need_conv:
             dtable, _, dWs, dbs = _textcnn_backward(S, d_pair, ctx.needs_input_grad[0], False)
         else:
