@@ -527,6 +527,20 @@ def _side_stream(dev):
     return s
 
 
+_SIDE_STREAMS2: dict = {}
+
+
+def _side_stream2(dev):
+    """A third stream of `dev`: the optimizer's early row update (its own queue: the weight-gradient chain on the second stream
+    must not wait behind it)."""
+    if os.environ.get("RBR_BWD_OVERLAP", "1") == "0":
+        return None
+    s = _SIDE_STREAMS2.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS2[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def _join(event) -> None:
     if event is not None:
         torch.cuda.current_stream().wait_event(event)
@@ -763,12 +777,18 @@ class _EncodeHead(torch.autograd.Function):
         if ev is not None:
             ev.record()
         # the token list exists: an optimizer that takes this table's gradient in row form may start on the rows of the tokens
-        # the batch does NOT hold right away, beside the GEMM (train_step.HipClipAdam.on_token_list)
+        # the batch does NOT hold right away (train_step.HipClipAdam.on_token_list) -- launched behind the gather below, so that
+        # its HBM stream runs under the latency-bound head kernels and the atomics-bound G build (RBR_EARLY_AT=gemm: here,
+        # under the GEMM, which it slows by as much as it saves)
+        row_sink = None
         if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS \
                 and L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)):
             row_sink = _ROW_GRAD_SINKS.get(table_c.data_ptr())
-            if row_sink is not None and row_sink.wants_row_grad(table_c):
-                row_sink.on_token_list(table_c, desc, prod_ws)
+            if row_sink is not None and not row_sink.wants_row_grad(table_c):
+                row_sink = None
+        early_at_gemm = os.environ.get("RBR_EARLY_AT", "head") == "gemm"
+        if row_sink is not None and early_at_gemm:
+            row_sink.on_token_list(table_c, desc, prod_ws)
         ev = TIMER.record("textcnn_prod_table")
         check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
         if ev is not None:
@@ -778,6 +798,8 @@ class _EncodeHead(torch.autograd.Function):
                                        dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
         if ev is not None:
             ev.record()
+        if row_sink is not None and not early_at_gemm:
+            row_sink.on_token_list(table_c, desc, prod_ws)
         # ---- pool epilogue + rating head (+ loss)
         K = head[0].shape[1]
         hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(head, _HEAD_NAMES)])

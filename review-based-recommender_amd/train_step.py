@@ -106,7 +106,7 @@ class HipClipAdam(torch.optim.Optimizer):
             return                        # a second conv over the table, or gradient accumulation: the one-launch form
         group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
         st_ = self._state_of(p)
-        side = RF._side_stream(p.device)
+        side = RF._side_stream2(p.device)
         if side is None:
             return
         L_ = _lib.lib()
