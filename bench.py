@@ -290,18 +290,61 @@ def time_gemm_launches(model, args, reps=50):
     return e0.elapsed_time(e1) / reps
 
 
-def time_optimizer_launches(opt, reps=50):
-    """The same for rbr_clip_adam_step (its two kernels: gradient norm, clip + Adam) on the gradients the last backward
-    left in place.  The parameters keep moving: run it after everything else.  Returns ms per call."""
-    for _ in range(3):
-        opt.clip_and_step(5.0)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        opt.clip_and_step(5.0)
-    e1.record()
+def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
+    """In-step time of rbr_clip_adam_step[_rows] (its two kernels: gradient norm, clip + Adam): HIP events on the launch
+    stream around every call, over `n_sets` ROTATING copies of the model + Adam state + gradients (3 x 210 MB: the working set
+    exceeds the 256 MiB Infinity Cache, as it does inside a step, where the conv kernels have pushed p / m / v out since the
+    last update).  Each set holds the gradients one backward left behind (the table's in compact row form); the row gradient is
+    restored from a copy between calls (outside the event pairs) so that every call clips as the first one did.  The queue
+    stays full, so an event pair holds kernel time only.  Returns (ms per call, bytes per call as the kernels move them)."""
+    from review_based_recommender_amd.train_step import HipClipAdam, _forward_loss_backward, make_optimizer
+    sets = []
+    for k in range(n_sets):
+        m = build_model(cfg, device)
+        m.train()
+        o = make_optimizer(m, hip_clip_adam=True)
+        a, r = batch_on(cfg, 200 + k, device)
+        o.zero_grad()
+        _forward_loss_backward(m, a, r)
+        rows = [(rg.rows, rg.rows.clone()) for rg in o._row_grads.values()] if isinstance(o, HipClipAdam) else []
+        dense = [(p.grad, p.grad.clone()) for p in m.parameters() if p.grad is not None]
+        sets.append((m, o, rows + dense))
+    for _, o, _ in sets:
+        o.clip_and_step(5.0)
+    pairs = []
+    for i in range(reps):
+        _, o, saved = sets[i % n_sets]
+        for dst, src in saved:
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o.clip_and_step(5.0)
+        e1.record()
+        pairs.append((e0, e1))
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    ms = sorted(a.elapsed_time(b) for a, b in pairs)
+    m, o, _ = sets[0]
+    n_par = sum(p.numel() for p in m.parameters())
+    row_elems = sum(int(rg.rows.shape[1]) * n for rg, n in ((rg, _listed_rows(rg)) for rg in o._row_grads.values()))
+    table_elems = sum(p.numel() for p in o._row_grads)
+    # p, m, v read + written for every parameter; g read twice (norm, update) and written once (clipped) where it exists:
+    # dense gradients of the other tensors, the listed rows of the table (its other rows are never materialised)
+    nbytes = 24.0 * n_par + 12.0 * ((n_par - table_elems) + row_elems)
+    del sets
+    torch.cuda.empty_cache()
+    return ms[len(ms) // 2], nbytes, row_elems, table_elems
+
+
+def _listed_rows(rg) -> int:
+    """Rows of a compact row gradient that hold a token of the batch (counted on the device, read back once)."""
+    return int(_row_of_token_tensor(rg).ge(0).sum().item())
+
+
+def _row_of_token_tensor(rg):
+    """row_of_token [V] of a RowGradient as a tensor (it lives inside the forward's workspace, which rg keeps alive)."""
+    ws = rg._keep
+    off = rg.row_of_token_ptr - ws.data_ptr()
+    return ws[off:off + 4 * rg.V].view(torch.int32)
 
 
 def dense_mode_env() -> bool:
@@ -481,10 +524,11 @@ def main():
     ksum = _lib.TIMER.summary()
 
     gemm_ms = opt_ms = None
+    opt_bytes = opt_rows = opt_table = 0
     if rank == 0 and not dense_mode_env():
         gemm_ms = time_gemm_launches(model, args)
         if not a.torch_optim:
-            opt_ms = time_optimizer_launches(opt)
+            opt_ms, opt_bytes, opt_rows, opt_table = time_optimizer_launches(cfg, device)
 
     # forward-only (eval) rate, reported beside the headline
     model.eval()
@@ -555,7 +599,8 @@ def main():
                                                      "v_mfma_f32_32x32x16_bf16, f32 accumulate (f32-class accuracy: parity tests at 1e-4)",
                                            "bf16x2": "2 bf16 planes, 3 plane products, f32 accumulate",
                                            "bf16": "operands rounded to bf16, f32 accumulate (reduced precision)"}[precision],
-                       "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else "HipClipAdam (clip + Adam, 2 launches)",
+                       "optimizer": "torch clip_grad_norm_ + fused Adam" if a.torch_optim else
+                                    "HipClipAdam (clip + Adam, 2 launches; word-table gradient in compact row form)",
                        "grad_exchange": None if world == 1 else (exchange_note or f"RCCL all-reduce, {a.comm_dtype} wire format, before the clip")},
             "fwd_only_pairs_per_s": round(cfg["B"] / fwd_s, 1),
             "fwd_only_graph_pairs_per_s": None if fwd_graph_s is None else round(cfg["B"] / fwd_graph_s, 1),
@@ -593,14 +638,15 @@ def main():
             # the prepare stage of the b16 arithmetics adds the weight-plane pack launch in front of the GEMM; the events
             # bracket rbr_textcnn_prod_table alone
             ach = nprod * gemm_flops / (gemm_ms * 1e-3) / 1e12
-            gemm_pmc = "r02_prod_gemm_b16_pmc.json" if precision != "f32" else "r01_prod_table_pmc.json"
+            gemm_pmc = "r03_prod_gemm_b16_pmc.json" if precision != "f32" else "r01_prod_table_pmc.json"
             out["roofline_gemm"] = {
                 "bound": "mfma",
                 "kernel": ("prod_gemm_kernel<60> (v_mfma_f32_32x32x2_f32)" if precision == "f32" else
                            f"prod_gemm_b16_kernel<{nprod}> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product)")
                           + ": T = table[distinct tokens] @ Wprod, rows gathered by LDS-DMA",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": measured_traffic(gemm_pmc), "traffic_source": f"profiles/{gemm_pmc}",
+                "traffic": measured_traffic(gemm_pmc) or measured_traffic("r02_prod_gemm_b16_pmc.json"),
+                "traffic_source": f"profiles/{gemm_pmc} (r02_ when this round's pass is absent)",
                 "algorithmic_flops_per_launch": gemm_flops, "executed_mfma_flops_per_launch": nprod * gemm_flops,
                 "avg_launch_ms": round(gemm_ms, 4), "launches_timed": gemm_calls,
                 "algorithmic_vs_f32_mfma_peak": round(gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
@@ -613,25 +659,46 @@ def main():
                 "formulation": "token-product: T = table[distinct tokens] @ W on the MFMA pipe, then gather-add + max-pool",
                 "ms": round(conv_ms, 4), "dense_conv_flops_it_replaces": flops}
             if opt_ms is not None:
-                # longest kernel pair of the step: clip_grad_norm_ + Adam over all 17 tensors.  Algorithmic bytes per
-                # launch: the norm pass reads every gradient (4 B/param); the update reads p, g, m, v
-                # and writes p, g (clipped, as clip_grad_norm_ leaves it), m, v (32 B/param).
+                # longest kernel pair of the step: clip_grad_norm_ + Adam over all 17 tensors.  Algorithmic bytes per call
+                # (DESIGN.md section 4): p, m, v read and written for every parameter (24 B each); the gradient read for the
+                # norm, read for the update and written back clipped (12 B) where it EXISTS -- the dense gradients of the small
+                # tensors and the rows of the batch's tokens in the word table's compact row gradient.
                 n_par = sum(p.numel() for p in model.parameters())
-                oc, oms = 50, opt_ms
-                obytes = 36.0 * n_par
-                gbps = obytes / (oms * 1e-3) / 1e9
+                gbps = opt_bytes / (opt_ms * 1e-3) / 1e9
                 out["roofline"] = {
-                    "bound": "hbm", "kernel": "grad_sqnorm_kernel + clip_adam_kernel (rbr_clip_adam_step: clip_grad_norm_ + Adam, "
-                                              "all 17 parameter tensors, 61.2 MB of f32 parameters)",
+                    "bound": "hbm", "kernel": "grad_sqnorm_kernel + clip_adam_kernel<1> (rbr_clip_adam_step_rows: clip_grad_norm_ + Adam, "
+                                              "all 17 parameter tensors, the word table's gradient in compact row form)",
                     "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                    "traffic": measured_traffic("r02_clip_adam_pmc.json") or measured_traffic("r01_clip_adam_pmc.json"),
-                    "traffic_source": "profiles/r02_clip_adam_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)",
-                    "bytes_per_launch": obytes, "avg_launch_ms": round(oms, 4), "launches_timed": oc,
-                    "timing": "HIP events on the launch stream around 50 back-to-back rbr_clip_adam_step calls (two kernels each)",
-                    "note": "longest kernel of the step (rocprofv3: clip_adam_kernel 76 us + grad_sqnorm_kernel 13 us); "
-                            "36 B per parameter x 15.3 M parameters; per pair: 36 * 15 301 513 / 256 = 2.15 MB of optimizer traffic"}
+                    "traffic": measured_traffic("r03_clip_adam_pmc.json"),
+                    "traffic_source": "profiles/r03_clip_adam_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)",
+                    "bytes_per_launch": opt_bytes, "avg_launch_ms": round(opt_ms, 4), "launches_timed": 45,
+                    "timing": "HIP events on the launch stream around each rbr_clip_adam_step_rows call (two kernels), median of 45 calls "
+                              "rotating over 3 copies of parameters + Adam state + gradients (630 MB: beyond the 256 MiB Infinity "
+                              "Cache, as inside a step); compare profiles/r03_bench_kernel_stats.csv",
+                    "note": f"24 B x {n_par} parameters (p, m, v read + written) + 12 B x ({n_par - opt_table} dense-gradient elements + "
+                            f"{opt_rows} elements of listed table rows); per pair: {opt_bytes / cfg['B'] / 1e6:.2f} MB of optimizer traffic"}
             else:
                 out["roofline"] = out["roofline_gemm"]
+        if "roofline" in out and not dense_mode:
+            # the whole step against HBM: unique bytes every stage has to move at least once, 8 TB/s
+            n_par = sum(p.numel() for p in model.parameters())
+            D, V = cfg["D"], cfg["V"]
+            cp = sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"])
+            n_pos = int(masks.numel())
+            parts = {
+                "optimizer (p, m, v r+w; existing gradients r, r, w)": 24.0 * n_par + 12.0 * ((n_par - V * D) + n_distinct * D),
+                "distinct-token GEMM (table rows in, product table T out)": 4.0 * n_distinct * (D + 768),
+                "gather + max-pool (T rows once, ids + masks)": 4.0 * n_distinct * 768 + 9.0 * n_pos,
+                "table gradient (G zero + read, compact rows out)": 4.0 * n_distinct * (2 * (cp + 2) + D),
+                "conv weight gradient (table rows once)": 4.0 * n_distinct * D,
+            }
+            step_bytes = sum(parts.values())
+            floor_ms = step_bytes / (PEAK_HBM_GBPS * 1e9) * 1e3
+            out["roofline"]["step"] = {"algorithmic_bytes": step_bytes, "floor_ms": round(floor_ms, 4),
+                                       "frac": round(floor_ms / (1e3 * med / a.steps), 4), "ms_per_step": round(1e3 * med / a.steps, 4),
+                                       "parts_bytes": {k: round(v) for k, v in parts.items()},
+                                       "note": "unique HBM bytes of a step / 8 TB/s over the measured step; the conv-stage kernels are "
+                                               "bound by L2 requests (rows re-read from L2 / Infinity Cache), not by these bytes"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
         print(json.dumps(out), flush=True)

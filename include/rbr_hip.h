@@ -92,6 +92,12 @@ void rbr_set_conv_mode(int32_t mode);
  *   RBR_PROD_BF16X2 two planes, 3 plane products (~2^-17 relative per product)
  *   RBR_PROD_BF16   operands rounded to bf16, one MFMA per 16 products: the reduced-precision row of
  *                   BASELINE configs 3 and 5 (tolerance class of its own, see tests/test_precision_gpu.py)
+ * Operand range of RBR_PROD_BF16X3: the split is exact (and the class f32-accurate) while the LOW plane, 2^-16 of the
+ * operand, is a normal number: |x| >= ~2^-110.  Smaller operands lose their low plane (accuracy slides towards BF16X2, measured
+ * 1e-3 relative at 2^-118); bf16 has f32's exponent range, so large operands overflow exactly where f32 products would.
+ * A row holding inf / NaN is outside the supported domain in every mode (the split's x - hi = inf - inf poisons the lower
+ * planes, and the max-pool's comparisons drop NaN where torch's max_pool1d propagates it); documents that do not read such a
+ * row are untouched (tests/test_precision_gpu.py).
  * The word table and the conv weights stay f32 in memory in every mode.  Set once, before the first forward of a step
  * (the workspace layout depends on it); -1 restores the default (env RBR_PROD_PRECISION=f32|bf16x3|bf16x2|bf16).
  * D % 4 != 0 always takes the f32 kernel. */
@@ -192,8 +198,7 @@ int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd
  *                                [V, D] output, deepconn/layers.py:22-24), and sq_part[rbr_textcnn_row_grad_partials(d)] receives
  *                                per-workgroup sums of squares of the rows in a fixed order (the table's share of
  *                                clip_grad_norm_'s norm).  Consumers: rbr_clip_adam_step_rows, rbr_row_grad_to_dense;
- *   RBR_G_ZEROED                 G's rows are already zero (the caller cleared them in a launch of its own -- rbr_textcnn_bwd_g_rows
- *                                says where they are; rbr_pair_head_bwd has a zero job for it): no zero launch here.
+ *   RBR_G_ZEROED                 G's rows are already zero (a caller that cleared `bwd_ws` itself): no zero launch here.
  * sq_part is only read with RBR_G_ROWS; dgate as for rbr_textcnn_bwd_dtable_prod. */
 #define RBR_G_BUILD 1
 #define RBR_G_PRODUCT 2
@@ -204,8 +209,7 @@ int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids
                                    const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                    float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream);
 size_t rbr_textcnn_row_grad_partials(const rbr_textcnn_desc* d);
-int rbr_textcnn_bwd_g_rows(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, const int32_t** n_rows, int32_t* max_rows,
-                           int32_t* row_f4, float** G);
+
 /* Device addresses of the forward's token list inside `fwd_ws` (its layout is private): row_of_token [V] (list row or -1),
  * n_rows [1] (rows in the list), tok_of_row [cap]; *cap = rows a compact gradient must have room for.  Any out-pointer may be NULL. */
 int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, const int32_t** row_of_token, const int32_t** n_rows,
@@ -294,14 +298,6 @@ int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, cons
                       const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
                       const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
                       const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream);
-/* The same launch with a zero job for extra workgroups: zero_base[0 .. min(*zero_rows, zero_max_rows) * zero_row_f4) float4 are
- * cleared -- the encoder backward's G (rbr_textcnn_bwd_g_rows), which runs next and would otherwise need a launch for it. */
-int rbr_pair_head_bwd_zero(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
-                           const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
-                           const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
-                           const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, const int32_t* zero_rows,
-                           int32_t zero_max_rows, int32_t zero_row_f4, float* zero_base, void* stream);
-
 /* ---- nn.Dropout multiplier (deepconn/layers.py:202, narre.py:73, dual_att/dual_att.py:33, simple_siamese/layers.py:7-68):
  *   out[i] = 0 with probability p, else 1/(1-p), i < n.  Philox4x32-10 keyed by `seed`, counter (i/4, call number).
  *   state: 2 x uint64 in device memory, zero-initialised by the caller once; state[0] is the call number, advanced by
@@ -511,21 +507,10 @@ typedef struct rbr_row_grad {
     float* rows;                    /* [list rows, D] */
     const float* sq_part;           /* [n_sq] partial sums of squares of `rows` */
     int32_t n_sq;
-    int32_t absent_rows_done;       /* 1: rbr_adam_absent_rows already updated the rows of absent tokens in this step */
-    const int64_t* tok_of_row;      /* [list rows] (needed with absent_rows_done) */
-    const int32_t* n_rows;          /* [1] device count of list rows (needed with absent_rows_done) */
 } rbr_row_grad;
 int rbr_clip_adam_step_rows(int32_t n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const int64_t* numel, float max_norm, float lr, float beta1, float beta2,
                             float eps, float* step, float* gnorm_out, float* ws, const rbr_row_grad* rg, void* stream);
-/* The part of that step that does not wait for the backward: Adam's update of the rows of the tokens the batch does NOT hold
- * (g = 0: m, v decay and p moves by the momentum term; no dependence on the clip coefficient).  Call it once the forward's
- * token list exists (rbr_textcnn_token_list), on any stream, BEFORE rbr_clip_adam_step_rows of the same step, which must
- * then be told absent_rows_done = 1 and walks only the listed rows.  `step`: the count of steps taken before this one (not
- * advanced here).  Same bits as the one-launch form.  Caveat: a non-finite gradient norm (clip_grad_norm_ would turn every
- * element into NaN) no longer reaches these rows. */
-int rbr_adam_absent_rows(int32_t V, int32_t D, const int32_t* row_of_token, float* param, float* exp_avg, float* exp_avg_sq,
-                         float lr, float beta1, float beta2, float eps, const float* step, void* stream);
 /* dense[v, :] = rows[row_of_token[v], :] for listed tokens, 0 elsewhere: the [V, D] gradient for consumers outside the fused step */
 int rbr_row_grad_to_dense(int32_t V, int32_t D, const int32_t* row_of_token, const float* rows, float* dense, void* stream);
 

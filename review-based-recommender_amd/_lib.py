@@ -58,8 +58,7 @@ MAX_ID_SETS = 8
 
 class RowGrad(C.Structure):       # rbr_row_grad
     _fields_ = [("tensor", C.c_int32), ("V", C.c_int32), ("D", C.c_int32), ("row_of_token", C.c_void_p), ("rows", C.c_void_p),
-                ("sq_part", C.c_void_p), ("n_sq", C.c_int32), ("absent_rows_done", C.c_int32), ("tok_of_row", C.c_void_p),
-                ("n_rows", C.c_void_p)]
+                ("sq_part", C.c_void_p), ("n_sq", C.c_int32)]
 
 
 G_BUILD, G_PRODUCT, G_ACCUMULATE, G_ROWS, G_ZEROED = 1, 2, 4, 8, 16      # RBR_G_* of rbr_hip.h
@@ -109,17 +108,11 @@ SIGNATURES = {
     "rbr_textcnn_token_list": (C.c_int, [_DESC, C.c_void_p, _PP, _PP, _PP, C.POINTER(i32)]),
     "rbr_textcnn_prod_prepare_ids": (C.c_int, [_DESC, i32, C.POINTER(IdSet), C.c_void_p, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p,
                                                c_stream]),
-    "rbr_textcnn_bwd_g_rows": (C.c_int, [_DESC, C.c_void_p, C.c_void_p, _PP, C.POINTER(i32), C.POINTER(i32), _PP]),
-    "rbr_pair_head_bwd_zero": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_i64p, c_i64p, C.POINTER(HeadParams), c_f32p,
-                                         c_f32p, c_f32p, c_f32p, i32, i32, C.POINTER(HeadGrads), c_f32p, c_f32p, c_i32p, i32, i32,
-                                         c_f32p, c_stream]),
     "rbr_pair_head_fwd_pool": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, i32, c_i64p, c_i64p, C.POINTER(HeadParams),
                                          c_f32p, C.c_float, C.c_uint64, C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p,
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
     "rbr_clip_adam_step_rows": (C.c_int, [i32, _PP, _PP, _PP, _PP, C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, C.POINTER(RowGrad), c_stream]),
-    "rbr_adam_absent_rows": (C.c_int, [i32, i32, c_i32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, C.c_float, C.c_float, c_f32p,
-                                       c_stream]),
     "rbr_row_grad_to_dense": (C.c_int, [i32, i32, c_i32p, c_f32p, c_f32p, c_stream]),
     "rbr_textcnn_bwd_dtable_list_ws_bytes": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dtable_list": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_f32p, c_i32p, c_f32p, C.c_void_p, c_f32p, c_stream]),

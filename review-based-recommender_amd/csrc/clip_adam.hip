@@ -38,16 +38,10 @@ struct OptTable {
     const int* row_of_token;
     float* grows;
     const float* sq_part;
-    // touched_only: the rows of the tokens the batch does NOT hold were updated earlier in the step (rbr_adam_absent_rows, beside
-    // the forward / backward on another stream -- their update does not depend on the gradient norm): only the listed rows are
-    // walked here, in list order.
-    int touched_only;
-    const long long* tok_of_row;
-    const int* n_rows;
 };
 
-// One element's update, every operation individually rounded (no contraction): the dense path, the row-gradient path and the
-// early update of the batch's absent rows (g = 0) must produce the same bits for the same inputs.
+// One element's update, every operation individually rounded (no contraction): the dense path and the row-gradient path (g = 0
+// for the rows of absent tokens) must produce the same bits for the same inputs, whatever code surrounds the call.
 struct AdamK { float coef, w1, beta2, w2, step_size, bc2_sqrt, eps; };
 __device__ __forceinline__ void adam1(const AdamK& K, float& g, float& m, float& v, float& p) {
     // plain operators under contract(off): every operation rounds on its own at every call site (HIP's __fmul_rn / __fadd_rn are
@@ -121,9 +115,12 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const OptTable T, long
     }
 }
 
-// MODE: 0 no row-gradient tensor (every tensor dense), 1 one table with a compact row gradient (all its rows updated here),
-// 2 the same with the absent rows already updated (touched_only).  Template parameter: as run-time branches of one kernel the
-// three forms cost the dense one half its occupancy (226 VGPRs against 104).
+// MODE: 0 no row-gradient tensor (every tensor dense), 1 one table with a compact row gradient.  A template parameter: as a
+// run-time branch of one kernel the row form cost the dense one half its occupancy (226 VGPRs against 104).
+// (Measured and dropped in round 3: updating the rows of the batch's ABSENT tokens early -- their gradient is zero whatever the
+// backward computes -- on another stream beside the GEMM or beside the head kernels, and walking only the listed rows here
+// (52 us instead of 77): the 41-55 us stream of the early kernel slowed whatever it ran beside by as much as it saved
+// (GEMM 61 -> 89 us; head_fwd 24 -> 46 us): step 0.394 / 0.402 ms against 0.385.)
 template <int MODE>
 __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long nchunks, const float* __restrict__ partials,
                                                         int npartials, float max_norm, float lr, float beta1, float beta2,
@@ -146,40 +143,6 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
         float* g = T.g[k] + e0;
         float* m = T.m[k] + e0;
         float* v = T.v[k] + e0;
-        if (MODE == 2 && k == T.rows_k) {      // chunk = 4096 elements of the COMPACT gradient: rows of listed tokens only
-            const int D = T.rows_D;
-            const long n_el = (long)min(*T.n_rows, (int)(T.n[k] / D)) * D;
-            if (e0 >= n_el) continue;
-            const int n4r = (int)((min((long)kOptChunk, n_el - e0)) >> 2);
-            constexpr int U = 4;
-            float4 G[U], M[U], V[U], P[U];
-            long poff[U];
-            unsigned ge[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {                    // unconditional loads (see above): past the end repeats the last float4
-                const int i = min((int)threadIdx.x + 256 * u, n4r - 1);
-                ge[u] = (unsigned)(e0 + 4 * i);
-                const unsigned r = ge[u] / (unsigned)D;
-                poff[u] = (long)T.tok_of_row[r] * D + (ge[u] - r * (unsigned)D);
-                G[u] = *reinterpret_cast<const float4*>(T.grows + ge[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                M[u] = *reinterpret_cast<const float4*>(T.m[k] + poff[u]); V[u] = *reinterpret_cast<const float4*>(T.v[k] + poff[u]);
-                P[u] = *reinterpret_cast<const float4*>(T.p[k] + poff[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if ((int)threadIdx.x + 256 * u >= n4r) continue;
-                RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
-                RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
-                if (clipped) *reinterpret_cast<float4*>(T.grows + ge[u]) = G[u];
-                *reinterpret_cast<float4*>(T.m[k] + poff[u]) = M[u];
-                *reinterpret_cast<float4*>(T.v[k] + poff[u]) = V[u];
-                *reinterpret_cast<float4*>(T.p[k] + poff[u]) = P[u];
-            }
-            continue;
-        }
         if (MODE == 1 && k == T.rows_k) {                 // compact-gradient table (rows_D % 4 == 0 and 16-byte aligned pointers: checked on the host)
             // every load is UNCONDITIONAL (an index past the chunk repeats its last float4, an absent token reads row 0 of the
             // compact gradient and discards it): a load behind a branch makes the compiler drain all loads in flight first
@@ -284,9 +247,6 @@ static int clip_adam_step(int32_t n_tensors, float* const* params, float* const*
             return RBR_ERR_BAD_ARG;
         }
         T.rows_k = k; T.rows_D = rg->D; T.n_sq = rg->n_sq; T.row_of_token = rg->row_of_token; T.grows = rg->rows; T.sq_part = rg->sq_part;
-        T.touched_only = rg->absent_rows_done ? 1 : 0;
-        T.tok_of_row = reinterpret_cast<const long long*>(rg->tok_of_row); T.n_rows = rg->n_rows;
-        if (T.touched_only && (!rg->tok_of_row || !rg->n_rows)) { set_error("clip_adam_step_rows: absent_rows_done needs tok_of_row and n_rows"); return RBR_ERR_BAD_ARG; }
     }
     long chunks = 0;
     for (int k = 0; k < n_tensors; ++k) {
@@ -303,10 +263,8 @@ static int clip_adam_step(int32_t n_tensors, float* const* params, float* const*
     const int nb2 = (int)std::min<long>(chunks, 4096);
     if (T.rows_k < 0)
         hipLaunchKernelGGL(clip_adam_kernel<0>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
-    else if (!T.touched_only)
-        hipLaunchKernelGGL(clip_adam_kernel<1>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
     else
-        hipLaunchKernelGGL(clip_adam_kernel<2>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
+        hipLaunchKernelGGL(clip_adam_kernel<1>, dim3(nb2), dim3(256), 0, st, T, chunks, ws, nb1, max_norm, lr, beta1, beta2, eps, step, gnorm_out);
     RBR_CHECK_LAUNCH("clip_adam launch");
     return 0;
 }
@@ -325,62 +283,6 @@ extern "C" int rbr_clip_adam_step_rows(int32_t n_tensors, float* const* params, 
     if (!rg) { set_error("clip_adam_step_rows: null row gradient"); return RBR_ERR_BAD_ARG; }
     return clip_adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, max_norm, lr, beta1, beta2, eps, step, gnorm_out, ws,
                           stream, rg);
-}
-
-// Adam's update of the table rows whose gradient is known to be zero before the backward has run: the tokens the batch does not
-// hold (m = m + (1-b1)(0 - m), v = b2 v, p -= ...: no dependence on the clip coefficient).  Launched beside the forward /
-// backward on another stream as soon as the token list exists; rbr_clip_adam_step_rows is then told absent_rows_done and walks
-// the listed rows only.  `step` holds the number of steps taken BEFORE this one (the later launch pair advances it).
-namespace rbr {
-__global__ __launch_bounds__(256) void adam_absent_rows_kernel(int V, int D, const int* __restrict__ row_of_token, float* __restrict__ p,
-                                                               float* __restrict__ m, float* __restrict__ v, float lr, float beta1,
-                                                               float beta2, float eps, const float* __restrict__ step) {
-    const AdamK K = adam_constants(1.f, lr, beta1, beta2, eps, (double)*step + 1.0);
-    const long n4 = (long)V * D / 4;
-    for (long i0 = (long)blockIdx.x * 1024; i0 < n4; i0 += (long)gridDim.x * 1024) {
-        constexpr int U = 4;
-        float4 M[U], Vv[U], P[U];
-        bool on[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long i = i0 + threadIdx.x + 256 * u;
-            on[u] = false;
-            if (i < n4) {
-                const unsigned tok = (unsigned)(4 * i) / (unsigned)D;
-                on[u] = row_of_token[tok] < 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (on[u]) {
-                const long i = i0 + threadIdx.x + 256 * u;
-                M[u] = reinterpret_cast<float4*>(m)[i]; Vv[u] = reinterpret_cast<float4*>(v)[i]; P[u] = reinterpret_cast<float4*>(p)[i];
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!on[u]) continue;
-            const long i = i0 + threadIdx.x + 256 * u;
-            float4 G = {0.f, 0.f, 0.f, 0.f};
-            adam1(K, G.x, M[u].x, Vv[u].x, P[u].x); adam1(K, G.y, M[u].y, Vv[u].y, P[u].y);
-            adam1(K, G.z, M[u].z, Vv[u].z, P[u].z); adam1(K, G.w, M[u].w, Vv[u].w, P[u].w);
-            reinterpret_cast<float4*>(m)[i] = M[u]; reinterpret_cast<float4*>(v)[i] = Vv[u]; reinterpret_cast<float4*>(p)[i] = P[u];
-        }
-    }
-}
-}  // namespace rbr
-
-extern "C" int rbr_adam_absent_rows(int32_t V, int32_t D, const int32_t* row_of_token, float* param, float* exp_avg, float* exp_avg_sq,
-                                    float lr, float beta1, float beta2, float eps, const float* step, void* stream) {
-    if (V <= 0 || D <= 0 || D % 4 != 0 || (int64_t)V * D >= ((int64_t)1 << 32) || !row_of_token || !param || !exp_avg || !exp_avg_sq || !step ||
-        ((((uintptr_t)param) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq)) & 15) != 0) {
-        set_error("adam_absent_rows: bad arguments (V=%d, D=%d)", V, D);
-        return RBR_ERR_BAD_ARG;
-    }
-    const long n4 = (long)V * D / 4;
-    hipLaunchKernelGGL(adam_absent_rows_kernel, dim3((unsigned)std::min<long>((n4 + 1023) / 1024, 2048)), dim3(256), 0, (hipStream_t)stream,
-                       V, D, row_of_token, param, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step);
-    RBR_CHECK_LAUNCH("adam_absent_rows launch");
-    return 0;
 }
 
 // dense[v, :] = rows[row_of_token[v], :] for the tokens the batch holds, 0 elsewhere: the [V, D] gradient nn.Embedding's backward

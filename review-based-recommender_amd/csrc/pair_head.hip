@@ -249,16 +249,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int K, cons
                                                        const float* __restrict__ drop, const float* __restrict__ ul,
                                                        const float* __restrict__ il, const float* __restrict__ d_pred,
                                                        int pad_u, int pad_i, const rbr_head_grads g,
-                                                       float* __restrict__ d_uf, float* __restrict__ d_if, int nb_work,
-                                                       const int* __restrict__ zero_rows, int zero_max_rows, int zero_row_f4,
-                                                       float4* __restrict__ zero_base) {
+                                                       float* __restrict__ d_uf, float* __restrict__ d_if) {
+    // (Measured and dropped in round 3: clearing the conv backward's G with extra workgroups of this launch instead of the
+    // zero_g_rows launch -- the step got 19 us SLOWER: the weight-gradient branch then starts beside the L2-bound sparse product
+    // instead of beside the zero fill and the atomics-bound G build, and both crawl.)
     extern __shared__ __attribute__((aligned(16))) float sm[];   // pair role: [2][K4]; reduce role: [3][8][32]
     const int t = threadIdx.x;
-    if ((int)blockIdx.x >= nb_work) {           // zero job (rbr_pair_head_bwd_zero): the workgroups behind the head's own
-        const long n = (long)min(*zero_rows, zero_max_rows) * zero_row_f4, nb = gridDim.x - nb_work;
-        for (long k = (long)(blockIdx.x - nb_work) * 256 + t; k < n; k += nb * 256) zero_base[k] = float4{0.f, 0.f, 0.f, 0.f};
-        return;
-    }
     if ((int)blockIdx.x < B) {
         const int K4 = (K + 3) & ~3;
         const int b = blockIdx.x;
@@ -485,39 +481,22 @@ extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pv
 
 extern "C" size_t rbr_pair_head_bwd_ws_floats(int32_t B, int32_t K) { (void)B; (void)K; return 0; }
 
-extern "C" int rbr_pair_head_bwd_zero(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
-                                      const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
-                                      const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
-                                      const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, const int32_t* zero_rows,
-                                      int32_t zero_max_rows, int32_t zero_row_f4, float* zero_base, void* stream) {
+extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
+                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
+                                 const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
+                                 const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
     if (!head_args_ok(B, H, K)) return RBR_ERR_BAD_ARG;
     if (!u_feat || !i_feat || !u_id || !i_id || !p || !ul || !il || !d_pred || !g || !d_ufeat || !d_ifeat) {
         set_error("null pointer");
         return RBR_ERR_BAD_ARG;
     }
-    const bool zero = zero_base != nullptr;
-    if (zero && (!zero_rows || zero_max_rows <= 0 || zero_row_f4 <= 0 || (((uintptr_t)zero_base) & 15) != 0)) {
-        set_error("pair_head_bwd_zero: malformed zero job");
-        return RBR_ERR_BAD_ARG;
-    }
+    (void)ws;      // no longer needed: the reduction blocks recompute d_l instead of reading it back
     const size_t lds = std::max((size_t)2 * ((K + 3) & ~3), (size_t)3 * 8 * 32) * sizeof(float);
-    const int nb_work = B + 2 * (H + 1);
-    const int nb_zero = zero ? (int)std::min<long>(((long)zero_max_rows * zero_row_f4 + 1023) / 1024, 2048) : 0;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nb_work + nb_zero)), dim3(256), lds, (hipStream_t)stream, B, H, K, u_feat,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(B + 2 * (H + 1))), dim3(256), lds, (hipStream_t)stream, B, H, K, u_feat,
                        i_feat, reinterpret_cast<const long long*>(u_id), reinterpret_cast<const long long*>(i_id), *p, drop,
-                       ul, il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat, nb_work, zero_rows, zero_max_rows, zero_row_f4,
-                       reinterpret_cast<float4*>(zero_base));
+                       ul, il, d_pred, pad_u, pad_i, *g, d_ufeat, d_ifeat);
     RBR_CHECK_LAUNCH("pair_head_bwd launch");
     return 0;
-}
-
-extern "C" int rbr_pair_head_bwd(int32_t B, int32_t H, int32_t K, const float* u_feat, const float* i_feat,
-                                 const int64_t* u_id, const int64_t* i_id, const rbr_head_params* p, const float* drop,
-                                 const float* ul, const float* il, const float* d_pred, int32_t pad_u, int32_t pad_i,
-                                 const rbr_head_grads* g, float* d_ufeat, float* d_ifeat, float* ws, void* stream) {
-    (void)ws;      // no longer needed: the reduction blocks recompute d_l instead of reading it back
-    return rbr_pair_head_bwd_zero(B, H, K, u_feat, i_feat, u_id, i_id, p, drop, ul, il, d_pred, pad_u, pad_i, g, d_ufeat, d_ifeat, nullptr,
-                                  0, 0, nullptr, stream);
 }
 
 // ---- D-ATT's rating: ratings[b] = sum_k u[b,k] * i[b,k] (dual_att.py:58) over a STACKED [2B, K] feature block (user rows

@@ -1042,7 +1042,7 @@ extern "C" int rbr_textcnn_bwd_g_product(const rbr_textcnn_desc* d, void* fwd_ws
 //   RBR_G_ACCUMULATE              the rows are added to the dense `dtable`;
 //   RBR_G_ROWS                    `dtable` is the COMPACT gradient [list rows, D] (row r = token tok_of_row[r]; absent tokens have
 //                                 no row) and sq_part[rbr_textcnn_row_grad_partials(d)] receives per-workgroup sums of squares;
-//   RBR_G_ZEROED                  G's rows are zero already (the caller cleared them: rbr_textcnn_bwd_g_rows).
+//   RBR_G_ZEROED                  G's rows are zero already (a caller that cleared bwd_ws itself).
 extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                               const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                               float* dtable, float* dgate, float* sq_part, int32_t flags, void* stream) {
@@ -1058,23 +1058,6 @@ extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const i
                   RBR_G_ZEROED == kGZeroed, "public flags = internal phases");
     return dtable_through_list(d, plans, ids, mask, gate, feat, argmax, d_feat, fwd_ws, bwd_ws, dtable, dgate, (hipStream_t)stream,
                                flags & (kGBuild | kGProduct | kGAccumulate | kGRows | kGZeroed), sq_part);
-}
-
-// Where the backward's G lives inside `bwd_ws`, for a caller that clears its rows in a launch of its own (the rating head's
-// backward: rbr_pair_head_bwd's zero job) and then passes RBR_G_ZEROED: rows to clear = min(*n_rows, max_rows), row_f4 float4 each.
-extern "C" int rbr_textcnn_bwd_g_rows(const rbr_textcnn_desc* d, void* fwd_ws, void* bwd_ws, const int32_t** n_rows, int32_t* max_rows,
-                                      int32_t* row_f4, float** G) {
-    ProdLayout Lo;
-    ProdBwdLayout B;
-    if (!fwd_ws || !bwd_ws || !prod_applicable(d) || !prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) {
-        set_error("no token-product backward for this shape");
-        return RBR_ERR_UNSUPPORTED;
-    }
-    if (n_rows) *n_rows = reinterpret_cast<const int32_t*>(static_cast<char*>(fwd_ws) + Lo.counter);
-    if (max_rows) *max_rows = Lo.cap;
-    if (row_f4) *row_f4 = B.KG / 4;
-    if (G) *G = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + B.G);
-    return 0;
 }
 
 // = the grid of the product kernel: one partial per workgroup, every one of them written

@@ -40,6 +40,25 @@ def set_prod_precision(name: Optional[str]) -> None:
     _lib.lib().rbr_set_prod_precision(-1 if name is None else _lib.PROD_PRECISIONS[name])
 
 
+_DTABLE_MODE: list = [None]
+
+
+def set_dtable_mode(mode: Optional[str]) -> None:
+    """How an un-gated conv's backward accumulates the word-table gradient: None (default; env RBR_DTABLE_MODE) = G built with
+    f32 atomics, whose arrival order leaves rounding-level run-to-run noise in the result; "fixed" = every (token, tap, channel)
+    cell summed in 64-bit fixed point (2^-40 units, integer adds: order-free) -- two runs over the same batch give the same
+    bits, like the reference's CPU embedding backward (models/deepconn/layers.py:22-24).  It is the data-parallel tap rebuild run
+    on this rank's taps alone (rbr_textcnn_bwd_taps + rbr_textcnn_dtable_from_taps, n_sets = 1): a sort per step, eager
+    launches only (rocPRIM's sort cannot be recorded into a hipGraph here), D % 4 == 0."""
+    if mode not in (None, "fixed"):
+        raise ValueError(f"unknown dtable mode {mode!r}; None or 'fixed'")
+    _DTABLE_MODE[0] = mode
+
+
+def _dtable_fixed() -> bool:
+    return (_DTABLE_MODE[0] or os.environ.get("RBR_DTABLE_MODE")) == "fixed"
+
+
 def get_prod_precision() -> str:
     mode = _lib.lib().rbr_get_prod_precision()
     return {v: k for k, v in _lib.PROD_PRECISIONS.items()}[mode]
@@ -323,6 +342,24 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
     use_taps = (sink is not None and need_table and gate is None and sink.accepts(table, desc, L_))
     if use_taps:
         need_table = False          # table.grad is produced by the exchange, after the all-gather of the taps
+    fixed_dtable = None
+    if need_table and gate is None and _dtable_fixed():
+        fixed_bytes = L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(desc), 1)
+        if fixed_bytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("RBR_DTABLE_MODE=fixed sorts with rocPRIM and cannot be recorded into a hipGraph: run the step eagerly")
+            n_taps = L_.rbr_textcnn_taps_count(C.byref(desc))
+            tok = torch.empty(n_taps, dtype=I32, device=dev)
+            val = torch.empty(n_taps, dtype=F32, device=dev)
+            tws = torch.empty(fixed_bytes, dtype=torch.uint8, device=dev)
+            fixed_dtable = torch.empty_like(table)
+            check(L_.rbr_textcnn_bwd_taps(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"), dev_ptr(feat, F32, "feat"),
+                                          dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"), dev_ptr(tok, I32, "tap tokens"),
+                                          dev_ptr(val, F32, "tap values"), current_stream()), "rbr_textcnn_bwd_taps")
+            check(L_.rbr_textcnn_dtable_from_taps(C.byref(desc), 1, dev_ptr(tok, I32, "tap tokens"), dev_ptr(val, F32, "tap values"),
+                                                  ptr_array(ws, F32, "conv weight"), tws.data_ptr(), dev_ptr(fixed_dtable, F32, "dtable"),
+                                                  current_stream()), "rbr_textcnn_dtable_from_taps")
+            need_table = False
     bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) if S.prod_ws is not None else 0
     # dense forward (no token list of its own), un-gated: the table gradient still goes through a distinct-token list built
     # here (16 us) instead of the window scatter's row of f32 atomics per (document, channel, tap)
@@ -383,6 +420,11 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
         return j
 
     ev = TIMER.record("textcnn_bwd_dtable")
+    if fixed_dtable is not None:          # table gradient done above (order-free fixed-point sums); the weight gradient remains
+        if ev is not None:
+            ev.record()
+        _join(run_dw())
+        return fixed_dtable, dgate, dWs, dbs
     if use_taps:
         tok, val = sink.local_buffers(L_.rbr_textcnn_taps_count(C.byref(desc)), dev)
         check(L_.rbr_textcnn_bwd_taps(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
@@ -482,8 +524,7 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
 
 
 # ---- compact row gradient of an embedding table (consumer: train_step.HipClipAdam) ------------------------------------------
-# word-table data_ptr -> sink: wants_row_grad(table) -> bool, put_row_grad(table, RowGradient), on_token_list(table, desc, fwd_ws)
-_ROW_GRAD_SINKS: dict = {}
+_ROW_GRAD_SINKS: dict = {}      # word-table data_ptr -> sink: wants_row_grad(table) -> bool, put_row_grad(table, RowGradient)
 
 
 def set_row_grad_sink(table: torch.Tensor, sink) -> None:
@@ -505,7 +546,6 @@ class RowGradient:
     def __init__(self, table, rows, sq, row_of_token_ptr, keep_alive):
         self.V, self.D = int(table.shape[0]), int(table.shape[1])
         self.rows, self.sq, self.row_of_token_ptr, self._keep = rows, sq, int(row_of_token_ptr), keep_alive
-        self.fwd_ws = keep_alive          # the forward's workspace: identifies the token list the rows belong to
 
     def to_dense(self) -> torch.Tensor:
         dense = torch.empty(self.V, self.D, dtype=F32, device=self.rows.device)
@@ -524,20 +564,6 @@ def _side_stream(dev):
     s = _SIDE_STREAMS.get(dev)
     if s is None:
         s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    return s
-
-
-_SIDE_STREAMS2: dict = {}
-
-
-def _side_stream2(dev):
-    """A third stream of `dev`: the optimizer's early row update (its own queue: the weight-gradient chain on the second stream
-    must not wait behind it)."""
-    if os.environ.get("RBR_BWD_OVERLAP", "1") == "0":
-        return None
-    s = _SIDE_STREAMS2.get(dev)
-    if s is None:
-        s = _SIDE_STREAMS2[dev] = torch.cuda.Stream(device=dev)
     return s
 
 
@@ -716,7 +742,7 @@ class _EncodeHead(torch.autograd.Function):
     """pred[B] (and the MSE loss against `target`) = rating head(TextCNN(user docs), TextCNN(item docs), ids): the training /
     eval forward of DeepCoNN++ (deepconn.py:43-53) as 6 launches -- id check + list state | token marks + slab scan | token list
     + weight images | distinct-token GEMM | gather + max-pool (+ clearing the backward's G) | pool epilogue + LastFeat x2 + FM
-    (+ MSELoss) -- and its backward as head_bwd, then [G build, G @ Wprod^T] beside [dW] (see _textcnn_backward)."""
+    (+ MSELoss) -- and its backward as head_bwd, then [zero G, G build, G @ Wprod^T] beside [dW] (see _textcnn_backward)."""
 
     @staticmethod
     def forward(ctx, table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i, n_widths, *params):
@@ -776,19 +802,6 @@ class _EncodeHead(torch.autograd.Function):
                   "rbr_textcnn_prod_prepare")
         if ev is not None:
             ev.record()
-        # the token list exists: an optimizer that takes this table's gradient in row form may start on the rows of the tokens
-        # the batch does NOT hold right away (train_step.HipClipAdam.on_token_list) -- launched behind the gather below, so that
-        # its HBM stream runs under the latency-bound head kernels and the atomics-bound G build (RBR_EARLY_AT=gemm: here,
-        # under the GEMM, which it slows by as much as it saves)
-        row_sink = None
-        if training and ctx.needs_input_grad[0] and table_c.data_ptr() not in _TAP_SINKS \
-                and L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)):
-            row_sink = _ROW_GRAD_SINKS.get(table_c.data_ptr())
-            if row_sink is not None and not row_sink.wants_row_grad(table_c):
-                row_sink = None
-        early_at_gemm = os.environ.get("RBR_EARLY_AT", "head") == "gemm"
-        if row_sink is not None and early_at_gemm:
-            row_sink.on_token_list(table_c, desc, prod_ws)
         ev = TIMER.record("textcnn_prod_table")
         check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
         if ev is not None:
@@ -798,8 +811,6 @@ class _EncodeHead(torch.autograd.Function):
                                        dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
         if ev is not None:
             ev.record()
-        if row_sink is not None and not early_at_gemm:
-            row_sink.on_token_list(table_c, desc, prod_ws)
         # ---- pool epilogue + rating head (+ loss)
         K = head[0].shape[1]
         hp = _lib.HeadParams(*[dev_ptr(t, F32, n) for t, n in zip(head, _HEAD_NAMES)])
@@ -871,21 +882,12 @@ class _EncodeHead(torch.autograd.Function):
         d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
         feat = S.feat
         need_conv = any(ctx.needs_input_grad[12:12 + 2 * n_widths]) or ctx.needs_input_grad[0]
-        # the conv backward's G is cleared by extra workgroups of THIS launch (it was a launch of its own): right in front of its
-        # use, so that its lines are still in the Infinity Cache when build_g and g_times_w come for them
-        zrows, zmax, zf4, zbase = C.c_void_p(), C.c_int32(0), C.c_int32(0), C.c_void_p()
-        if ctx.needs_input_grad[0] and S.table.data_ptr() not in _TAP_SINKS:
-            bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(S.desc))
-            if bws_bytes:
-                S.bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
-                check(L_.rbr_textcnn_bwd_g_rows(C.byref(S.desc), S.prod_ws.data_ptr(), S.bws.data_ptr(), C.byref(zrows), C.byref(zmax),
-                                                C.byref(zf4), C.byref(zbase)), "rbr_textcnn_bwd_g_rows")
-        check(L_.rbr_pair_head_bwd_zero(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
-                                        dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
-                                        dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
-                                        dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
-                                        dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), zrows.value,
-                                        zmax.value, zf4.value, zbase.value, current_stream()), "rbr_pair_head_bwd")
+        check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
+                                   dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                   dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
+                                   dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
+                                   dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), None,
+                                   current_stream()), "rbr_pair_head_bwd")
         if need_conv:
             dtable, _, dWs, dbs = _textcnn_backward(S, d_pair, ctx.needs_input_grad[0], False)
         else:

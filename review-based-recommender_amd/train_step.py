@@ -67,8 +67,6 @@ class HipClipAdam(torch.optim.Optimizer):
         self._gnorm = None
         self._row_grads = {}          # parameter -> functional.RowGradient of the last backward
         self._row_tables = []
-        self._early = {}              # parameter -> (fwd_ws, tok_of_row ptr, n_rows ptr, event): absent rows already updated
-        self._armed = False
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             row_grads = False         # a data-parallel exchange reads every gradient as a dense .grad
@@ -85,48 +83,6 @@ class HipClipAdam(torch.optim.Optimizer):
     # ---- functional.set_row_grad_sink protocol
     def wants_row_grad(self, table) -> bool:
         return any(table.data_ptr() == p.data_ptr() for p in self._row_tables)
-
-    def arm(self) -> None:
-        """train_step() calls this in front of the forward: THIS forward's backward is followed by clip_and_step(), so the part
-        of the update that does not wait for the backward may start as soon as the forward's token list exists
-        (on_token_list).  Never armed with gradient accumulation or a data-parallel exchange."""
-        self._armed = True
-
-    def on_token_list(self, table, desc, fwd_ws) -> None:
-        """Called by the fused forward once the batch's distinct-token list exists.  When armed: Adam's update of the rows of
-        the tokens the batch does NOT hold (their gradient is zero whatever the backward computes, and a zero gradient does not
-        feel the clip) is launched on the second stream, beside the conv's GEMM and everything after it; clip_and_step joins
-        it and then walks the listed rows only (rbr_adam_absent_rows / rbr_row_grad.absent_rows_done)."""
-        if not getattr(self, "_armed", False):
-            return
-        import ctypes as C
-        from . import _lib
-        p = next(q for q in self._row_tables if q.data_ptr() == table.data_ptr())
-        if p in self._early or p.grad is not None or p in self._row_grads:
-            return                        # a second conv over the table, or gradient accumulation: the one-launch form
-        group = next(g for g in self.param_groups if any(q is p for q in g["params"]))
-        st_ = self._state_of(p)
-        side = RF._side_stream2(p.device)
-        if side is None:
-            return
-        L_ = _lib.lib()
-        rot, nrows, tor = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _lib.check(L_.rbr_textcnn_token_list(C.byref(desc), fwd_ws.data_ptr(), C.byref(rot), C.byref(nrows), C.byref(tor), None),
-                   "rbr_textcnn_token_list")
-        fork = torch.cuda.Event()
-        fork.record()
-        side.wait_event(fork)
-        b1, b2 = group["betas"]
-        with torch.cuda.stream(side):
-            _lib.check(L_.rbr_adam_absent_rows(p.shape[0], p.shape[1], rot.value, _lib.dev_ptr(p.data, torch.float32, "param"),
-                                               _lib.dev_ptr(st_["exp_avg"], torch.float32, "exp_avg"),
-                                               _lib.dev_ptr(st_["exp_avg_sq"], torch.float32, "exp_avg_sq"), float(group["lr"]),
-                                               float(b1), float(b2), float(group["eps"]),
-                                               _lib.dev_ptr(st_["step"], torch.float32, "step"), _lib.current_stream()),
-                       "rbr_adam_absent_rows")
-            done = torch.cuda.Event()
-            done.record()
-        self._early[p] = (fwd_ws, tor.value, nrows.value, done)
 
     def put_row_grad(self, table, rg) -> None:
         p = next(q for q in self._row_tables if q.data_ptr() == table.data_ptr())
@@ -153,9 +109,6 @@ class HipClipAdam(torch.optim.Optimizer):
         self._row_grads.clear()
 
     def zero_grad(self, set_to_none: bool = True):
-        if self._early:
-            raise RuntimeError("HipClipAdam: a step was begun (the rows of the batch's absent tokens are updated) but "
-                               "clip_and_step() never ran -- the forward of an armed train_step() must be followed by its update")
         self._row_grads.clear()
         super().zero_grad(set_to_none=set_to_none)
 
@@ -174,13 +127,6 @@ class HipClipAdam(torch.optim.Optimizer):
         import ctypes as C
         from . import _lib
         L_ = _lib.lib()
-        self._armed = False
-        for p, (fwd_ws, _, _, done) in self._early.items():
-            rg = self._row_grads.get(p)
-            if rg is None or rg.fwd_ws is not fwd_ws or p.grad is not None:
-                raise RuntimeError("HipClipAdam: the early update of the absent rows has no matching row gradient "
-                                   "(the backward of the armed forward did not run, or produced a dense gradient)")
-            torch.cuda.current_stream().wait_event(done)       # before the step counter moves
         for p in [q for q in self._row_grads if q.grad is not None]:      # mixed: a dense gradient exists too -> dense path
             p.grad = p.grad + self._row_grads.pop(p).to_dense()
         todo = [(g, p) for g in self.param_groups for p in g["params"] if p.grad is not None or p in self._row_grads]
@@ -200,8 +146,6 @@ class HipClipAdam(torch.optim.Optimizer):
             for k in range(0, len(ps), self.MAX_TENSORS):
                 batches.append((g, ps[k:k + self.MAX_TENSORS]))
         if self._row_grads and (len(batches) > 1 or len(self._row_grads) > 1):
-            if self._early:
-                raise RuntimeError("HipClipAdam: early row updates need one parameter group, <= 64 tensors and one row-gradient table")
             self.materialize_grads()          # one compact table per launch pair: anything else takes the dense path
         if len(batches) > 1 and max_grad_norm is not None:
             # the fused clip needs every gradient in ONE launch pair; beyond 64 tensors (or with several parameter groups) the
@@ -233,16 +177,12 @@ class HipClipAdam(torch.optim.Optimizer):
             rowp = [k for k, p in enumerate(ps) if p in self._row_grads]
             if rowp:
                 rg = self._row_grads[ps[rowp[0]]]
-                early = self._early.get(ps[rowp[0]])
-                crg = _lib.RowGrad(rowp[0], rg.V, rg.D, rg.row_of_token_ptr, rg.rows.data_ptr(), rg.sq.data_ptr(), rg.sq.numel(),
-                                   1 if early is not None else 0, early[1] if early is not None else None,
-                                   early[2] if early is not None else None)
+                crg = _lib.RowGrad(rowp[0], rg.V, rg.D, rg.row_of_token_ptr, rg.rows.data_ptr(), rg.sq.data_ptr(), rg.sq.numel())
                 _lib.check(L_.rbr_clip_adam_step_rows(*args, C.byref(crg), st), "rbr_clip_adam_step_rows")
             else:
                 _lib.check(L_.rbr_clip_adam_step(*args, st), "rbr_clip_adam_step")
             if ev is not None:
                 ev.record()
-        self._early.clear()
         return self._gnorm
 
     @torch.no_grad()
@@ -269,8 +209,6 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     (NARRE: pred, u_att, i_att) contribute their first element.  `grad_sync(model)` is the
     data-parallel gradient all-reduce hook (None on one GPU).  Returns (loss, gnorm, pred) tensors."""
     optimizer.zero_grad()
-    if grad_sync is None and isinstance(optimizer, HipClipAdam) and os.environ.get("RBR_EARLY_ROWS", "1") != "0":
-        optimizer.arm()
     pred, loss = _forward_loss_backward(model, batch, ratings)
     if grad_sync is not None:
         if isinstance(optimizer, HipClipAdam):

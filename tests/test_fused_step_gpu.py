@@ -46,17 +46,14 @@ class _env:
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("early", [False, True])
 @pytest.mark.parametrize("cfgname", ["small", "cfg1", "cfg2"])
-def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname, early):
+def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
     """HipClipAdam(row_grads=True) takes the table gradient as the rows of the batch's tokens.  Fed the SAME gradient in dense
     form (the rows scattered into a zero [V, D] tensor), a second optimizer on a copy of the model ends its steps with the
     same bits in parameters and Adam state while the clip coefficient is 1; the norm itself is summed in another order
     (per-workgroup partials of the producer against chunks of the dense tensor), so it -- and with it a clipping step --
     agrees to rounding, not to the bit.
-    (Two separate backwards cannot be compared bit for bit: G is built with f32 atomics.)  early: the optimizer is armed as
-    train_step() arms it, so the rows of the batch's absent tokens are updated beside the forward (rbr_adam_absent_rows) and
-    clip_and_step walks the listed rows only -- still the same bits."""
+    (Two separate backwards cannot be compared bit for bit: G is built with f32 atomics.)"""
     from review_based_recommender_amd import _lib
     from review_based_recommender_amd.train_step import HipClipAdam, _forward_loss_backward
     _lib.lib().rbr_set_conv_mode(2)
@@ -74,10 +71,7 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname, early):
         for step in range(3):
             args, r = _batch(cfg, 3 + step, edge=(cfgname == "small"))
             oa.zero_grad()
-            if early:
-                oa.arm()
             _forward_loss_backward(ma, args, r)
-            assert bool(oa._early) == early
             assert table_a.grad is None and table_a in oa._row_grads, "the compact row gradient was not handed over"
             dense = oa._row_grads[table_a].to_dense()
             # what the dense backward computes: the same rows, zeros elsewhere (checked against a second, dense backward)
@@ -229,3 +223,30 @@ def test_graphed_hipclipadam_datt_cfg4_matches_reference(golden_dir):
     args, ratings = (b["u_docs"].to(DEV), b["i_docs"].to(DEV)), b["ratings"].to(DEV)
     cap_args, cap_r = (c["u_docs"].to(DEV), c["i_docs"].to(DEV)), c["ratings"].to(DEV)
     _graphed_vs_golden(m, g, args, ratings, cap_args, cap_r)
+
+
+@pytest.mark.parametrize("conv", ["dense", "product"])
+def test_fixed_dtable_mode_is_bit_reproducible(conv):
+    """functional.set_dtable_mode("fixed") (env RBR_DTABLE_MODE=fixed): the word-table gradient of two backward runs over the
+    same batch is the same bits (64-bit fixed-point cell sums: SURVEY 7's deterministic mode; the reference's CPU embedding
+    backward, models/deepconn/layers.py:22-24, is reproducible too), and agrees with the default atomics path to rounding."""
+    from review_based_recommender_amd import _lib, functional as RF
+    _lib.lib().rbr_set_conv_mode({"dense": 1, "product": 2}[conv])
+    try:
+        cfg = synth.DEEPCONN_CFGS["cfg1"]
+        args, r = _batch(cfg, 5)
+        grads = []
+        for mode in ("fixed", "fixed", None):
+            RF.set_dtable_mode(mode)
+            with _env(RBR_FUSED_STEP="0"):
+                m = _deepconn(cfg)
+                m.train()
+                torch.nn.functional.mse_loss(m(*args), r).backward()
+            grads.append(m.word_embeddings.embedding.weight.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+        assert float(grads[0][0].abs().max()) == 0.0                 # padding row
+        scale = float(grads[2].abs().max())
+        assert float((grads[0] - grads[2]).abs().max()) <= 1e-5 * scale
+    finally:
+        RF.set_dtable_mode(None)
+        _lib.lib().rbr_set_conv_mode(0)

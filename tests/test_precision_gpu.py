@@ -143,3 +143,84 @@ def test_narre_cfg3_precision_classes(golden_dir, precision):
     loss.backward()
     errs = _grad_norm_errs(m, g)
     assert max(errs.values()) <= tol_g, errs
+
+
+# ---- operand range of the exact three-plane split: the claim "bf16x3 = f32-class" rests on no plane
+#      under- or overflowing.  Pretrained embeddings are the reference's documented input (models/deepconn/layers.py:15-18).
+def _features(table, ids, masks, weights, biases, prec):
+    from review_based_recommender_amd import functional as RF
+    RF.set_prod_precision(prec)
+    try:
+        with torch.no_grad():
+            return RF.textcnn(table, ids, masks, weights, biases, padding_idx=0).clone()
+    finally:
+        RF.set_prod_precision(None)
+
+
+@pytest.mark.parametrize("log2_scale", [40, -40, 60, -60])
+def test_bf16x3_holds_f32_class_accuracy_across_operand_scales(log2_scale):
+    """Table scaled by 2^s and conv weights by 2^-s (the products keep their size, every operand plane moves by s binades):
+    the three-plane split stays f32-class against the f32 MFMA chain -- powers of two commute with every rounding involved,
+    so the features are the unscaled run's bit for bit while nothing under- or overflows."""
+    from review_based_recommender_amd import _lib
+    _lib.lib().rbr_set_conv_mode(2)
+    try:
+        cfg = synth.DEEPCONN_CFGS["cfg1"]
+        sd = synth.deepconn_params(cfg, 0)
+        b = synth.deepconn_batch(cfg, 1)
+        ids = torch.cat([b["u_docs"], b["i_docs"]]).to(DEV)
+        masks = torch.cat([b["u_masks"], b["i_masks"]]).to(DEV)
+        table = sd["word_embeddings.embedding.weight"].to(DEV)
+        ws = [sd[f"ngram.feature_layer.0.list_of_conv1d.{i}.weight"].to(DEV) for i in range(len(cfg["kz"]))]
+        bs = [sd[f"ngram.feature_layer.0.list_of_conv1d.{i}.bias"].to(DEV) for i in range(len(cfg["kz"]))]
+        ref = _features(table, ids, masks, ws, bs, "f32")
+        base = _features(table, ids, masks, ws, bs, "bf16x3")
+        s = 2.0 ** log2_scale
+        scaled = _features(table * s, ids, masks, [w / s for w in ws], bs, "bf16x3")
+        scaled_f32 = _features(table * s, ids, masks, [w / s for w in ws], bs, "f32")
+        tol = 2e-5 * float(ref.abs().max())
+        assert float((base - ref).abs().max()) <= tol
+        assert float((scaled - scaled_f32).abs().max()) <= tol
+        assert torch.equal(scaled, base), "a power-of-two operand scale changed the split's result"
+    finally:
+        _lib.lib().rbr_set_conv_mode(0)
+
+
+def test_bf16x3_small_magnitudes_and_non_finite_rows():
+    """Where the split stops being exact, and what it does there (documented in include/rbr_hip.h):
+      * operands below ~2^-110: the low plane (2^-16 of the operand) falls under the bf16 / f32 normal range and is lost --
+        accuracy degrades towards the two-plane class, it does not fail: features within 1e-3 relative of the f32 chain;
+      * a table row holding inf or NaN is outside the supported domain (x - hi = inf - inf poisons the lower planes; the
+        max-pool's `>` comparisons drop NaN where torch's max_pool1d would propagate it): what is guaranteed, and checked here
+        for both classes, is containment -- a document that never reads the row is untouched."""
+    from review_based_recommender_amd import _lib
+    _lib.lib().rbr_set_conv_mode(2)
+    try:
+        cfg = synth.DEEPCONN_CFGS["cfg1"]
+        sd = synth.deepconn_params(cfg, 0)
+        b = synth.deepconn_batch(cfg, 1)
+        ids = torch.cat([b["u_docs"], b["i_docs"]]).to(DEV)
+        masks = torch.cat([b["u_masks"], b["i_masks"]]).to(DEV)
+        table = sd["word_embeddings.embedding.weight"].to(DEV)
+        ws = [sd[f"ngram.feature_layer.0.list_of_conv1d.{i}.weight"].to(DEV) for i in range(len(cfg["kz"]))]
+        bs = [torch.zeros_like(sd[f"ngram.feature_layer.0.list_of_conv1d.{i}.bias"]).to(DEV) for i in range(len(cfg["kz"]))]
+        tiny = 2.0 ** -118
+        t_small = table * tiny                                   # operands around 2^-118 .. 2^-116, products around 2^-120
+        ref = _features(t_small, ids, masks, ws, bs, "f32")
+        got = _features(t_small, ids, masks, ws, bs, "bf16x3")
+        assert float(ref.abs().max()) > 0.0
+        assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+        # one poisoned vocabulary row
+        tok = int(ids[masks].flatten()[0])
+        reads = ((ids == tok) & masks).any(dim=1)
+        for bad in (float("inf"), float("nan")):
+            t_bad = table.clone()
+            t_bad[tok, 3] = bad
+            for prec in ("f32", "bf16x3"):
+                f = _features(t_bad, ids, masks, ws, bs, prec)
+                finite = torch.isfinite(f).all(dim=1)
+                assert bool(finite[~reads].all()), (bad, prec, "a document that never reads the row was poisoned")
+                clean = _features(table, ids, masks, ws, bs, prec)
+                assert torch.equal(f[~reads], clean[~reads]), (bad, prec)
+    finally:
+        _lib.lib().rbr_set_conv_mode(0)

@@ -73,11 +73,11 @@ def test_fast_step_trains_like_the_eager_step(tmp_path):
         assert abs(va - vb) <= 5e-3 * max(1.0, abs(va)), (a, b)
 
 
-@pytest.mark.parametrize("kind", ["deepconn", "narre"])
+@pytest.mark.parametrize("kind", ["deepconn", "narre", "dual_att"])
 def test_one_epoch_follows_the_oracle_step_by_step(tmp_path, kind):
     """f-1 numerics: one epoch with dropout 0 and shuffling off -- every step's training loss and the
     validation RMSE after the epoch against the CPU oracle driven over the SAME batches in the same order
-    (trainer/train_deepconn_pp.py:143-168 train loop, :191-232 validation)."""
+    (trainer/train_deepconn_pp.py:143-168 train loop, :191-232 validation; train_dual_att.py:158-164 for D-ATT)."""
     import math
 
     from oracle import ref_cpu as O
@@ -87,7 +87,7 @@ def test_one_epoch_follows_the_oracle_step_by_step(tmp_path, kind):
     exp = ReviewExperiment(kind, parse_args(_cfg(tmp_path, kind, data_dir, dropout=0.0, shuffle=False, record_steps=True,
                                                  epochs=1, batch_size=16)), uid="o1")
     p0 = {k: v.detach().cpu().clone() for k, v in exp.model.state_dict().items()}
-    fwd = O.deepconn_forward if kind == "deepconn" else (lambda q, *b: O.narre_forward(q, *b)[0])
+    fwd = {"deepconn": O.deepconn_forward, "narre": (lambda q, *b: O.narre_forward(q, *b)[0]), "dual_att": O.datt_forward}[kind]
     steps = [((lambda q, b=b: fwd(q, *b[:-1])), b[-1]) for b in exp.train_loader]
     exp.train_one_epoch(0)
     exp.valid_one_epoch()
