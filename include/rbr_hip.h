@@ -107,6 +107,12 @@ void rbr_set_conv_mode(int32_t mode);
 #define RBR_PROD_BF16 3
 void rbr_set_prod_precision(int32_t mode);
 int32_t rbr_get_prod_precision(void);
+/* RBR_PROD_BF16 with bf16 STORAGE (default on; 0 = f32 streams, -1 = default / env RBR_B16_STORAGE): the byte streams of the
+ * conv stage are bf16 as well -- the distinct tokens' rows are rounded once into a compact bf16 copy the GEMM reads (600-byte
+ * rows by plain index, no conversion in the loop), and the product table T is stored in bf16 (the gather-add reads half the
+ * bytes; its sums stay f32).  Same tolerance class as RBR_PROD_BF16 with f32 streams (tests/test_precision_gpu.py); parameters,
+ * Adam state and every gradient stay f32.  Like the precision itself: set between steps only. */
+void rbr_set_b16_storage(int32_t on);
 int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                          const float* table, const float* const* W, const float* packed, float* pval, int32_t* pidx,
                          void* ws, void* stream);

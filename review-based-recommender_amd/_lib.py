@@ -83,6 +83,7 @@ SIGNATURES = {
     "rbr_set_conv_mode": (None, [i32]),
     "rbr_set_prod_precision": (None, [i32]),
     "rbr_get_prod_precision": (i32, []),
+    "rbr_set_b16_storage": (None, [i32]),
     "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, _PP, c_f32p, c_f32p, c_i32p, C.c_void_p,
                                        c_stream]),
     "rbr_textcnn_prod_prepare": (C.c_int, [_DESC, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p, c_stream]),

@@ -151,31 +151,37 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
             constexpr int U = 4;
             float4 G[U], M[U], V[U], P[U];
             long goff[U];
-            int idx[U];
-            bool have[U];
+            int idx[U], r[U];
+            unsigned e[U], tok[U];
+            // round 1: the list row of every float4's token and the p / m / v streams -- 16 independent loads per thread in flight;
+            // round 2 (needs the list rows): the gradient rows.  Nothing in round 1 waits for anything.
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = threadIdx.x + 256 * u;
-                idx[u] = min(i, n4r - 1);
-                const unsigned e = (unsigned)(e0 + 4 * idx[u]);              // numel < 2^32: checked on the host
-                const unsigned tok = e / (unsigned)D;
-                const int r = T.row_of_token[tok];
-                have[u] = r >= 0;
-                goff[u] = (long)max(r, 0) * D + (e - tok * (unsigned)D);
+                idx[u] = min((int)threadIdx.x + 256 * u, n4r - 1);
+                e[u] = (unsigned)(e0 + 4 * idx[u]);                          // numel < 2^32: checked on the host
+                tok[u] = e[u] / (unsigned)D;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = T.row_of_token[tok[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 M[u] = reinterpret_cast<float4*>(m)[idx[u]]; V[u] = reinterpret_cast<float4*>(v)[idx[u]];
                 P[u] = reinterpret_cast<float4*>(p)[idx[u]];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                goff[u] = (long)max(r[u], 0) * D + (e[u] - tok[u] * (unsigned)D);
                 G[u] = *reinterpret_cast<const float4*>(T.grows + goff[u]);
-                if (!have[u]) G[u] = float4{0.f, 0.f, 0.f, 0.f};
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (r[u] < 0) G[u] = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if ((int)threadIdx.x + 256 * u >= n4r) continue;
                 RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
                 RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
-                if (clipped && have[u]) *reinterpret_cast<float4*>(T.grows + goff[u]) = G[u];
+                if (clipped && r[u] >= 0) *reinterpret_cast<float4*>(T.grows + goff[u]) = G[u];
                 reinterpret_cast<float4*>(m)[idx[u]] = M[u];
                 reinterpret_cast<float4*>(v)[idx[u]] = V[u];
                 reinterpret_cast<float4*>(p)[idx[u]] = P[u];

@@ -88,7 +88,10 @@ size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real);
 struct B16Pack;
 B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d);     // textcnn_b16.h
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
-                  const float* table, const void* bimg, float* T, hipStream_t st);
+                  const float* table, const void* bimg, void* T, void* a16, hipStream_t st);
+// bf16 STORAGE of the plain-bf16 class (textcnn_prod_b16.hip): T holds bf16, and `a16` (prod_b16_rows_bytes) the compact bf16 rows
+bool prod_t_bf16(const rbr_textcnn_desc* d);
+size_t prod_b16_rows_bytes(const rbr_textcnn_desc* d, int cap);
 // Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not
 // hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and stays a chain of
 // plain kernel nodes (memset nodes of these shapes faulted on replay with ROCm 7.2).

@@ -20,6 +20,13 @@ constexpr int kB16BFrag = 1024;                                 // one (tile, pl
 constexpr int kB16BBytes = (kB16BN / 32) * 3 * kB16BFrag;       // 12 KiB
 constexpr int kB16Lds = kB16Stages * (kB16ABytes + kB16BBytes); // 80 KiB: two workgroups per CU
 static_assert(kB16Waves == 4 && kB16Stages == 4, "the fill schedule below (5 LDS-DMA instructions per wave and stage) assumes 4 x 4");
+// "bf16 storage" form of the GEMM (RBR_PROD_BF16 only; textcnn_prod_b16.hip: prod_gemm_b16s_kernel): the token rows come from a
+// compact bf16 copy [list rows][kB16sDp(D)] made once per forward, the product table T is written in bf16, a stage is 32 deep
+constexpr int kB16sKC = 32;
+constexpr int kB16sABytes = kB16BM * kB16sKC * 2;               // 8 KiB: [128 rows][4 x 16 B]
+constexpr int kB16sBBytes = 2 * (kB16BN / 32) * kB16BFrag;      // 8 KiB: [2 k-halves][4 tiles] hi-plane fragments
+constexpr int kB16sLds = kB16Stages * (kB16sABytes + kB16sBBytes);   // 64 KiB
+inline int b16s_dp(int D) { return (D + kB16sKC - 1) / kB16sKC * kB16sKC; }      // row length of the compact bf16 copy
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);       // v_cvt_pk_bf16_f32 (round to nearest even)

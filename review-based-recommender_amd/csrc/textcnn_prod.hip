@@ -167,11 +167,17 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // segm
 
 // (Measured and dropped in round 3: clearing the backward's G with extra workgroups of this launch -- 59.6 us against 42.7 + 10.9
 // for the separate zero launch, and, worse, G is then cold when the backward reads it: g_times_w 59 -> 72 us.)
+typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(2)));  // four bf16 of a segment that starts at any element
+// TB16: T holds bf16 (the plain-bf16 class with bf16 storage, textcnn_prod_b16.hip): a position's row segments are half the bytes
+// -- this kernel is bound by L2 requests for exactly those -- and are widened to f32 in registers; the sums stay f32.
+template <bool TB16>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
-                                                          const int* __restrict__ row_of_token, const float* __restrict__ T,
+                                                          const int* __restrict__ row_of_token, const void* __restrict__ Tv,
                                                           const int* __restrict__ sched, float* __restrict__ pval,
                                                           int* __restrict__ pidx) {
+    const float* T = static_cast<const float*>(Tv);
+    const unsigned short* T16 = static_cast<const unsigned short*>(Tv);
     __shared__ int s_row[kWavesPerWG][kTile + kMaxKF];
     __shared__ float s_gate[kWavesPerWG][kTile + kMaxKF];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
             const int q = qb + ql;
             const bool valid = q < nquads;
             const float* tcol = T + A.poff[w] + 4 * (valid ? q : 0);
+            const unsigned short* tcol16 = T16 + A.poff[w] + 4 * (valid ? q : 0);
             float best[4] = {NEG, NEG, NEG, NEG};
             int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
             for (int p0 = 0; p0 < kTile; p0 += 8) {                       // two positions per lane and round:
@@ -218,7 +225,14 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int r = p0 + 4 * u + ps + j + off;
-                            const f32x4u v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
+                            f32x4 v;
+                            if (TB16) {
+                                const u32x2u b = *reinterpret_cast<const u32x2u*>(tcol16 + (long)s_row[wave][r] * A.pitch + j * ch);
+                                v = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                          __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
+                            } else {
+                                v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
+                            }
                             const float gv = s_gate[wave][r];
                             y[u].x = fmaf(v.x, gv, y[u].x); y[u].y = fmaf(v.y, gv, y[u].y);
                             y[u].z = fmaf(v.z, gv, y[u].z); y[u].w = fmaf(v.w, gv, y[u].w);
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
                                                       const int* __restrict__ row_of_token, const float* __restrict__ T,
                                                       const float* __restrict__ feat, const int* __restrict__ argmax,
                                                       const float* __restrict__ d_feat, float* __restrict__ G,
-                                                      float* __restrict__ dgate) {
+                                                      float* __restrict__ dgate, int t_bf16) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     const long o = e / A.KF;
     const int j = (int)(e - o * A.KF);
@@ -308,7 +322,11 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
     const int row = row_of_token[t];
     if (row < 0) return;
     const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
-    if (dgate != nullptr) atomicAdd(dgate + tok, g * T[(long)row * A.t_pitch + col]);
+    if (dgate != nullptr) {
+        const long at = (long)row * A.t_pitch + col;
+        const float tv = t_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(T)[at] << 16) : T[at];
+        atomicAdd(dgate + tok, g * tv);
+    }
     if (G == nullptr) return;
     // the pad token's row stays in G (the weight gradient needs it); its TABLE row gets no gradient: g_times_w zeroes it
     atomicAdd(G + (long)row * A.KG + col, (gate != nullptr) ? g * gate[tok] : g);
@@ -859,7 +877,7 @@ using namespace rbr;
 namespace {
 
 struct ProdLayout {      // byte offsets inside the workspace
-    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, bimg, table_T, total;
+    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, bimg, a16, table_T, total;
     int cap, Cp, tiles_p;
     rbr_textcnn_desc dp;
 };
@@ -917,6 +935,9 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     for (int w = 0; w < d->n_widths; ++w) cp_real += (long)d->kz[w] * d->ch[w];
     Lo.wt = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
     Lo.bimg = o;         o += prod_b16_applicable(d) ? align256(prod_b16_image_bytes(d, (int)cp_real)) : 0;
+    Lo.a16 = o;          o += align256(prod_b16_rows_bytes(d, Lo.cap));        // bf16 storage: compact bf16 copy of the listed rows
+    // (bf16 storage: T's elements are 2 bytes; the space is reserved for f32 either way -- the layout must not depend on more
+    // run-time state than it does today)
     Lo.table_T = o;      o += align256((((size_t)Lo.cap + 1) * p.nslots_total + 4) * sizeof(float));   // + one float4 of slack: quads read whole
     Lo.total = o;
     return true;
@@ -1122,7 +1143,7 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
         const long n_items = (long)d->n_docs * A.C * A.KF;
         hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
                            reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat,
-                           want_g ? G : nullptr, dgate);
+                           want_g ? G : nullptr, dgate, prod_t_bf16(d) ? 1 : 0);
         RBR_CHECK_LAUNCH("textcnn build_g launch");
     }
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
@@ -1236,7 +1257,10 @@ static int prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uin
     const int nb_pack = (int)std::min<long>((n_pack + 255) / 256, 2048);
     // (bf16-plane GEMM: the weight planes in MFMA-fragment order instead of the f32 tile image)
     hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, S.Lo.cap, S.used,
-                       S.row_of_token, S.tok_of_row, S.row_mask, S.counter, S.T + (size_t)S.Lo.cap * S.A.pitch, S.A.pitch, wp,
+                       S.row_of_token, S.tok_of_row, S.row_mask, S.counter,
+                       prod_t_bf16(d) ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(S.T) + (size_t)S.Lo.cap * S.A.pitch)
+                                      : S.T + (size_t)S.Lo.cap * S.A.pitch,
+                       prod_t_bf16(d) ? S.A.pitch / 2 : S.A.pitch, wp,
                        b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
     return 0;
@@ -1332,7 +1356,7 @@ extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* ta
     if (int e = prod_state(d, ws, S)) return e;
     if (prod_b16_applicable(d))
         return prod_b16_gemm(d, S.A.cp_real, S.Lo.cap, S.A.pitch, S.counter, S.tok_of_row, table, S.base + S.Lo.bimg, S.T,
-                             (hipStream_t)stream);
+                             S.base + S.Lo.a16, (hipStream_t)stream);
     return run_conv_groups(S.pp, 1, S.tok_of_row, S.row_mask, nullptr, table, S.packed_p, S.T, nullptr, S.sched_p, (hipStream_t)stream);
 }
 
@@ -1349,8 +1373,12 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     hipStream_t st = (hipStream_t)stream;
     const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(gather_pool_kernel, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
-                       reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, S.T, sched, pval, pidx);
+    if (prod_t_bf16(d))
+        hipLaunchKernelGGL(gather_pool_kernel<true>, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
+                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx);
+    else
+        hipLaunchKernelGGL(gather_pool_kernel<false>, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
+                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx);
     RBR_CHECK_LAUNCH("textcnn gather_pool launch");
     return 0;
 }

@@ -190,6 +190,140 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
     }
 }
 
+// ---------------------------------------------------------------------------------- bf16 storage form (RBR_PROD_BF16)
+// The reduced-precision class as BASELINE configs 3 and 5 name it: not only the MFMA operands but the byte streams are bf16.
+//   rows_to_b16   : the distinct tokens' table rows, rounded once, as a compact [list rows][Dp] bf16 array (zero-padded to a
+//                   multiple of 32): every channel group of the GEMM re-reads 600-byte rows instead of 1200-byte ones, by plain
+//                   row index (no token indirection), and no wave converts anything in the loop;
+//   prod_gemm_b16s: 32-deep stages, 2 + 2 LDS-DMA instructions per wave and stage for 8 MFMAs (the f32-row kernel: 5 for 4 --
+//                   the LDS-fill path that bounds it), only the hi weight plane is staged, T is written as bf16 (the gather reads
+//                   half the bytes, which is what bounds IT).
+struct B16sGemm {
+    const int* counter;
+    const unsigned short* a16;       // [rows][Dp] bf16
+    const unsigned char* bimg;       // as B16Gemm
+    unsigned short* T;               // [rows][pitch] bf16
+    int cap, Dp, pitch, ngroups, nchunks16;
+};
+
+__global__ __launch_bounds__(256) void rows_to_b16_kernel(const int* __restrict__ counter, int cap, int D, int Dp,
+                                                          const long long* __restrict__ tok_of_row, const float* __restrict__ table,
+                                                          unsigned short* __restrict__ a16) {
+    const int n = min(*counter, cap);
+    const int segs = Dp / 8;                                   // 16-byte output segments per row
+    const long total = (long)n * segs;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
+        const int row = (int)(k / segs), sg = (int)(k - (long)row * segs);
+        const int col = sg * 8;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (col < D) {                                         // D % 4 == 0: a float4 never straddles the row end
+            const float* src = table + tok_of_row[row] * (long)D + col;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src);
+            f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+            if (col + 4 < D) x1 = *reinterpret_cast<const f32x4*>(src + 4);
+            o = u32x4{pack_bf16(x0.x, x0.y), pack_bf16(x0.z, x0.w), pack_bf16(x1.x, x1.y), pack_bf16(x1.z, x1.w)};
+        }
+        *reinterpret_cast<u32x4*>(a16 + (long)row * Dp + col) = o;
+    }
+}
+
+__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16s_kernel(const B16sGemm g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int n = min(*g.counter, g.cap);
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int mblock = (jj / g.ngroups) * 8 + xcd, ng = jj - (jj / g.ngroups) * g.ngroups;
+    const int m0 = mblock * kB16BM;
+    if (m0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const Abuf = smem;
+    unsigned char* const Bbuf = smem + kB16Stages * kB16sABytes;
+    const int nch = g.Dp / kB16sKC;                            // stages
+
+    // gather role: instruction q moves rows wave*32 + q*16 .. +15 (this wave's own tile), lane = (row in 16, 16-byte position)
+    long aoff[2];
+    int aseg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rl = wave * 32 + q * 16 + (lane >> 2);
+        const int row = m0 + rl;
+        aoff[q] = (row < n) ? (long)row * g.Dp : -1;
+        aseg[q] = ((lane & 3) ^ ((rl >> 2) & 3)) * 8;          // position p of the row holds segment p ^ swz(row) (8 bf16 each)
+    }
+    // hi-plane weight fragments of a stage: (k-half 0 | 1) x tile `wave`; image chunk = 16 k: [group][chunk16][tile][plane][1 KiB]
+    const unsigned char* bsrc = g.bimg + ((size_t)ng * g.nchunks16) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
+    auto issue_a = [&](int c) {
+        const int buf = c & (kB16Stages - 1), cs = min(c, nch - 1);
+        unsigned char* A = Abuf + buf * kB16sABytes + wave * 32 * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const void* src = (aoff[q] >= 0) ? static_cast<const void*>(g.a16 + aoff[q] + cs * kB16sKC + aseg[q])
+                                             : static_cast<const void*>(g_b16_zero);
+            b16_dma16(src, A + q * 16 * 64);
+        }
+    };
+    auto issue_b = [&](int c) {
+        const int buf = c & (kB16Stages - 1);
+        unsigned char* B = Bbuf + buf * kB16sBBytes + wave * kB16BFrag;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int c16 = min(2 * min(c, nch - 1) + kh, g.nchunks16 - 1);      // past the image: any finite weights (the rows are zero there)
+            b16_dma16(bsrc + (size_t)c16 * kB16BBytes, B + kh * 4 * kB16BFrag);
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int r32 = lane & 31, h = lane >> 5;
+    const int swz = (r32 >> 2) & 3;
+    const int arow = (wave * 32 + r32) * 64;
+    const int rd0 = (h ^ swz) * 16, rd1 = ((2 + h) ^ swz) * 16;         // k-halves of the stage's two 16-deep MFMA steps
+
+    for (int c = 0; c < 3; ++c) { issue_a(c); issue_b(c); }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     // stage 0 (4 fills per wave and stage)
+    bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Abuf + arow + rd0), a1 = *reinterpret_cast<const bf16x8*>(Abuf + arow + rd1);
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // weights of stage c landed for every wave; every wave is done with stage c - 1
+        asm volatile("" ::: "memory");
+        const unsigned char* B = Bbuf + (c & (kB16Stages - 1)) * kB16sBBytes + lane * 16;
+        const unsigned char* An = Abuf + ((c + 1) & (kB16Stages - 1)) * kB16sABytes + arow;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, *reinterpret_cast<const bf16x8*>(B + t * kB16BFrag), acc[t], 0, 0, 0);
+            if (t == 0) issue_a(c + 3);       // into the slot of stage c - 1
+            if (t == 1) issue_b(c + 3);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(B + (4 + t) * kB16BFrag), acc[t], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // this wave's own rows of stage c + 1 (its fills are 8 instructions back)
+        a0 = *reinterpret_cast<const bf16x8*>(An + rd0);
+        a1 = *reinterpret_cast<const bf16x8*>(An + rd1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // C/D map of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); neighbouring lanes pair
+    // their columns so that every store moves 4 bytes (two bf16)
+    unsigned short* out = g.T + (size_t)(m0 + wave * 32 + 4 * h) * g.pitch + ng * kB16BN + (r32 & ~1);
+    const int rows_left = n - (m0 + wave * 32 + 4 * h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float mine = acc[t][r];
+            const float other = __shfl_xor(mine, 1);
+            // even lane: (mine, other) of tile t for this row -- every lane takes part in the shuffle, the even ones store
+            if (!(r32 & 1) && dr < rows_left)
+                *reinterpret_cast<unsigned*>(out + (size_t)dr * g.pitch + t * 32) = pack_bf16(mine, other);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- host side
 static int g_prod_precision = -1;        // -1: RBR_PROD_PRECISION env or the default (bf16x3)
 
@@ -206,6 +340,18 @@ int prod_precision() {
 }
 
 bool prod_b16_applicable(const rbr_textcnn_desc* d) { return prod_precision() != RBR_PROD_F32 && d->D % 4 == 0; }
+
+// bf16 STORAGE (rows copy, product table): the plain-bf16 class only; RBR_B16_STORAGE=0 keeps f32 streams (an A/B switch: same
+// arithmetic class either way, T's extra rounding stays inside the class's stated tolerances)
+static int g_b16_storage = -1;           // -1: RBR_B16_STORAGE env (default on), 0 off, 1 on
+bool prod_t_bf16(const rbr_textcnn_desc* d) {
+    static const char* env = getenv("RBR_B16_STORAGE");
+    const bool on = g_b16_storage >= 0 ? g_b16_storage != 0 : !(env && !strcmp(env, "0"));
+    return on && prod_b16_applicable(d) && prod_precision() == RBR_PROD_BF16;
+}
+size_t prod_b16_rows_bytes(const rbr_textcnn_desc* d, int cap) {
+    return prod_t_bf16(d) ? (size_t)(cap + kB16BM) * b16s_dp(d->D) * 2 : 0;
+}
 
 int prod_b16_groups(int cp_real) { return (cp_real + kB16BN - 1) / kB16BN; }
 size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real) {
@@ -224,8 +370,31 @@ B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d) {
 }
 
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
-                  const float* table, const void* bimg, float* T, hipStream_t st) {
+                  const float* table, const void* bimg, void* Tv, void* a16, hipStream_t st) {
     if (((uintptr_t)table & 15) != 0) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
+    if (prod_t_bf16(d)) {
+        if (!a16) { set_error("bf16 storage needs the row workspace"); return RBR_ERR_BAD_ARG; }
+        B16sGemm g{};
+        g.counter = counter; g.a16 = static_cast<const unsigned short*>(a16); g.bimg = static_cast<const unsigned char*>(bimg);
+        g.T = static_cast<unsigned short*>(Tv); g.cap = cap; g.Dp = b16s_dp(d->D); g.pitch = pitch; g.ngroups = prod_b16_groups(cp_real);
+        g.nchunks16 = (d->D + kB16KC - 1) / kB16KC;
+        if (pitch < g.ngroups * kB16BN || (pitch & 1)) { set_error("product table pitch %d unusable", pitch); return RBR_ERR_BAD_ARG; }
+        static bool attr_s = false;
+        if (!attr_s) {
+            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16s_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kB16sLds), "prod_gemm_b16s LDS")) return e;
+            attr_s = true;
+        }
+        const long segs = (long)cap * (g.Dp / 8);
+        hipLaunchKernelGGL(rows_to_b16_kernel, dim3((unsigned)std::min<long>((segs + 255) / 256, 4096)), dim3(256), 0, st, counter, cap, d->D,
+                           g.Dp, tok_of_row, table, static_cast<unsigned short*>(a16));
+        RBR_CHECK_LAUNCH("textcnn rows_to_b16 launch");
+        const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
+        hipLaunchKernelGGL(prod_gemm_b16s_kernel, dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16sLds, st, g);
+        RBR_CHECK_LAUNCH("textcnn prod_gemm_b16s launch");
+        return 0;
+    }
+    float* T = static_cast<float*>(Tv);
     B16Gemm g{};
     g.counter = counter; g.tok_of_row = tok_of_row; g.table = table; g.bimg = static_cast<const unsigned char*>(bimg); g.T = T;
     g.cap = cap; g.D = d->D; g.pitch = pitch; g.ngroups = prod_b16_groups(cp_real); g.nchunks = (d->D + kB16KC - 1) / kB16KC;
@@ -259,3 +428,4 @@ extern "C" void rbr_set_prod_precision(int32_t mode) {
     rbr::g_prod_precision = (mode >= RBR_PROD_F32 && mode <= RBR_PROD_BF16) ? mode : -1;
 }
 extern "C" int32_t rbr_get_prod_precision(void) { return rbr::prod_precision(); }
+extern "C" void rbr_set_b16_storage(int32_t on) { rbr::g_b16_storage = (on == 0 || on == 1) ? on : -1; }

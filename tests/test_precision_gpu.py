@@ -224,3 +224,46 @@ def test_bf16x3_small_magnitudes_and_non_finite_rows():
                 assert torch.equal(f[~reads], clean[~reads]), (bad, prec)
     finally:
         _lib.lib().rbr_set_conv_mode(0)
+
+
+def test_bf16_storage_stays_inside_the_bf16_class(golden_dir):
+    """RBR_PROD_BF16 with bf16 STORAGE (compact bf16 row copy + bf16 product table; the default of the class) against the same
+    class with f32 streams (rbr_set_b16_storage(0)) and against the reference fixture: the extra rounding of T (one 2^-9
+    relative step per tap term) keeps features, predictions, loss and gradient norms inside the class's stated tolerances."""
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd import functional as RF
+    L_ = _lib.lib()
+    g = golden(golden_dir, "deepconn_cfg2")
+    cfg = synth.DEEPCONN_CFGS["cfg2"]
+    args, ratings = _deepconn_batch(cfg, False)
+    L_.rbr_set_conv_mode(2)
+    RF.set_prod_precision("bf16")
+    out = {}
+    try:
+        for storage in (0, 1):
+            L_.rbr_set_b16_storage(storage)
+            model = _deepconn(cfg)
+            model.eval()
+            with torch.no_grad():
+                pred = model(*args).clone()
+                ids = torch.cat([args[0], args[1]])
+                masks = torch.cat([args[2], args[3]])
+                conv = model.ngram.feature_layer[0]
+                feat = RF.textcnn(model.word_embeddings.weight, ids, masks, conv.weights(), conv.biases()).clone()
+            model.train()
+            loss = torch.nn.functional.mse_loss(model(*args), ratings)
+            loss.backward()
+            out[storage] = (pred, feat, float(loss), _grad_norm_errs(model, g))
+    finally:
+        L_.rbr_set_b16_storage(-1)
+        RF.set_prod_precision(None)
+        L_.rbr_set_conv_mode(0)
+    for storage, (pred, feat, loss, gerrs) in out.items():
+        err = max_err(pred.cpu().numpy(), g["pred_eval"])
+        assert 1e-6 < err <= 3e-2, (storage, err)
+        assert abs(loss - float(g["loss"])) <= 2e-2 * float(g["loss"]), (storage, loss)
+        assert max(gerrs.values()) <= 5e-2, (storage, gerrs)
+    # the two forms differ from each other by T's rounding only
+    fscale = float(out[0][1].abs().max())
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 6e-3 * fscale
+    assert not torch.equal(out[0][1], out[1][1]), "bf16 storage was not engaged"
