@@ -207,8 +207,7 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
             // independent float4 loads are in flight together
             for (int dl = dsub; dl < nb; dl += 4 * dpar) {
                 f32x4 x[4][kDwMaxM];
-                u32x2 xb[4][kDwMaxM];          // RB16: the raw bf16 quads -- widened only where they are used, so that all the
-                float sc[4][kDwMaxM];          // loads of the round are issued before the first conversion waits for one
+                float sc[4][kDwMaxM];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int du = dl + u * dpar;
@@ -218,8 +217,13 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
                     for (int m = 0; m < kDwMaxM; ++m) {
                         if (m < M) {
                             const int e = dq * kz + jsub + m * jslots;
-                            if (RB16) xb[u][m] = *reinterpret_cast<const u32x2*>(a16 + s_row[e] + 4 * q4);
-                            else x[u][m] = *reinterpret_cast<const f32x4*>(table + s_row[e] + 4 * q4);
+                            if (RB16) {
+                                const u32x2 b = *reinterpret_cast<const u32x2*>(a16 + s_row[e] + 4 * q4);
+                                x[u][m] = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                                __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
+                            } else {
+                                x[u][m] = *reinterpret_cast<const f32x4*>(table + s_row[e] + 4 * q4);
+                            }
                             sc[u][m] = ok ? s_sc[e] : 0.f;
                         }
                     }
@@ -228,11 +232,7 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int m = 0; m < kDwMaxM; ++m)
-                        if (m < M) {
-                            if (RB16) x[u][m] = f32x4{__uint_as_float(xb[u][m].x << 16), __uint_as_float(xb[u][m].x & 0xffff0000u),
-                                                      __uint_as_float(xb[u][m].y << 16), __uint_as_float(xb[u][m].y & 0xffff0000u)};
-                            acc[m] += sc[u][m] * x[u][m];
-                        }
+                        if (m < M) acc[m] += sc[u][m] * x[u][m];
             }
         }
     }

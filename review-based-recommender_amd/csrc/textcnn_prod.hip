@@ -222,16 +222,6 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
             int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
             for (int p0 = 0; p0 < kTile; p0 += 8) {                       // two positions per lane and round:
                 f32x4 y[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // 2 * kz independent float4 loads in flight
-                u32x2u raw[kMaxKF][2];      // TB16: all the round's loads are issued before the first widening waits for one
-                if (TB16) {
-#pragma unroll
-                    for (int j = 0; j < kMaxKF; ++j)
-                        if (j < kz) {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                raw[j][u] = *reinterpret_cast<const u32x2u*>(tcol16 + (long)s_row[wave][p0 + 4 * u + ps + j + off] * A.pitch + j * ch);
-                        }
-                }
 #pragma unroll
                 for (int j = 0; j < kMaxKF; ++j) {
                     if (j < kz) {
@@ -240,8 +230,9 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
                             const int r = p0 + 4 * u + ps + j + off;
                             f32x4 v;
                             if (TB16) {
-                                v = f32x4{__uint_as_float(raw[j][u].x << 16), __uint_as_float(raw[j][u].x & 0xffff0000u),
-                                          __uint_as_float(raw[j][u].y << 16), __uint_as_float(raw[j][u].y & 0xffff0000u)};
+                                const u32x2u b = *reinterpret_cast<const u32x2u*>(tcol16 + (long)s_row[wave][r] * A.pitch + j * ch);
+                                v = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                          __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
                             } else {
                                 v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
                             }
@@ -419,8 +410,6 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
             }
             for (int q0 = 0; q0 < cnt; q0 += 4) {
                 f32x4 wv[4][kSpQ4];
-                typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-                u32x2w wb[4][kSpQ4];        // WB16: the raw bf16 quads, widened where they are used (all loads issued first)
                 float gv[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -432,7 +421,10 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
                     for (int u = 0; u < kSpQ4; ++u) {
                         if (WB16) {         // WT holds bf16 (bf16 storage of the plain-bf16 class): 600-byte weight rows from L2
                             const unsigned short* wr16 = reinterpret_cast<const unsigned short*>(WT) + s_pc[it];
-                            wb[v][u] = *reinterpret_cast<const u32x2w*>(wr16 + max(doff[u], 0));      // unconditional: lanes past D discard
+                            typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+                            const u32x2w b = (doff[u] >= 0) ? *reinterpret_cast<const u32x2w*>(wr16 + doff[u]) : u32x2w{0u, 0u};
+                            wv[v][u] = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
+                                             __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
                         } else {
                             wv[v][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
@@ -441,11 +433,7 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int u = 0; u < kSpQ4; ++u) {
-                        if (WB16) wv[v][u] = f32x4{__uint_as_float(wb[v][u].x << 16), __uint_as_float(wb[v][u].x & 0xffff0000u),
-                                                   __uint_as_float(wb[v][u].y << 16), __uint_as_float(wb[v][u].y & 0xffff0000u)};
-                        sum[u] += gv[v] * wv[v][u];
-                    }
+                    for (int u = 0; u < kSpQ4; ++u) sum[u] += gv[v] * wv[v][u];
             }
 #pragma unroll
             for (int u = 0; u < kSpQ4; ++u)
