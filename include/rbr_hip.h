@@ -110,8 +110,7 @@ int32_t rbr_get_prod_precision(void);
 /* RBR_PROD_BF16 with bf16 STORAGE (default on; 0 = f32 streams, -1 = default / env RBR_B16_STORAGE): the byte streams of the
  * conv stage are bf16 as well -- the distinct tokens' rows are rounded once into a compact bf16 copy the GEMM reads (600-byte
  * rows by plain index, no conversion in the loop), and the product table T is stored in bf16 (the gather-add reads half the
- * bytes; its sums stay f32); in the backward the sparse product reads a bf16 Wprod^T and the weight gradient the bf16 row copy
- * (gradients of the class: operands rounded to bf16, f32 sums).  Same tolerance class as RBR_PROD_BF16 with f32 streams (tests/test_precision_gpu.py); parameters,
+ * bytes; its sums stay f32).  Same tolerance class as RBR_PROD_BF16 with f32 streams (tests/test_precision_gpu.py); parameters,
  * Adam state and every gradient stay f32.  Like the precision itself: set between steps only. */
 void rbr_set_b16_storage(int32_t on);
 int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
@@ -160,11 +159,6 @@ size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d);
 int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                        const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
                        float* const* dW, float* const* dbias, float* ws, void* stream);
-/* rbr_textcnn_bwd_dw for a forward that ran the product formulation, `fwd_ws` still intact: with bf16 storage in force
- * (rbr_set_b16_storage) the window rows are read from the forward's compact bf16 row copy; otherwise identical. */
-int rbr_textcnn_bwd_dw_ws(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                          const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
-                          float* const* dW, float* const* dbias, float* ws, void* fwd_ws, void* stream);
 int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                            const float* table, const float* packed, const float* feat, const int32_t* argmax,
                            const float* d_feat, float* dtable, float* dgate, void* stream);

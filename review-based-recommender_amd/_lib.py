@@ -93,8 +93,6 @@ SIGNATURES = {
     "rbr_textcnn_bwd_ws_floats": (C.c_size_t, [_DESC]),
     "rbr_textcnn_bwd_dw": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP, c_f32p,
                                      c_stream]),
-    "rbr_textcnn_bwd_dw_ws": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP, c_f32p, C.c_void_p,
-                                        c_stream]),
     "rbr_textcnn_bwd_dtable": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p,
                                          c_f32p, c_stream]),
     "rbr_textcnn_bwd_prod_ws_bytes": (C.c_size_t, [_DESC]),

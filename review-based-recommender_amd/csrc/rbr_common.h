@@ -92,8 +92,6 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
 // bf16 STORAGE of the plain-bf16 class (textcnn_prod_b16.hip): T holds bf16, and `a16` (prod_b16_rows_bytes) the compact bf16 rows
 bool prod_t_bf16(const rbr_textcnn_desc* d);
 size_t prod_b16_rows_bytes(const rbr_textcnn_desc* d, int cap);
-// the forward's compact bf16 rows inside `fwd_ws` (textcnn_prod.hip); false when bf16 storage is not in force for `d`
-bool prod_b16_rows(const rbr_textcnn_desc* d, void* fwd_ws, const int** row_of_token, const unsigned short** a16, int* Dp);
 // Zero-fills up to three regions (4-byte aligned, sizes multiples of 4) with ONE kernel launch.  A kernel, not
 // hipMemsetAsync: the launch sequence is recorded into hipGraphs (train_step.GraphedTrainStep) and stays a chain of
 // plain kernel nodes (memset nodes of these shapes faulted on replay with ROCm 7.2).

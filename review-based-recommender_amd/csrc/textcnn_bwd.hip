@@ -138,17 +138,13 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
 // Partial sums of the `dpar` document classes meet in LDS; same slabs, same dw_reduce.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // kDwMaxM = taps per thread (compile-time bound: the register arrays below are sized by it)
-// RB16: the window rows come from the forward's compact bf16 copy of the batch's distinct rows (bf16 storage of the plain-bf16
-// class, textcnn_prod_b16.hip): a16[row_of_token[id]], Dp elements apart -- half the bytes of the L2-bound row reads.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-template <int kDwMaxM, bool RB16>
+template <int kDwMaxM>
 __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ gate, const float* __restrict__ table,
                                                           const float* __restrict__ feat, const int* __restrict__ argmax,
                                                           const float* __restrict__ d_feat, float* __restrict__ ws_w,
-                                                          float* __restrict__ ws_b, const int* __restrict__ row_of_token,
-                                                          const unsigned short* __restrict__ a16, int Dp) {
+                                                          float* __restrict__ ws_b) {
     __shared__ long s_row[kDocsPerBatch * kMaxKF];
     __shared__ float s_sc[kDocsPerBatch * kMaxKF];
     __shared__ float s_g[kDocsPerBatch];
@@ -186,13 +182,8 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
             if (g != 0.f && p >= 0 && p < L) {
                 const long tok = (long)(b0 + dl) * L + p;
                 if (mask == nullptr || mask[tok]) {
-                    if (RB16) {
-                        const int r = row_of_token[ids[tok]];
-                        if (r >= 0) { row = (long)r * Dp; sc = (gate != nullptr) ? g * gate[tok] : g; }
-                    } else {
-                        row = ids[tok] * (long)D;
-                        sc = (gate != nullptr) ? g * gate[tok] : g;
-                    }
+                    row = ids[tok] * (long)D;
+                    sc = (gate != nullptr) ? g * gate[tok] : g;
                 }
             }
             s_row[e] = row;
@@ -217,13 +208,7 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
                     for (int m = 0; m < kDwMaxM; ++m) {
                         if (m < M) {
                             const int e = dq * kz + jsub + m * jslots;
-                            if (RB16) {
-                                const u32x2 b = *reinterpret_cast<const u32x2*>(a16 + s_row[e] + 4 * q4);
-                                x[u][m] = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
-                                                __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
-                            } else {
-                                x[u][m] = *reinterpret_cast<const f32x4*>(table + s_row[e] + 4 * q4);
-                            }
+                            x[u][m] = *reinterpret_cast<const f32x4*>(table + s_row[e] + 4 * q4);
                             sc[u][m] = ok ? s_sc[e] : 0.f;
                         }
                     }
@@ -693,34 +678,11 @@ extern "C" size_t rbr_textcnn_bwd_ws_floats(const rbr_textcnn_desc* d) {
     return (size_t)A.NCH * A.C * A.KF * A.D + (size_t)A.NCH * A.C;
 }
 
-static int bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                  const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
-                  float* const* dW, float* const* dbias, float* ws, void* fwd_ws, void* stream);
-
 extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                   const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
                                   float* const* dW, float* const* dbias, float* ws, void* stream) {
-    return bwd_dw(d, ids, mask, gate, table, feat, argmax, d_feat, dW, dbias, ws, nullptr, stream);
-}
-
-// rbr_textcnn_bwd_dw for a forward that ran in the token-product formulation with `fwd_ws` still intact: in the plain-bf16 class
-// with bf16 storage the window rows are read from the forward's compact bf16 row copy (half the bytes; the rounding the forward's
-// GEMM applied to the same rows).  Every other configuration: exactly rbr_textcnn_bwd_dw.
-extern "C" int rbr_textcnn_bwd_dw_ws(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                                     const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
-                                     float* const* dW, float* const* dbias, float* ws, void* fwd_ws, void* stream) {
-    return bwd_dw(d, ids, mask, gate, table, feat, argmax, d_feat, dW, dbias, ws, fwd_ws, stream);
-}
-
-static int bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
-                  const float* table, const float* feat, const int32_t* argmax, const float* d_feat,
-                  float* const* dW, float* const* dbias, float* ws, void* fwd_ws, void* stream) {
     BwdArgs A;
     if (int e = fill_args(d, A)) return e;
-    const int* rot = nullptr;
-    const unsigned short* a16 = nullptr;
-    int Dp = 0;
-    const bool rb16 = fwd_ws != nullptr && prod_b16_rows(d, fwd_ws, &rot, &a16, &Dp);
     if (!ids || !table || !feat || !argmax || !d_feat || !dW || !dbias || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
@@ -740,19 +702,11 @@ static int bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* 
                 taps_per_thread = std::max(taps_per_thread, (d->kz[w] + js - 1) / js);
             }
         if (vec4 && taps_per_thread <= 1) {
-            if (rb16)
-                hipLaunchKernelGGL((dw_partial4_kernel<1, true>), dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                                   argmax, d_feat, ws_w, ws_b, rot, a16, Dp);
-            else
-                hipLaunchKernelGGL((dw_partial4_kernel<1, false>), dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                                   argmax, d_feat, ws_w, ws_b, rot, a16, Dp);
+            hipLaunchKernelGGL(dw_partial4_kernel<1>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
+                               argmax, d_feat, ws_w, ws_b);
         } else if (vec4 && taps_per_thread <= 3) {
-            if (rb16)
-                hipLaunchKernelGGL((dw_partial4_kernel<3, true>), dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                                   argmax, d_feat, ws_w, ws_b, rot, a16, Dp);
-            else
-                hipLaunchKernelGGL((dw_partial4_kernel<3, false>), dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                                   argmax, d_feat, ws_w, ws_b, rot, a16, Dp);
+            hipLaunchKernelGGL(dw_partial4_kernel<3>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
+                               argmax, d_feat, ws_w, ws_b);
         } else {      // odd widths, or rows so long that one slot would own > 3 taps: the scalar-column kernel
             hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
                                d_feat, ws_w, ws_b);

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
                                                            long long* __restrict__ tok_of_row, unsigned char* __restrict__ row_mask,
                                                            int* __restrict__ counter, float* __restrict__ zero_row, int pitch,
                                                            const PtrArray W, float* __restrict__ packed, float* __restrict__ WT,
-                                                           const B16Pack JB, unsigned char* __restrict__ bimg,
-                                                           unsigned short* __restrict__ WT16) {
+                                                           const B16Pack JB, unsigned char* __restrict__ bimg) {
     if ((int)blockIdx.x < nb_compact) {
         if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
             for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
@@ -152,9 +151,7 @@ __global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int 
         } else {
             const long e = idx - n_img;
             const int pc = (int)(e / J.D), d = (int)(e - (long)pc * J.D);
-            const float wv = prod_weight(J, W, pc, d);
-            WT[e] = wv;                               // WT[(w, j, cl)][d] = W_w[cl, d, j]
-            if (WT16 != nullptr) WT16[e] = (unsigned short)(pack_bf16(wv, 0.f) & 0xffffu);      // bf16 storage: the backward's copy
+            WT[e] = prod_weight(J, W, pc, d);         // WT[(w, j, cl)][d] = W_w[cl, d, j]
         }
     }
 }
@@ -343,7 +340,7 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 // Dynamic LDS: per wave KGW (int offset, float value) pairs + [4][D] partial sums.
 enum { kGtwDense = 0, kGtwAccumulate = 1, kGtwRows = 2 };
 constexpr int kGtwMaxBlocks = 8192;      // workgroups of g_times_w = entries of its sq_part
-template <int MODE, bool WB16>
+template <int MODE>
 __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
@@ -418,17 +415,8 @@ __global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, con
                     const float* wrow = WT + s_pc[it];
                     gv[v] = ok ? s_val[it] : 0.f;
 #pragma unroll
-                    for (int u = 0; u < kSpQ4; ++u) {
-                        if (WB16) {         // WT holds bf16 (bf16 storage of the plain-bf16 class): 600-byte weight rows from L2
-                            const unsigned short* wr16 = reinterpret_cast<const unsigned short*>(WT) + s_pc[it];
-                            typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-                            const u32x2w b = (doff[u] >= 0) ? *reinterpret_cast<const u32x2w*>(wr16 + doff[u]) : u32x2w{0u, 0u};
-                            wv[v][u] = f32x4{__uint_as_float(b.x << 16), __uint_as_float(b.x & 0xffff0000u),
-                                             __uint_as_float(b.y << 16), __uint_as_float(b.y & 0xffff0000u)};
-                        } else {
-                            wv[v][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    }
+                    for (int u = 0; u < kSpQ4; ++u)
+                        wv[v][u] = (doff[u] >= 0) ? *reinterpret_cast<const f32x4*>(wrow + doff[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
@@ -889,7 +877,7 @@ using namespace rbr;
 namespace {
 
 struct ProdLayout {      // byte offsets inside the workspace
-    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, wt16, bimg, a16, table_T, total;
+    size_t used, row_of_token, tok_of_row, row_mask, counter, sched, packed, wt, bimg, a16, table_T, total;
     int cap, Cp, tiles_p;
     rbr_textcnn_desc dp;
 };
@@ -946,7 +934,6 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
     long cp_real = 0;
     for (int w = 0; w < d->n_widths; ++w) cp_real += (long)d->kz[w] * d->ch[w];
     Lo.wt = o;           o += align256((size_t)cp_real * d->D * sizeof(float));
-    Lo.wt16 = o;         o += prod_t_bf16(d) ? align256((size_t)cp_real * d->D * 2) : 0;      // bf16 storage: Wprod^T for the backward
     Lo.bimg = o;         o += prod_b16_applicable(d) ? align256(prod_b16_image_bytes(d, (int)cp_real)) : 0;
     Lo.a16 = o;          o += align256(prod_b16_rows_bytes(d, Lo.cap));        // bf16 storage: compact bf16 copy of the listed rows
     // (bf16 storage: T's elements are 2 bytes; the space is reserved for f32 either way -- the layout must not depend on more
@@ -957,18 +944,6 @@ bool prod_layout(const rbr_textcnn_desc* d, ProdLayout& Lo) {
 }
 
 }  // namespace
-
-namespace rbr {
-bool prod_b16_rows(const rbr_textcnn_desc* d, void* fwd_ws, const int** row_of_token, const unsigned short** a16, int* Dp) {
-    ProdLayout Lo;
-    if (fwd_ws == nullptr || !prod_t_bf16(d) || !prod_applicable(d) || !prod_layout(d, Lo)) return false;
-    char* base = static_cast<char*>(fwd_ws);
-    *row_of_token = reinterpret_cast<const int*>(base + Lo.row_of_token);
-    *a16 = reinterpret_cast<const unsigned short*>(base + Lo.a16);
-    *Dp = b16s_dp(d->D);
-    return true;
-}
-}  // namespace rbr
 
 extern "C" void rbr_set_conv_mode(int32_t mode) { g_conv_mode = (mode >= 0 && mode <= 2) ? mode : -1; }
 
@@ -1174,24 +1149,17 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     const dim3 grid((unsigned)std::min(Lo.cap, kGtwMaxBlocks));
-    const bool wb16 = prod_t_bf16(d);          // whoever built the list (the forward, or rbr_textcnn_bwd_dtable_list) left a bf16 Wprod^T too
-    const float* W16 = reinterpret_cast<const float*>(fbase + Lo.wt16);
-#define RBR_GTW(MODE_, SQ_)                                                                                                         \
-    do {                                                                                                                            \
-        if (wb16) hipLaunchKernelGGL((g_times_w_kernel<MODE_, true>), grid, dim3(256), lds, st, A, B.KGW, counter, G, W16, tok_of_row,  \
-                                     row_of_token, d->V, dtable, SQ_);                                                              \
-        else hipLaunchKernelGGL((g_times_w_kernel<MODE_, false>), grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row,    \
-                                row_of_token, d->V, dtable, SQ_);                                                                   \
-    } while (0)
     if (phases & kGRows) {
         if (sq_part == nullptr) { set_error("compact row gradient needs sq_part"); return RBR_ERR_BAD_ARG; }
-        RBR_GTW(kGtwRows, sq_part);
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwRows>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V,
+                           dtable, sq_part);
     } else if (phases & kGAccumulate) {
-        RBR_GTW(kGtwAccumulate, (float*)nullptr);
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwAccumulate>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
+                           d->V, dtable, (float*)nullptr);
     } else {
-        RBR_GTW(kGtwDense, (float*)nullptr);
+        hipLaunchKernelGGL(g_times_w_kernel<kGtwDense>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
+                           d->V, dtable, (float*)nullptr);
     }
-#undef RBR_GTW
     RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
@@ -1293,8 +1261,7 @@ static int prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uin
                        prod_t_bf16(d) ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(S.T) + (size_t)S.Lo.cap * S.A.pitch)
                                       : S.T + (size_t)S.Lo.cap * S.A.pitch,
                        prod_t_bf16(d) ? S.A.pitch / 2 : S.A.pitch, wp,
-                       b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr,
-                       prod_t_bf16(d) ? reinterpret_cast<unsigned short*>(S.base + S.Lo.wt16) : nullptr);
+                       b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
     RBR_CHECK_LAUNCH("textcnn compact_pack launch");
     return 0;
 }
@@ -1377,8 +1344,7 @@ extern "C" int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int6
                        reinterpret_cast<unsigned char*>(base + Lo.used), reinterpret_cast<int*>(base + Lo.row_of_token),
                        reinterpret_cast<long long*>(base + Lo.tok_of_row), reinterpret_cast<unsigned char*>(base + Lo.row_mask),
                        reinterpret_cast<int*>(base + Lo.counter), reinterpret_cast<float*>(base + Lo.table_T), pp[0].nslots_total, wp,
-                       (float*)nullptr, reinterpret_cast<float*>(base + Lo.wt), B16Pack{}, (unsigned char*)nullptr,
-                       prod_t_bf16(d) ? reinterpret_cast<unsigned short*>(base + Lo.wt16) : nullptr);
+                       (float*)nullptr, reinterpret_cast<float*>(base + Lo.wt), B16Pack{}, (unsigned char*)nullptr);
     RBR_CHECK_LAUNCH("textcnn compact launch");
     return dtable_through_list(d, plans, ids, mask, nullptr, feat, argmax, d_feat, base, base + align256(list_bytes), dtable, nullptr, st);
 }

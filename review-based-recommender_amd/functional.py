@@ -408,10 +408,9 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
             side.wait_event(fork)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             ev_dw = TIMER.record("textcnn_bwd_dw")
-            check(L_.rbr_textcnn_bwd_dw_ws(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                           dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
-                                           ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"),
-                                           S.prod_ws.data_ptr() if S.prod_ws is not None else None, current_stream()),
+            check(L_.rbr_textcnn_bwd_dw(*common, dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
+                                        dev_ptr(d_feat, F32, "d_feat"), ptr_array(dWs, F32, "dW"),
+                                        ptr_array(dbs, F32, "dbias"), dev_ptr(wsb, F32, "ws"), current_stream()),
                   "rbr_textcnn_bwd_dw")
             if ev_dw is not None:
                 ev_dw.record()
