@@ -196,8 +196,11 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
 //                   multiple of 32): every channel group of the GEMM re-reads 600-byte rows instead of 1200-byte ones, by plain
 //                   row index (no token indirection), and no wave converts anything in the loop;
 //   prod_gemm_b16s: 32-deep stages, 2 + 2 LDS-DMA instructions per wave and stage for 8 MFMAs (the f32-row kernel: 5 for 4 --
-//                   the LDS-fill path that bounds it), only the hi weight plane is staged, T is written as bf16 (the gather reads
-//                   half the bytes, which is what bounds IT).
+//                   the LDS-fill path that bounds it), only the hi weight plane is staged, T is written as bf16.
+// Measured at cfg2 (round 3, one box): GEMM 38.7 -> 24.4 us (+ 8.8 us for rows_to_b16), gather_pool 44.0 -> 38.9 us, step
+// 0.3455 -> 0.3419 ms.  The row-reading kernels of the backward were given bf16 rows too (bf16 Wprod^T in g_times_w, the bf16
+// row copy in dw_partial4) and did NOT get faster -- 64 and 76 us against 61 and 71: they issue one load instruction per lane
+// and row either way and are bound by that count, not by the bytes -- so the backward keeps its f32 rows.
 struct B16sGemm {
     const int* counter;
     const unsigned short* a16;       // [rows][Dp] bf16

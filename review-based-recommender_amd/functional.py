@@ -567,18 +567,6 @@ def _side_stream(dev):
     return s
 
 
-_TOWER_STREAMS: dict = {}
-
-
-def tower_stream(dev):
-    """The stream on which a two-tower model may run its second tower (models/dual_att)."""
-    dev = torch.device(dev)
-    s = _TOWER_STREAMS.get(dev)
-    if s is None:
-        s = _TOWER_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    return s
-
-
 def _join(event) -> None:
     if event is not None:
         torch.cuda.current_stream().wait_event(event)

@@ -17,8 +17,6 @@ class DualAtt(nn.Module):
         self.fc_input = l_out_size + 3 * g_out_size
         self.vocab_size = vocab_size
         self.validate_ids = True      # device-side range check of the token ids (functional.sanitize_ids), see DeepCoNNpp
-        import os
-        self.two_streams = os.environ.get("RBR_DATT_STREAMS", "0") == "1"      # the towers as two concurrent streams
 
         self.word_embeddings = WordEmbedding(vocab_size, emb_size, pretrained_embeddings=pretrained_embeddings)
         self.u_local_atten = LocalAttention(doc_len, l_window_size, l_out_size, emb_size)
@@ -49,30 +47,12 @@ class DualAtt(nn.Module):
             u_docs, i_docs = RF.sanitize_ids([(u_docs, self.vocab_size, pad), (i_docs, self.vocab_size, pad)])
         # eight ops of the step produce gradient for the word table (a gate and a conv, local and global, per tower): each gets
         # its own alias, and their backwards add their rows into one buffer instead of eight dense gradients summed by autograd
-        tower = RF.tower_stream(u_docs.device) if self.two_streams else None
-        if tower is not None:
-            # the towers share nothing but the word table: the item tower runs on a stream of its own (a parallel branch of a
-            # recorded step), so one tower's latency-bound launches -- ~40 of its ~50 -- run under the other's long kernels.
-            # Each tower has its own fan-out (its gradient buffer is added to by ops of ONE stream); autograd replays the
-            # backward of every op on the stream its forward ran on.
-            cur = torch.cuda.current_stream()
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            tower.wait_event(fork)
-            with torch.cuda.stream(tower):
-                tabs_i = RF.table_fanout(self.word_embeddings.weight, 4)
-                i_loc, i_glo = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs_i)
-                join = torch.cuda.Event()
-                join.record(tower)
-            tabs_u = RF.table_fanout(self.word_embeddings.weight, 4)
-            u_loc, u_glo = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs_u)
-            cur.wait_event(join)
-            for t in (i_loc, i_glo):
-                t.record_stream(cur)
-        else:
-            tabs = RF.table_fanout(self.word_embeddings.weight, 8)
-            u_loc, u_glo = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs[0:4])
-            i_loc, i_glo = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
+        # (Tried in round 3 and dropped: the item tower on a stream of its own, so that one tower's ~40 latency-bound launches run
+        # under the other's long kernels -- autograd then replays every backward op on its forward's stream, and recording that
+        # backward into a hipGraph crashed the process inside the capture; the towers stay one after the other.)
+        tabs = RF.table_fanout(self.word_embeddings.weight, 8)
+        u_loc, u_glo = self._encode(u_docs, self.u_local_atten, self.u_global_atten, tabs[0:4])
+        i_loc, i_glo = self._encode(i_docs, self.i_local_atten, self.i_global_atten, tabs[4:8])
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
         # backward) as a single 2*bz batch, user rows first
         # cat((local, global), 1) per tower (dual_att.py:50,56), user rows over item rows: one launch (RF.block_cat)
