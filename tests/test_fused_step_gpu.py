@@ -94,7 +94,7 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
                     assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"]), (step, k)
                     assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"]), (step, k)
                 else:
-                    assert torch.allclose(pa, pb, rtol=0, atol=1e-8), (step, k)
+                    assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7), (step, k)      # an ulp of the clip coefficient
                     assert torch.allclose(pa.grad, pb.grad, rtol=1e-5, atol=0), (step, k, "clipped gradient")
                     assert torch.allclose(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"], rtol=1e-5, atol=1e-12), (step, k)
                     assert torch.allclose(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"], rtol=1e-5, atol=1e-20), (step, k)
