@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
         float* g = T.g[k] + e0;
         float* m = T.m[k] + e0;
         float* v = T.v[k] + e0;
-        if (MODE == 1 && k == T.rows_k && n == kOptChunk) {
+        if (MODE == 1 && k == T.rows_k && n == kOptChunk && T.rows_D >= 256) {      // (shorter rows: a wave spans more than two)
             // Compact-gradient table, whole chunk (rows_D % 4 == 0, V * D < 2^32 and 16-byte aligned pointers: checked on the host).
             // The 64 float4 of a wave and round lie in at most TWO vocabulary rows, so the two list rows are WAVE-UNIFORM: they
             // come through the scalar cache (s_load), not as a per-lane gather, and a wave whose two rows are both absent from
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
             }
             continue;
         }
-        if (MODE == 1 && k == T.rows_k) {                 // the table's last, partial chunk: one float4 at a time
+        if (MODE == 1 && k == T.rows_k) {                 // the table's last, partial chunk (and short rows): one float4 at a time
             const int D = T.rows_D;
             const int n4r = (int)(n >> 2);               // numel = V * D is a multiple of 4
             for (int i = threadIdx.x; i < n4r; i += 256) {
