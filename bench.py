@@ -292,11 +292,11 @@ def time_gemm_launches(model, args, reps=50):
 
 def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
     """In-step time of rbr_clip_adam_step[_rows] (its two kernels: gradient norm, clip + Adam): HIP events on the launch
-    stream around every call, over `n_sets` ROTATING copies of the model + Adam state + gradients (3 x 210 MB: the working set
-    exceeds the 256 MiB Infinity Cache, as it does inside a step, where the conv kernels have pushed p / m / v out since the
-    last update).  Each set holds the gradients one backward left behind (the table's in compact row form); the row gradient is
-    restored from a copy between calls (outside the event pairs) so that every call clips as the first one did.  The queue
-    stays full, so an event pair holds kernel time only.  Returns (ms per call, bytes per call as the kernels move them)."""
+    stream around `n_sets` back-to-back calls, one per ROTATING copy of the model + Adam state + gradients (3 x 210 MB: the
+    working set exceeds the 256 MiB Infinity Cache, as it does inside a step, where the conv kernels have pushed p / m / v out
+    since the last update).  Each set holds the gradients one backward left behind (the table's in compact row form); they are
+    restored from a copy before every timed trio so that every call clips as the first one did.  The queue stays full, so the
+    interval holds kernel time only.  Returns (ms per call, bytes per call as the kernels move them, ...)."""
     from review_based_recommender_amd.train_step import HipClipAdam, _forward_loss_backward, make_optimizer
     sets = []
     for k in range(n_sets):
@@ -312,17 +312,18 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
     for _, o, _ in sets:
         o.clip_and_step(5.0)
     pairs = []
-    for i in range(reps):
-        _, o, saved = sets[i % n_sets]
-        for dst, src in saved:
-            dst.copy_(src)
+    for i in range(reps // n_sets):
+        for _, _, saved in sets:           # every set clips as its first call did (restored outside the timed interval)
+            for dst, src in saved:
+                dst.copy_(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o.clip_and_step(5.0)
+        for _, o, _ in sets:               # one call per set, back to back: the queue stays full across the calls
+            o.clip_and_step(5.0)
         e1.record()
         pairs.append((e0, e1))
     torch.cuda.synchronize()
-    ms = sorted(a.elapsed_time(b) for a, b in pairs)
+    ms = sorted(a.elapsed_time(b) / n_sets for a, b in pairs)
     m, o, _ = sets[0]
     n_par = sum(p.numel() for p in m.parameters())
     row_elems = sum(int(rg.rows.shape[1]) * n for rg, n in ((rg, _listed_rows(rg)) for rg in o._row_grads.values()))
@@ -642,6 +643,8 @@ def main():
             out["roofline_gemm"] = {
                 "bound": "mfma",
                 "kernel": ("prod_gemm_kernel<60> (v_mfma_f32_32x32x2_f32)" if precision == "f32" else
+                           "rows_to_b16_kernel + prod_gemm_b16s_kernel (bf16 storage: compact bf16 row copy, v_mfma_f32_32x32x16_bf16, "
+                           "bf16 product table)" if (precision == "bf16" and os.environ.get("RBR_B16_STORAGE", "1") != "0") else
                            f"prod_gemm_b16_kernel<{nprod}> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product)")
                           + ": T = table[distinct tokens] @ Wprod, rows gathered by LDS-DMA",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -669,12 +672,15 @@ def main():
                     "bound": "hbm", "kernel": "grad_sqnorm_kernel + clip_adam_kernel<1> (rbr_clip_adam_step_rows: clip_grad_norm_ + Adam, "
                                               "all 17 parameter tensors, the word table's gradient in compact row form)",
                     "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                    "traffic": measured_traffic("r03_clip_adam_pmc.json"),
-                    "traffic_source": "profiles/r03_clip_adam_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)",
+                    "traffic": (lambda a_, b_: None if a_ is None or b_ is None else a_ + b_)(
+                        measured_traffic("r03_clip_adam_pmc.json"), measured_traffic("r03_grad_sqnorm_pmc.json")),
+                    "traffic_source": "profiles/r03_clip_adam_pmc.json + r03_grad_sqnorm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes, gfx950 correction)",
                     "bytes_per_launch": opt_bytes, "avg_launch_ms": round(opt_ms, 4), "launches_timed": 45,
-                    "timing": "HIP events on the launch stream around each rbr_clip_adam_step_rows call (two kernels), median of 45 calls "
-                              "rotating over 3 copies of parameters + Adam state + gradients (630 MB: beyond the 256 MiB Infinity "
-                              "Cache, as inside a step); compare profiles/r03_bench_kernel_stats.csv",
+                    "timing": "HIP events on the launch stream around 3 back-to-back rbr_clip_adam_step_rows calls (two kernels each), one per "
+                              "rotating copy of parameters + Adam state + gradients (630 MB: beyond the 256 MiB Infinity Cache, as "
+                              "inside a step), median of 15 trios / 3; compare clip_adam_kernel<1> + grad_sqnorm_kernel in "
+                              "profiles/r03_bench_kernel_stats.csv",
                     "note": f"24 B x {n_par} parameters (p, m, v read + written) + 12 B x ({n_par - opt_table} dense-gradient elements + "
                             f"{opt_rows} elements of listed table rows); per pair: {opt_bytes / cfg['B'] / 1e6:.2f} MB of optimizer traffic"}
             else:
