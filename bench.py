@@ -589,7 +589,7 @@ def main():
             "ms_per_step": round(1e3 * med / a.steps, 4), "ms_per_step_min": round(1e3 * best / a.steps, 4),
             "repeats": len(headline), "timed_region_s": round(sum(headline), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
             "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
