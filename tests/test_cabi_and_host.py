@@ -166,3 +166,14 @@ def test_bench_starts_its_own_ranks():
         pytest.skip("GPU present: the real multi-rank run is the driver's")
     assert r.returncode != 0
     assert out.count("bench.py needs an MI355X") >= 2, out[-2000:]
+
+
+def test_product_library_holds_no_wrong_result_switches():
+    """the RBR_DEV_* ablation / tuning switches (no atomics, no accumulation phase, extra LDS, generic GEMM)
+    exist only in -DRBR_DIAG builds (RBR_DIAG=1 python build.py); the product library must not even contain their names, so no
+    environment variable can turn gradient accumulation off in it."""
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "review-based-recommender_amd", "csrc", "librbr_hip.so")
+    blob = open(lib, "rb").read()
+    for name in (b"RBR_DEV_DX_ABLATE", b"RBR_DEV_DX_WIN", b"RBR_DEV_CONV_EXTRA_LDS", b"RBR_DEV_GENERIC_GEMM"):
+        assert name not in blob, name
