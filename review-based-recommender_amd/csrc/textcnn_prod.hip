@@ -883,36 +883,28 @@ __global__ __launch_bounds__(256) void dw_from_g_reduce_kernel(const ProdBwdArgs
 //   Partials reduced by dw_from_g_reduce_kernel (fixed order), dbias as above.  ~100 MB of L2 traffic instead of 504.
 constexpr int kListBlk = 32;
 
-template <int NK>      // NK = ceil(KG / 256) <= 4: a wave's 8 rows stay in registers between the count and the write (one read of G)
 __global__ __launch_bounds__(256) void g_compact_kernel(int KG, int cap, const int* __restrict__ counter, const float* __restrict__ G,
                                                         int* __restrict__ cursor, int* __restrict__ blk_ptr, int* __restrict__ blk_cnt,
                                                         int2* __restrict__ entries) {
     __shared__ int s_cnt[kListBlk], s_off[kListBlk];
     __shared__ int s_base;
-    constexpr int RPW = kListBlk / kWavesPerWG;                  // rows per wave
     const int n = min(*counter, cap);
     const int r0 = blockIdx.x * kListBlk;
     if (r0 >= n) return;                                         // workgroup-uniform
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1;
-    f32x4 v[RPW][NK];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {                              // all of the wave's loads first
-        const int row = r0 + wave * RPW + i;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const int k = kk * 256 + 4 * lane;
-            v[i][kk] = (row < n && k < KG) ? *reinterpret_cast<const f32x4*>(G + (long)row * KG + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
+    for (int i = 0; i < kListBlk / kWavesPerWG; ++i) {
+        const int lrow = wave * (kListBlk / kWavesPerWG) + i, row = r0 + lrow;
         int cnt = 0;
+        if (row < n)
+            for (int k0 = 0; k0 < KG; k0 += 256) {
+                const int k = k0 + 4 * lane;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < KG) v = *reinterpret_cast<const f32x4*>(G + (long)row * KG + k);
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cnt += __popcll(__ballot(v[i][kk][c] != 0.f));
-        if (lane == 0) s_cnt[wave * RPW + i] = cnt;
+                for (int c = 0; c < 4; ++c) cnt += __popcll(__ballot(v[c] != 0.f));
+            }
+        if (lane == 0) s_cnt[lrow] = cnt;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -924,19 +916,22 @@ __global__ __launch_bounds__(256) void g_compact_kernel(int KG, int cap, const i
         s_base = base;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int lrow = wave * RPW + i;
+    for (int i = 0; i < kListBlk / kWavesPerWG; ++i) {
+        const int lrow = wave * (kListBlk / kWavesPerWG) + i, row = r0 + lrow;
+        if (row >= n || s_cnt[lrow] == 0) continue;              // wave-uniform
         int pos = s_base + s_off[lrow];
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk)
+        for (int k0 = 0; k0 < KG; k0 += 256) {
+            const int k = k0 + 4 * lane;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < KG) v = *reinterpret_cast<const f32x4*>(G + (long)row * KG + k);     // second read: L2
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const bool nz = v[i][kk][c] != 0.f;
+                const bool nz = v[c] != 0.f;
                 const unsigned long long b = __ballot(nz);
-                if (nz) entries[pos + __popcll(b & lt)] = int2{(kk * 256 + 4 * lane + c) | (lrow << 16), __float_as_int(v[i][kk][c])};
+                if (nz) entries[pos + __popcll(b & lt)] = int2{(k + c) | (lrow << 16), __float_as_int(v[c])};
                 pos += __popcll(b);
             }
+        }
     }
 }
 
@@ -972,8 +967,7 @@ __global__ __launch_bounds__(64) void dw_lists_kernel(int KG, int D, int cap, co
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int col = e[u].x & 0xffff, lr = e[u].x >> 16;
-                // ds_add_f32: the four entries of a round may sit in one column (atomicAdd() itself compiles to a CAS loop here)
-                unsafeAtomicAdd(&s_dw[col * 16 + f], __int_as_float(e[u].y) * s_x[lr * 16 + f]);
+                atomicAdd(&s_dw[col * 16 + f], __int_as_float(e[u].y) * s_x[lr * 16 + f]);      // ds_add_f32 (one wave: program order)
             }
         }
     }
@@ -1511,7 +1505,7 @@ static bool dw_lists_applicable(const rbr_textcnn_desc* d) {
     long cp = 0;
     for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
     const long KG = (cp + 3) / 4 * 4;
-    return prod_applicable(d) && !dw_from_g_applicable(d) && d->D % 4 == 0 && KG * 64 + kListBlk * 64 <= 64 * 1024 && KG <= 1024;
+    return prod_applicable(d) && !dw_from_g_applicable(d) && d->D % 4 == 0 && KG * 64 + kListBlk * 64 <= 64 * 1024 && KG < 65536;
 }
 struct DwListsLayout { size_t part, part_b, blk_ptr, blk_cnt, entries, total; int nblk; long max_nnz; };      // offsets in floats
 static DwListsLayout dw_lists_layout(const rbr_textcnn_desc* d, int C, int KF, int KG, int cap) {
@@ -1568,12 +1562,8 @@ extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float*
         int* blk_cnt = reinterpret_cast<int*>(ws + W.blk_cnt);
         int2* entries = reinterpret_cast<int2*>(ws + W.entries);
         int* cursor = reinterpret_cast<int*>(static_cast<char*>(bwd_ws) + B.cursor);      // cleared by the G build's zero launch
-        switch ((B.KG + 255) / 256) {
-            case 1: hipLaunchKernelGGL(g_compact_kernel<1>, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt, entries); break;
-            case 2: hipLaunchKernelGGL(g_compact_kernel<2>, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt, entries); break;
-            case 3: hipLaunchKernelGGL(g_compact_kernel<3>, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt, entries); break;
-            default: hipLaunchKernelGGL(g_compact_kernel<4>, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt, entries); break;
-        }
+        hipLaunchKernelGGL(g_compact_kernel, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt,
+                           entries);
         RBR_CHECK_LAUNCH("textcnn g_compact launch");
         const size_t lds = ((size_t)B.KG * 16 + kListBlk * 16) * sizeof(float);
         hipLaunchKernelGGL(dw_lists_kernel, dim3((unsigned)((d->D + 15) / 16), kDwgSplit), dim3(64), lds, st, B.KG, d->D, Lo.cap, counter,
