@@ -286,8 +286,7 @@ struct ProdBwdArgs {
 
 // ... and the gate gradient build_g accumulates into (n_dgate floats, 0 for un-gated convs): one launch for both
 __global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
-                                                          float* __restrict__ dgate, long n_dgate, int* __restrict__ cursor) {
-    if (cursor != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *cursor = 0;      // entry cursor of g_compact_kernel
+                                                          float* __restrict__ dgate, long n_dgate) {
     const long n = (G != nullptr) ? (long)min(*counter, cap) * KG4 : 0;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_dgate; k += (long)gridDim.x * 256) dgate[k] = 0.f;
@@ -871,111 +870,6 @@ __global__ __launch_bounds__(256) void dw_from_g_reduce_kernel(const ProdBwdArgs
     }
 }
 
-// ---------------------------------------------------------------------------------- conv weight gradient from G's non-zeros
-// dW[(w,j,cl), :] = sum over the batch's distinct tokens t of G[t][(w,j,cl)] * table[t, :], G ~2 % dense.  The window-row kernel
-// (textcnn_bwd.hip: dw_partial4) reads one 1200-byte table row per (document, channel, tap) -- 384 k rows, 504 MB of L2
-// requests at cfg2 -- although only 21 k DISTINCT rows exist: through G every table row is needed once per 16-float slice.
-//   g_compact : G's non-zeros as (column | row-in-block << 16, value) entries, one contiguous run per block of 32 list rows
-//               (block-local prefix + ONE cursor atomic per block: the runs land in any order, their content is fixed);
-//   dw_lists  : one WAVE per (16-float slice of the embedding dim, split z): it keeps dW[:, slice] in LDS (KG x 64 bytes), walks
-//               the blocks b = z, z + 32, ... -- 32 row slices of 64 bytes, then the block's entries as one linear stream, four
-//               entries x 16 floats per LDS add -- and writes its partial; program order inside one wave: reproducible.
-//   Partials reduced by dw_from_g_reduce_kernel (fixed order), dbias as above.  ~100 MB of L2 traffic instead of 504.
-constexpr int kListBlk = 32;
-
-__global__ __launch_bounds__(256) void g_compact_kernel(int KG, int cap, const int* __restrict__ counter, const float* __restrict__ G,
-                                                        int* __restrict__ cursor, int* __restrict__ blk_ptr, int* __restrict__ blk_cnt,
-                                                        int2* __restrict__ entries) {
-    __shared__ int s_cnt[kListBlk], s_off[kListBlk];
-    __shared__ int s_base;
-    const int n = min(*counter, cap);
-    const int r0 = blockIdx.x * kListBlk;
-    if (r0 >= n) return;                                         // workgroup-uniform
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1;
-    for (int i = 0; i < kListBlk / kWavesPerWG; ++i) {
-        const int lrow = wave * (kListBlk / kWavesPerWG) + i, row = r0 + lrow;
-        int cnt = 0;
-        if (row < n)
-            for (int k0 = 0; k0 < KG; k0 += 256) {
-                const int k = k0 + 4 * lane;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < KG) v = *reinterpret_cast<const f32x4*>(G + (long)row * KG + k);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) cnt += __popcll(__ballot(v[c] != 0.f));
-            }
-        if (lane == 0) s_cnt[lrow] = cnt;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int q = 0; q < kListBlk; ++q) { s_off[q] = t; t += s_cnt[q]; }
-        const int base = t ? atomicAdd(cursor, t) : 0;
-        blk_ptr[blockIdx.x] = base;
-        blk_cnt[blockIdx.x] = t;
-        s_base = base;
-    }
-    __syncthreads();
-    for (int i = 0; i < kListBlk / kWavesPerWG; ++i) {
-        const int lrow = wave * (kListBlk / kWavesPerWG) + i, row = r0 + lrow;
-        if (row >= n || s_cnt[lrow] == 0) continue;              // wave-uniform
-        int pos = s_base + s_off[lrow];
-        for (int k0 = 0; k0 < KG; k0 += 256) {
-            const int k = k0 + 4 * lane;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < KG) v = *reinterpret_cast<const f32x4*>(G + (long)row * KG + k);     // second read: L2
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool nz = v[c] != 0.f;
-                const unsigned long long b = __ballot(nz);
-                if (nz) entries[pos + __popcll(b & lt)] = int2{(k + c) | (lrow << 16), __float_as_int(v[c])};
-                pos += __popcll(b);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(64) void dw_lists_kernel(int KG, int D, int cap, const int* __restrict__ counter,
-                                                      const long long* __restrict__ tok_of_row, const float* __restrict__ table,
-                                                      const int* __restrict__ blk_ptr, const int* __restrict__ blk_cnt,
-                                                      const int2* __restrict__ entries, float* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float s_dw[];          // [KG][16] | xs [32][16]
-    float* s_x = s_dw + (size_t)KG * 16;
-    const int lane = threadIdx.x, f = lane & 15, q = lane >> 4;
-    const int d0 = blockIdx.x * 16, z = blockIdx.y;
-    const int n = min(*counter, cap);
-    const bool fok = d0 + f < D;
-    for (int k = lane; k < KG * 16; k += 64) s_dw[k] = 0.f;
-    for (int b = z; b * kListBlk < n; b += kDwgSplit) {
-        const int r0 = b * kListBlk;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < kListBlk / 4; ++i) {                 // the block's 32 row slices: 8 independent 64-byte loads per lane group
-            const int lr = q + 4 * i, row = r0 + lr;
-            s_x[lr * 16 + f] = (row < n && fok) ? table[tok_of_row[row] * (long)D + d0 + f] : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int base = blk_ptr[b], cnt = blk_cnt[b];
-        for (int i0 = 0; i0 < cnt; i0 += 32) {                   // 8 rounds of 4 entries, their loads issued together
-            int2 e[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = i0 + 4 * u + q;
-                e[u] = entries[base + min(idx, cnt - 1)];        // unconditional load; a repeat past the end adds zero
-                if (idx >= cnt) e[u].y = 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int col = e[u].x & 0xffff, lr = e[u].x >> 16;
-                atomicAdd(&s_dw[col * 16 + f], __int_as_float(e[u].y) * s_x[lr * 16 + f]);      // ds_add_f32 (one wave: program order)
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (fok)
-        for (int col = q; col < KG; col += 4) part[((long)z * KG + col) * D + d0 + f] = s_dw[col * 16 + f];
-}
-
 }  // namespace rbr
 
 using namespace rbr;
@@ -1076,7 +970,7 @@ extern "C" size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d) {
 namespace {
 
 struct ProdBwdLayout {
-    size_t G, cursor, total;
+    size_t G, total;
     int KG, KGW, cp_real;
 };
 
@@ -1090,7 +984,6 @@ bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLay
     if ((size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;   // lists + partial rows in LDS
     size_t o = 0;
     B.G = o;  o += align256((size_t)Lo.cap * B.KG * sizeof(float));
-    B.cursor = o; o += 256;                                     // entry cursor of the non-zero lists (g_compact_kernel)
     B.total = o;
     return true;
 }
@@ -1244,8 +1137,7 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
         if ((want_g && !(phases & kGZeroed)) || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
             hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4,
                                (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate,
-                               dgate != nullptr ? (long)d->n_docs * d->L : 0L,
-                               reinterpret_cast<int*>(static_cast<char*>(bwd_ws) + B.cursor));
+                               dgate != nullptr ? (long)d->n_docs * d->L : 0L);
             RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;
@@ -1493,42 +1385,17 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
 
 // ---- conv weight / bias gradient from G (see dw_from_g_kernel): after rbr_textcnn_bwd_dtable_prod built G in `bwd_ws`
 static bool dw_from_g_applicable(const rbr_textcnn_desc* d) {
-    // the shapes the document-centric dW kernel serves (textcnn_bwd.hip): many short documents -> G^T @ rows on the MFMA pipe
+    // the shapes the document-centric dW kernel serves (textcnn_bwd.hip): many short documents
     long cp = 0;
     for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
     return prod_applicable(d) && d->D % 4 == 0 && d->L <= 128 && d->n_docs >= 512 && cp <= 2048;
 }
-// every other token-product shape whose dW slice fits in LDS: dW from the non-zero lists of G (g_compact + dw_lists)
-static bool dw_lists_applicable(const rbr_textcnn_desc* d) {
-    static const char* env = getenv("RBR_DW_LISTS");
-    if (env && !strcmp(env, "0")) return false;
-    long cp = 0;
-    for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
-    const long KG = (cp + 3) / 4 * 4;
-    return prod_applicable(d) && !dw_from_g_applicable(d) && d->D % 4 == 0 && KG * 64 + kListBlk * 64 <= 64 * 1024 && KG < 65536;
-}
-struct DwListsLayout { size_t part, part_b, blk_ptr, blk_cnt, entries, total; int nblk; long max_nnz; };      // offsets in floats
-static DwListsLayout dw_lists_layout(const rbr_textcnn_desc* d, int C, int KF, int KG, int cap) {
-    DwListsLayout W{};
-    size_t o = 0;
-    W.part = o;    o += (size_t)kDwgSplit * KG * d->D;
-    W.part_b = o;  o += (size_t)kDbChunks * C;
-    W.nblk = (cap + kListBlk - 1) / kListBlk;
-    W.blk_ptr = o; o += (size_t)W.nblk;
-    W.blk_cnt = o; o += (size_t)W.nblk;
-    o = (o + 1) & ~(size_t)1;                                   // entries are 8-byte pairs
-    W.max_nnz = std::min((long)d->n_docs * C * KF, (long)cap * KG);
-    W.entries = o; o += 2 * (size_t)W.max_nnz;
-    W.total = o;
-    return W;
-}
 
 extern "C" size_t rbr_textcnn_bwd_dw_from_g_ws_floats(const rbr_textcnn_desc* d) {
     ConvPlan plans[kMaxGroups];
-    if (!build_plans(d, plans) || !(dw_from_g_applicable(d) || dw_lists_applicable(d))) return 0;
+    if (!build_plans(d, plans) || !dw_from_g_applicable(d)) return 0;
     ProdLayout Lo; ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return 0;
-    if (dw_lists_applicable(d)) return dw_lists_layout(d, plans[0].C, plans[0].KF, B.KG, Lo.cap).total;
     return (size_t)kDwgSplit * B.KG * d->D + (size_t)kDbChunks * plans[0].C;
 }
 
@@ -1536,8 +1403,7 @@ extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float*
                                          void* fwd_ws, void* bwd_ws, float* const* dW, float* const* dbias, float* ws, void* stream) {
     ConvPlan plans[kMaxGroups];
     if (!build_plans(d, plans)) return RBR_ERR_BAD_ARG;
-    const bool lists = dw_lists_applicable(d);
-    if (!lists && !dw_from_g_applicable(d)) { set_error("dW-from-G does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
+    if (!dw_from_g_applicable(d)) { set_error("dW-from-G does not apply to this shape"); return RBR_ERR_UNSUPPORTED; }
     if (!table || !feat || !d_feat || !fwd_ws || !bwd_ws || !dW || !dbias || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     ProdLayout Lo; ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
@@ -1556,24 +1422,9 @@ extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float*
     }
     float* part = ws;
     float* part_b = ws + (size_t)kDwgSplit * B.KG * d->D;
-    if (lists) {
-        const DwListsLayout W = dw_lists_layout(d, A.C, A.KF, B.KG, Lo.cap);
-        int* blk_ptr = reinterpret_cast<int*>(ws + W.blk_ptr);
-        int* blk_cnt = reinterpret_cast<int*>(ws + W.blk_cnt);
-        int2* entries = reinterpret_cast<int2*>(ws + W.entries);
-        int* cursor = reinterpret_cast<int*>(static_cast<char*>(bwd_ws) + B.cursor);      // cleared by the G build's zero launch
-        hipLaunchKernelGGL(g_compact_kernel, dim3((unsigned)W.nblk), dim3(256), 0, st, B.KG, Lo.cap, counter, G, cursor, blk_ptr, blk_cnt,
-                           entries);
-        RBR_CHECK_LAUNCH("textcnn g_compact launch");
-        const size_t lds = ((size_t)B.KG * 16 + kListBlk * 16) * sizeof(float);
-        hipLaunchKernelGGL(dw_lists_kernel, dim3((unsigned)((d->D + 15) / 16), kDwgSplit), dim3(64), lds, st, B.KG, d->D, Lo.cap, counter,
-                           tok_of_row, table, blk_ptr, blk_cnt, entries, part);
-        RBR_CHECK_LAUNCH("textcnn dw_lists launch");
-    } else {
-        hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
-                           counter, G, tok_of_row, table, part);
-        RBR_CHECK_LAUNCH("textcnn dw_from_g launch");
-    }
+    hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                       counter, G, tok_of_row, table, part);
+    RBR_CHECK_LAUNCH("textcnn dw_from_g launch");
     hipLaunchKernelGGL(dbias_partial_kernel, dim3((A.C + 255) / 256, kDbChunks), dim3(256), 0, st, d->n_docs, A.C, d->act, feat, d_feat,
                        part_b);
     RBR_CHECK_LAUNCH("textcnn dbias partial launch");

@@ -478,13 +478,9 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
                     join = torch.cuda.Event()
                     join.record()
             if need_table:
-                if acc is not None:      # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
-                    dtable = out = acc
-                    flags |= _lib.G_ACCUMULATE
                 check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), None, None, None, None, None, None, S.prod_ws.data_ptr(),
                                                         bws.data_ptr(), dev_ptr(out, F32, "dtable"), None, dev_ptr(sq, F32, "sq_part"),
-                                                        _lib.G_PRODUCT | (flags & (_lib.G_ROWS | _lib.G_ACCUMULATE)), st),
-                      "rbr_textcnn_bwd_g_product")
+                                                        _lib.G_PRODUCT | (flags & _lib.G_ROWS), st), "rbr_textcnn_bwd_g_product")
             if ev is not None:
                 ev.record()
             _join(join)
