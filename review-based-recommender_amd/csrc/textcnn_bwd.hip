@@ -132,6 +132,11 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
     if (tid == 0) ws_b[(long)chunk * C + c] = bsum;
 }
 
+// (Measured and dropped in round 3: dW from the NON-ZERO LISTS of the per-token tap matrix G -- G compacted into (column, value)
+// runs per 32 list rows (25 us), then one wave per 16-float slice of the embedding dim keeping dW[:, slice] in LDS and adding
+// value x row slice per entry: every distinct table row is read once per slice (100 MB of L2 traffic instead of 504), but the
+// work becomes 7.3 M wave-level LDS adds of 64 bytes: 957 us as first built (one wave per SIMD, every batch of entry loads a
+// full memory round trip), and LDS-pipe-bound at 50-100 us on paper once pipelined -- no better than this kernel's 70.)
 // float4 variant of dw_partial (D % 4 == 0, D <= 1024): thread = (slot, float4 column).  The 256 / (D/4) slots of a
 // workgroup split into `jslots` taps x `dpar` documents in flight, so a 300-wide row is read by 75 lanes with one
 // dwordx4 each and three window rows are read at once (the scalar kernel needs 300 + 44 lanes in two passes per row).
