@@ -311,6 +311,20 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
         sets.append((m, o, rows + dense))
     for _, o, _ in sets:
         o.clip_and_step(5.0)
+    torch.cuda.synchronize()
+    # the three calls recorded into ONE hipGraph: replayed, their six kernels run back to back (launched from Python a call costs
+    # more host time than its kernels take on the GPU, and the event interval would hold the gaps)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _, o, _ in sets:
+            o.clip_and_step(5.0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _, o, _ in sets:
+            o.clip_and_step(5.0)
     pairs = []
     for i in range(reps // n_sets):
         for _, _, saved in sets:           # every set clips as its first call did (restored outside the timed interval)
@@ -318,8 +332,7 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
                 dst.copy_(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _, o, _ in sets:               # one call per set, back to back: the queue stays full across the calls
-            o.clip_and_step(5.0)
+        graph.replay()
         e1.record()
         pairs.append((e0, e1))
     torch.cuda.synchronize()
@@ -677,10 +690,10 @@ def main():
                     "traffic_source": "profiles/r03_clip_adam_pmc.json + r03_grad_sqnorm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       "passes, gfx950 correction)",
                     "bytes_per_launch": opt_bytes, "avg_launch_ms": round(opt_ms, 4), "launches_timed": 45,
-                    "timing": "HIP events on the launch stream around 3 back-to-back rbr_clip_adam_step_rows calls (two kernels each), one per "
-                              "rotating copy of parameters + Adam state + gradients (630 MB: beyond the 256 MiB Infinity Cache, as "
-                              "inside a step), median of 15 trios / 3; compare clip_adam_kernel<1> + grad_sqnorm_kernel in "
-                              "profiles/r03_bench_kernel_stats.csv",
+                    "timing": "HIP events on the launch stream around a replayed hipGraph of 3 rbr_clip_adam_step_rows calls (two kernels "
+                              "each), one per rotating copy of parameters + Adam state + gradients (630 MB: beyond the 256 MiB "
+                              "Infinity Cache, as inside a step), median of 15 replays / 3; compare clip_adam_kernel<1> + "
+                              "grad_sqnorm_kernel in profiles/r03_bench_kernel_stats.csv",
                     "note": f"24 B x {n_par} parameters (p, m, v read + written) + 12 B x ({n_par - opt_table} dense-gradient elements + "
                             f"{opt_rows} elements of listed table rows); per pair: {opt_bytes / cfg['B'] / 1e6:.2f} MB of optimizer traffic"}
             else:
