@@ -290,13 +290,14 @@ def time_gemm_launches(model, args, reps=50):
     return e0.elapsed_time(e1) / reps
 
 
-def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
+def time_optimizer_launches(cfg, device, clipping=True, n_sets=3, reps=45):
     """In-step time of rbr_clip_adam_step[_rows] (its two kernels: gradient norm, clip + Adam): HIP events on the launch
     stream around `n_sets` back-to-back calls, one per ROTATING copy of the model + Adam state + gradients (3 x 210 MB: the
     working set exceeds the 256 MiB Infinity Cache, as it does inside a step, where the conv kernels have pushed p / m / v out
     since the last update).  Each set holds the gradients one backward left behind (the table's in compact row form); they are
-    restored from a copy before every timed trio so that every call clips as the first one did.  The queue stays full, so the
-    interval holds kernel time only.  Returns (ms per call, bytes per call as the kernels move them, ...)."""
+    restored from a copy before every timed trio so that every call sees the same gradient.  `clipping`: whether the timed step's
+    gradient norm exceeds max_grad_norm (the clip then re-writes every existing gradient element: 12 instead of 8 bytes each) --
+    the calls here are given the same state.  Returns (ms per call, bytes per call as the kernels move them, ...)."""
     from review_based_recommender_amd.train_step import HipClipAdam, _forward_loss_backward, make_optimizer
     sets = []
     for k in range(n_sets):
@@ -309,8 +310,9 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
         rows = [(rg.rows, rg.rows.clone()) for rg in o._row_grads.values()] if isinstance(o, HipClipAdam) else []
         dense = [(p.grad, p.grad.clone()) for p in m.parameters() if p.grad is not None]
         sets.append((m, o, rows + dense))
+    max_norm = 5.0 if clipping else 1e30
     for _, o, _ in sets:
-        o.clip_and_step(5.0)
+        o.clip_and_step(max_norm)
     torch.cuda.synchronize()
     # the three calls recorded into ONE hipGraph: replayed, their six kernels run back to back (launched from Python a call costs
     # more host time than its kernels take on the GPU, and the event interval would hold the gaps)
@@ -318,13 +320,13 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _, o, _ in sets:
-            o.clip_and_step(5.0)
+            o.clip_and_step(max_norm)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for _, o, _ in sets:
-            o.clip_and_step(5.0)
+            o.clip_and_step(max_norm)
     pairs = []
     for i in range(reps // n_sets):
         for _, _, saved in sets:           # every set clips as its first call did (restored outside the timed interval)
@@ -341,9 +343,9 @@ def time_optimizer_launches(cfg, device, n_sets=3, reps=45):
     n_par = sum(p.numel() for p in m.parameters())
     row_elems = sum(int(rg.rows.shape[1]) * n for rg, n in ((rg, _listed_rows(rg)) for rg in o._row_grads.values()))
     table_elems = sum(p.numel() for p in o._row_grads)
-    # p, m, v read + written for every parameter; g read twice (norm, update) and written once (clipped) where it exists:
-    # dense gradients of the other tensors, the listed rows of the table (its other rows are never materialised)
-    nbytes = 24.0 * n_par + 12.0 * ((n_par - table_elems) + row_elems)
+    # p, m, v read + written for every parameter; g read twice (norm, update) and -- when the clip scales it -- written once,
+    # where it exists: dense gradients of the other tensors, the listed rows of the table (its other rows are never materialised)
+    nbytes = 24.0 * n_par + (12.0 if clipping else 8.0) * ((n_par - table_elems) + row_elems)
     del sets
     torch.cuda.empty_cache()
     return ms[len(ms) // 2], nbytes, row_elems, table_elems
@@ -539,10 +541,13 @@ def main():
 
     gemm_ms = opt_ms = None
     opt_bytes = opt_rows = opt_table = 0
+    step_clips = True
     if rank == 0 and not dense_mode_env():
         gemm_ms = time_gemm_launches(model, args)
         if not a.torch_optim:
-            opt_ms, opt_bytes, opt_rows, opt_table = time_optimizer_launches(cfg, device)
+            # the clip's state in the timed steps (their last gradient norm): the timing loop is given the same
+            step_clips = True if stepper is None else bool(float(stepper.gnorm) > 5.0)
+            opt_ms, opt_bytes, opt_rows, opt_table = time_optimizer_launches(cfg, device, clipping=step_clips)
 
     # forward-only (eval) rate, reported beside the headline
     model.eval()
@@ -694,8 +699,11 @@ def main():
                               "each), one per rotating copy of parameters + Adam state + gradients (630 MB: beyond the 256 MiB "
                               "Infinity Cache, as inside a step), median of 15 replays / 3; compare clip_adam_kernel<1> + "
                               "grad_sqnorm_kernel in profiles/r03_bench_kernel_stats.csv",
-                    "note": f"24 B x {n_par} parameters (p, m, v read + written) + 12 B x ({n_par - opt_table} dense-gradient elements + "
-                            f"{opt_rows} elements of listed table rows); per pair: {opt_bytes / cfg['B'] / 1e6:.2f} MB of optimizer traffic"}
+                    "clip_active": step_clips,
+                    "note": f"24 B x {n_par} parameters (p, m, v read + written) + {12 if step_clips else 8} B x ({n_par - opt_table} "
+                            f"dense-gradient elements + {opt_rows} elements of listed table rows: norm read, update read"
+                            f"{', clipped write-back' if step_clips else '; the timed steps do not clip, so no write-back'}); per pair: "
+                            f"{opt_bytes / cfg['B'] / 1e6:.2f} MB of optimizer traffic"}
             else:
                 out["roofline"] = out["roofline_gemm"]
         if "roofline" in out and not dense_mode:
@@ -705,7 +713,8 @@ def main():
             cp = sum(k * (cfg["H"] // len(cfg["kz"])) for k in cfg["kz"])
             n_pos = int(masks.numel())
             parts = {
-                "optimizer (p, m, v r+w; existing gradients r, r, w)": 24.0 * n_par + 12.0 * ((n_par - V * D) + n_distinct * D),
+                "optimizer (p, m, v r+w; existing gradients r, r[, w when clipping])":
+                    24.0 * n_par + (12.0 if step_clips else 8.0) * ((n_par - V * D) + n_distinct * D),
                 "distinct-token GEMM (table rows in, product table T out)": 4.0 * n_distinct * (D + 768),
                 "gather + max-pool (T rows once, ids + masks)": 4.0 * n_distinct * 768 + 9.0 * n_pos,
                 "table gradient (G zero + read, compact rows out)": 4.0 * n_distinct * (2 * (cp + 2) + D),
