@@ -52,7 +52,15 @@ typedef struct rbr_textcnn_desc {
     int32_t pad_mode;           /* RBR_PAD_* */
     int32_t act;                /* RBR_ACT_* */
     int32_t padding_idx;        /* table row that never receives gradient (nn.Embedding padding_idx); -1 = none */
+    int32_t flags;              /* RBR_CONV_* bits; 0 = none */
 } rbr_textcnn_desc;
+/* RBR_CONV_PAD_RUNS (un-masked convs: D-ATT, whose documents are right-padded with padding_idx and carry no masks,
+ * dual_att/layers.py:43-53,81-89): the caller guarantees that a position whose tokens are all padding_idx within 8 positions
+ * either side sees the same gate value as every other such position of its document (true for the local gate -- a 5-wide
+ * window of the same tokens -- and for the global gate, one scalar per document).  Every such position then has the SAME conv
+ * output, so a 32-token slab that is all padding (halo included) and FOLLOWS another such slab cannot change max / first argmax
+ * and is not computed.  Exact; valid-padded or width-1 banks only (the flag is ignored otherwise). */
+#define RBR_CONV_PAD_RUNS 1
 
 int rbr_version(void);
 const char* rbr_last_error(void);

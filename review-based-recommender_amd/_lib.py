@@ -33,7 +33,7 @@ class TextCNNDesc(C.Structure):
         ("n_docs", C.c_int32), ("L", C.c_int32), ("D", C.c_int32), ("V", C.c_int32),
         ("n_widths", C.c_int32),
         ("kz", C.c_int32 * RBR_MAX_WIDTHS), ("ch", C.c_int32 * RBR_MAX_WIDTHS),
-        ("pad_mode", C.c_int32), ("act", C.c_int32), ("padding_idx", C.c_int32),
+        ("pad_mode", C.c_int32), ("act", C.c_int32), ("padding_idx", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -254,7 +254,10 @@ def current_stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx) -> TextCNNDesc:
+CONV_PAD_RUNS = 1      # RBR_CONV_PAD_RUNS
+
+
+def make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx, flags: int = 0) -> TextCNNDesc:
     if len(kernel_sizes) > RBR_MAX_WIDTHS:
         raise RuntimeError(f"at most {RBR_MAX_WIDTHS} kernel widths are supported")
     d = TextCNNDesc()
@@ -265,6 +268,7 @@ def make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_id
         d.ch[i] = int(c)
     d.pad_mode, d.act = int(pad_mode), int(act)
     d.padding_idx = -1 if padding_idx is None else int(padding_idx)
+    d.flags = int(flags)
     return d
 
 

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
         float v = NEG;
         if (P.slot_chan[ls] >= 0) {
             const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
-            v = s_flag[side * wpd + w] ? hp.pval[base] : ((w * kTile < Lv) ? 0.f : NEG);
+            const int fl = s_flag[side * wpd + w];          // 1 computed, 0 all masked (sum exactly 0), kSlabDup: changes nothing
+            v = (fl == 1) ? hp.pval[base] : ((fl == 0 && w * kTile < Lv) ? 0.f : NEG);
         }
         s_val[i] = v;
     }
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
         }
         int bidx = 0;
         if (bw_tile >= 0) {
-            if (s_flag[side * wpd + bw_tile]) bidx = hp.pidx[((long)doc * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
+            if (s_flag[side * wpd + bw_tile] == 1) bidx = hp.pidx[((long)doc * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
             else bidx = bw_tile * kTile;
         }
         const int bw = P.slot_w[ls];

@@ -49,6 +49,7 @@ struct ConvPlan {
     unsigned char slot_kz[kMaxSlots];  // kernel width (0 = padding slot)
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
+    int pad_runs;       // RBR_CONV_PAD_RUNS in force (un-masked, valid-padded or width-1 conv): token id of the padding, else -1
 };
 
 struct PtrArray {
@@ -134,8 +135,13 @@ __device__ __forceinline__ void sanitize_id(const IdSets& S, long long k, long l
 
 // Work-list scan of 256 wave-tiles (block `blk` of the scan grid): flags[wt], and the active tiles appended to the
 // list in any order.  sched = flags[total_wt] | list[total_wt] | counters; the counters must be zero beforehand.
+// flags: 1 = computed; 0 = all tokens masked (its conv sums are exactly 0: the finalize kernels count it as that);
+// kSlabDup = un-masked slab of pure padding behind another one (P.pad_runs): position for position the values of its
+// predecessor, so it can change neither a maximum nor a FIRST argmax -- neither computed nor looked at.
+constexpr int kSlabDup = 2;
+constexpr int kPadRunHalo = 8;
 __device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigned char* __restrict__ mask,
-                                                int* __restrict__ sched, int blk) {
+                                                int* __restrict__ sched, int blk, const long long* __restrict__ ids = nullptr) {
     const int wt = blk * 256 + threadIdx.x;
     int act = 0;
     if (wt < P.total_wt) {
@@ -156,10 +162,28 @@ __device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigne
                 for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
             }
             act = act ? 1 : 0;
+        } else if (ids != nullptr && P.pad_runs >= 0) {
+            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
+            // this slab AND the one in front of it, frames and gate halo included, inside the document and all padding?
+            const int lo = l0 - kTile - P.P - kPadRunHalo, hi = l0 + kTile + P.KF - 1 - P.P + kPadRunHalo;
+            if (lo >= 0 && hi <= P.L) {
+                const long long* row = ids + (long)doc * P.L;
+                bool all = true;
+                for (int p = lo; p < hi; p += 8) {          // 8 independent loads per round
+                    long long t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = row[min(p + u, hi - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) all = all && (t[u] == (long long)P.pad_runs);
+                    if (!all) break;
+                }
+                if (all) act = kSlabDup;
+            }
         }
         sched[wt] = act;
     }
-    const unsigned long long b = __ballot(act);
+    const unsigned long long b = __ballot(act == 1);
+    act = act == 1;
     const int lane = threadIdx.x & 63;
     int base = 0;
     if (lane == 0 && b) base = atomicAdd(sched + 2 * (long)P.total_wt, __popcll(b));

@@ -77,6 +77,7 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans, int tiles_per_group)
         p.group = g;
         p.ntiles = std::min(per_group, tiles_total - p.tile_base);
         p.pad_mode = d->pad_mode; p.act = d->act;
+        p.pad_runs = ((d->flags & RBR_CONV_PAD_RUNS) && d->padding_idx >= 0 && (d->pad_mode == RBR_PAD_VALID || KF == 1)) ? d->padding_idx : -1;
         p.n_widths = d->n_widths;
         for (int w = 0; w < d->n_widths; ++w) { p.kz[w] = d->kz[w]; p.ch[w] = d->ch[w]; p.ch_off[w] = ch_off[w]; }
         int lo[kMaxTiles], hi[kMaxTiles];

@@ -671,11 +671,12 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, co
 #pragma unroll
             for (int q = 0; q < 8; ++q) fl[q] = (w0 + q < P.wpd) ? flags[doc * P.wpd + w0 + q] : 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = fl[q] ? pval[base + (long)(w0 + q) * P.nslots_total] : 0.f;
+            for (int q = 0; q < 8; ++q) v[q] = (fl[q] == 1) ? pval[base + (long)(w0 + q) * P.nslots_total] : 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int w = w0 + q;
                 if (w >= P.wpd) break;
+                if (fl[q] == kSlabDup) continue;                // padding run behind an identical slab: changes nothing
                 if (fl[q]) {
                     if (v[q] > best) { best = v[q]; bw_tile = w; }
                 } else if (w * kTile < Lv && 0.f > best) {      // all-masked tile: conv sum is exactly 0 everywhere

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void mark_scan_kernel(const ConvPlan P, int nb
                                                         const unsigned char* __restrict__ mask, int* __restrict__ sched,
                                                         unsigned char* __restrict__ used) {
     if ((int)blockIdx.x < nb_scan) {
-        tile_scan_block(P, mask, sched, blockIdx.x);
+        tile_scan_block(P, mask, sched, blockIdx.x, ids);
         return;
     }
     const long nb = gridDim.x - nb_scan;

@@ -210,7 +210,7 @@ class _TextCNN(torch.autograd.Function):
     """feat[n_docs, C] = pool(act(conv(mask * gate * table[ids])))  -- see rbr_textcnn_* in rbr_hip.h."""
 
     @staticmethod
-    def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *wb):
+    def forward(ctx, table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, conv_flags, *wb):
         ctx.fanout_acc = _fanout_acc(table)
         n = len(kernel_sizes)
         weights, biases = wb[:n], wb[n:]
@@ -223,7 +223,7 @@ class _TextCNN(torch.autograd.Function):
             assert w.shape[1] == D and w.shape[2] == k and b.shape[0] == w.shape[0]
         channels = [w.shape[0] for w in weights]
         Ctot = sum(channels)
-        desc = _lib.make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx)
+        desc = _lib.make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_idx, conv_flags)
         L_ = _lib.lib()
         dev = table.device
         ids = ids.contiguous()
@@ -315,7 +315,7 @@ class _TextCNN(torch.autograd.Function):
         S = _ConvSaved(table=table, ids=ids, packed=packed, feat=feat, argmax=argmax, mask8=mask8, gate=gate, ws=list(saved[k:]),
                        desc=ctx.desc, prod_ws=ctx.prod_ws, fanout_acc=ctx.fanout_acc, bws=None)
         dtable, dgate, dWs, dbs = _textcnn_backward(S, d_feat, ctx.needs_input_grad[0], ctx.has_gate and ctx.needs_input_grad[1])
-        return (dtable, dgate, None, None, None, None, None, None, *dWs, *dbs)
+        return (dtable, dgate, None, None, None, None, None, None, None, *dWs, *dbs)
 
 
 class _ConvSaved:
@@ -574,13 +574,16 @@ def _join(event) -> None:
 
 def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor], weights: Sequence[torch.Tensor],
             biases: Sequence[torch.Tensor], *, gate: Optional[torch.Tensor] = None, pad_mode: int = PAD_SAME,
-            act: int = ACT_RELU, padding_idx: Optional[int] = 0, return_argmax: bool = False):
+            act: int = ACT_RELU, padding_idx: Optional[int] = 0, return_argmax: bool = False, pad_runs: bool = False):
     """Fused WordEmbedding -> masked_tensor -> MyConv1d -> act -> MaxPool1d(seq_len).
 
     table [V,D] f32; ids [n_docs,L] int64; mask [n_docs,L] bool or None; weights[w] [C_w,D,kz_w];
-    biases[w] [C_w].  Returns feat [n_docs, sum C_w] (width-major channels)."""
+    biases[w] [C_w].  Returns feat [n_docs, sum C_w] (width-major channels).
+    pad_runs (un-masked convs only): the caller vouches that `gate` is the same at every position whose tokens are all
+    padding_idx within 8 positions either side (RBR_CONV_PAD_RUNS): runs of padding are then encoded once, exactly."""
     kernel_sizes = tuple(int(w.shape[2]) for w in weights)
-    feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, *weights, *biases)
+    flags = _lib.CONV_PAD_RUNS if (pad_runs and mask is None and padding_idx is not None) else 0
+    feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, flags, *weights, *biases)
     return (feat, argmax) if return_argmax else feat
 
 

@@ -49,8 +49,10 @@ class LocalAttention(nn.Module):
         gate = RF.datt_gate(t_gate, self.attn[0].weight, self.attn[0].bias, ids, is_global=False, padding_idx=padding_idx,
                             rows=rows)
         c = self.conv[0]
+        # pad_runs: the gate of a position is a function of the 5 tokens around it, so positions deep inside a run of padding
+        # all see one gate value and one table row -- the conv encodes such runs once (exact)
         return RF.textcnn(t_conv, ids, None, [c.weight], [c.bias], gate=gate, pad_mode=RF.PAD_SAME, act=RF.ACT_TANH,
-                          padding_idx=padding_idx)                       # [bz, out_size]
+                          padding_idx=padding_idx, pad_runs=self.window_size <= 17)      # [bz, out_size]
 
     def forward(self, x):
         table, ids = _as_table(x)
@@ -78,8 +80,9 @@ class GlobalAttention(nn.Module):
                             rows=rows)
         convs = [self.conv1[0], self.conv2[0], self.conv3[0]]
         # the three widths run in ONE launch of the fused kernel; channels come back width-major
+        # pad_runs: the global gate is one scalar per document (exactly uniform over its padding)
         return RF.textcnn(t_conv, ids, None, [c.weight for c in convs], [c.bias for c in convs], gate=gate,
-                          pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=padding_idx)   # [bz, 3*out_size]
+                          pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=padding_idx, pad_runs=True)   # [bz, 3*out_size]
 
     def forward(self, x):
         table, ids = _as_table(x)

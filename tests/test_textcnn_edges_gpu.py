@@ -167,3 +167,41 @@ def _random_shape(rng):
 def test_textcnn_random_shapes(case, conv_mode):
     rng = np.random.default_rng(1000 + case)
     _case(seed=case, **_random_shape(rng))
+
+
+@pytest.mark.parametrize("kind", ["global", "local"])
+def test_padding_runs_are_encoded_once_and_exactly(kind):
+    """RBR_CONV_PAD_RUNS (D-ATT's un-masked convs over right-padded documents, dual_att/layers.py:43-53,81-89): 32-token slabs of
+    pure padding behind another such slab are not computed.  Features AND first argmax are the bits of the full computation --
+    also with a non-zero padding row (a pretrained table) and with documents that are all padding or have none."""
+    from review_based_recommender_amd import _lib, functional as RF
+    _lib.lib().rbr_set_conv_mode(2)
+    try:
+        g = torch.Generator().manual_seed(11)
+        n_docs, L, E, V = 64, 512, 100, 3000
+        table = torch.randn(V, E, generator=g).to(DEV)             # row 0 (padding) NOT zero
+        ids = torch.randint(1, V, (n_docs, L), generator=g)
+        lens = torch.randint(0, L + 1, (n_docs,), generator=g)
+        lens[0], lens[1], lens[2], lens[3] = 0, L, 1, L - 1
+        ids[torch.arange(L)[None, :] >= lens[:, None]] = 0
+        ids = ids.to(DEV)
+        if kind == "global":
+            ws = [(torch.randn(40, E, k, generator=g) * 0.05).to(DEV) for k in (2, 3, 4)]
+            gate = torch.sigmoid(torch.randn(n_docs, 1, generator=g)).expand(n_docs, L).contiguous().to(DEV)    # one scalar per document
+            kw = dict(pad_mode=RF.PAD_VALID)
+        else:
+            ws = [(torch.randn(96, E, 1, generator=g) * 0.05).to(DEV)]
+            wg = (torch.randn(1, E, 5, generator=g) * 0.1).to(DEV)
+            gate = RF.datt_gate(table, wg, torch.zeros(1, device=DEV), ids, is_global=False, padding_idx=0)      # a function of 5 tokens
+            kw = dict(pad_mode=RF.PAD_SAME)
+        bs = [(torch.randn(w.shape[0], generator=g) * 0.1).to(DEV) for w in ws]
+        outs = []
+        for runs in (False, True):
+            with torch.no_grad():
+                f, am = RF.textcnn(table, ids, None, ws, bs, gate=gate, act=RF.ACT_TANH, padding_idx=0, return_argmax=True,
+                                   pad_runs=runs, **kw)
+            outs.append((f.clone(), am.clone()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        _lib.lib().rbr_set_conv_mode(0)

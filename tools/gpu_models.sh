@@ -19,7 +19,7 @@ for l in sys.stdin:
     rm -rf gpurun_out/mprof_$name
     timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/mprof_$name -o r -- python3 tools/bench_models.py $model ${MODEL_ARGS} > gpurun_out/mprof_$name.log 2>&1
     for e in $envs; do unset "${e%%=*}"; done
-    python tools/prof_db.py gpurun_out/mprof_$name > gpurun_out/mprof_$name.txt 2>&1; head -32 gpurun_out/mprof_$name.txt | cut -c1-120
+    python tools/prof_db.py gpurun_out/mprof_$name --timeline 130 > gpurun_out/mprof_$name.txt 2>&1; head -4 gpurun_out/mprof_$name.txt | cut -c1-120
     rm -rf gpurun_out/mprof_$name
   fi
 done <<< "$AB_CONFIGS"

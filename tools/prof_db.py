@@ -16,7 +16,7 @@ for n, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:28]:
     print(f"{n[:72]:72s} {len(v):6d} {v2[len(v)//2]:8.1f} {sum(v)/len(v):8.1f} {sum(v)/1e3:8.2f} {100*sum(v)/tot:5.1f}")
 if "--timeline" in sys.argv:
     k = int(sys.argv[sys.argv.index("--timeline") + 1])
-    i = len(rows) // 2
+    i = len(rows) // 2 if "--from" not in sys.argv else int(float(sys.argv[sys.argv.index("--from") + 1]) * len(rows))
     while i < len(rows) and not rows[i][0].startswith("__amd_rocclr_copyBuffer"):
         i += 1
     t0 = rows[i][1]
