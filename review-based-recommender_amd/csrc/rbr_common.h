@@ -162,25 +162,48 @@ __device__ __forceinline__ void tile_scan_block(const ConvPlan& P, const unsigne
                 for (int p = lo; p < hi; ++p) act |= mask[(long)doc * P.L + p];
             }
             act = act ? 1 : 0;
-        } else if (ids != nullptr && P.pad_runs >= 0) {
-            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
-            // this slab AND the one in front of it, frames and gate halo included, inside the document and all padding?
-            const int lo = l0 - kTile - P.P - kPadRunHalo, hi = l0 + kTile + P.KF - 1 - P.P + kPadRunHalo;
-            if (lo >= 0 && hi <= P.L) {
-                const long long* row = ids + (long)doc * P.L;
-                bool all = true;
-                for (int p = lo; p < hi; p += 8) {          // 8 independent loads per round
-                    long long t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = row[min(p + u, hi - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) all = all && (t[u] == (long long)P.pad_runs);
-                    if (!all) break;
-                }
-                if (all) act = kSlabDup;
-            }
         }
         sched[wt] = act;
+    }
+    if (mask == nullptr && ids != nullptr && P.pad_runs >= 0) {      // workgroup-uniform
+        // own(w): slab w, frame and gate halo included, lies inside its document and is all padding (16-byte loads, 8 per round);
+        // slab w is a duplicate when own(w) and own(w - 1) -- the predecessor's answer comes from the neighbouring thread
+        __shared__ unsigned char s_own[256];
+        bool own = false;
+        if (wt < P.total_wt) {
+            const int doc = wt / P.wpd, l0 = (wt % P.wpd) * kTile;
+            const int lo = l0 - P.P - kPadRunHalo, hi = l0 + kTile + P.KF - 1 - P.P + kPadRunHalo;
+            if (lo >= 0 && hi <= P.L) {
+                const long long* row = ids + (long)doc * P.L;
+                const long long pad = (long long)P.pad_runs;
+                own = true;
+                int p = lo;
+                if ((((uintptr_t)(row + p)) & 15) == 0) {
+                    for (; p + 16 <= hi && own; p += 16) {
+                        longlong2 t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const longlong2*>(row + p + 2 * u);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) own = own && t[u].x == pad && t[u].y == pad;
+                    }
+                }
+                for (; p < hi && own; ++p) own = row[p] == pad;
+            }
+        }
+        s_own[threadIdx.x] = own ? 1 : 0;
+        __syncthreads();
+        if (wt < P.total_wt && own && (wt % P.wpd) != 0) {
+            bool prev;
+            if (threadIdx.x > 0) {
+                prev = s_own[threadIdx.x - 1] != 0;
+            } else {                                             // first thread of the block: its predecessor belongs to another block
+                const int doc = wt / P.wpd, l0 = (wt % P.wpd - 1) * kTile;
+                const int lo = l0 - P.P - kPadRunHalo, hi = l0 + kTile + P.KF - 1 - P.P + kPadRunHalo;
+                prev = lo >= 0 && hi <= P.L;
+                for (int q = lo; q < hi && prev; ++q) prev = ids[(long)doc * P.L + q] == (long long)P.pad_runs;
+            }
+            if (prev) { act = kSlabDup; sched[wt] = act; }
+        }
     }
     const unsigned long long b = __ballot(act == 1);
     act = act == 1;
