@@ -582,7 +582,8 @@ def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor]
     pad_runs (un-masked convs only): the caller vouches that `gate` is the same at every position whose tokens are all
     padding_idx within 8 positions either side (RBR_CONV_PAD_RUNS): runs of padding are then encoded once, exactly."""
     kernel_sizes = tuple(int(w.shape[2]) for w in weights)
-    flags = _lib.CONV_PAD_RUNS if (pad_runs and mask is None and padding_idx is not None) else 0
+    flags = _lib.CONV_PAD_RUNS if (pad_runs and mask is None and padding_idx is not None
+                                   and os.environ.get("RBR_PAD_RUNS", "1") != "0") else 0
     feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, flags, *weights, *biases)
     return (feat, argmax) if return_argmax else feat
 
