@@ -170,6 +170,11 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));    // segm
 typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(2)));  // four bf16 of a segment that starts at any element
 // TB16: T holds bf16 (the plain-bf16 class with bf16 storage, textcnn_prod_b16.hip): a position's row segments are half the bytes
 // -- this kernel is bound by L2 requests for exactly those -- and are widened to f32 in registers; the sums stay f32.
+// (Measured and dropped, round 3: a TB16 form whose lanes own EIGHT channels -- 8 position classes x 8 octets, one 16-byte load
+// where this kernel issues two 8-byte ones.  52 us against 39 us at cfg2: halving the load instructions does not help when
+// the same row segments, 100 bytes at 4-byte alignment, are fetched by wider and fewer lanes.  The f32 kernel's counters
+// (profiles/r03_gather_pool_pmc.json) say what bounds it instead: its L2 requests equal the distinct 128-byte lines of the
+// rows a tile reads (the L1 absorbs the kz-fold re-reads), 27 % of them miss, and T (44 MB; 22 MB in bf16) fits no XCD's L2.)
 template <bool TB16>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
