@@ -15,9 +15,11 @@ fp32, synthetic Zipf token ids (tests/golden/synth.py).  One step = the referenc
 [N>1: RCCL gradient exchange] -> clip_grad_norm_(5.0) -> Adam(lr=2e-3).  Inputs are resident in
 HBM before the timed region.  Weak scaling: every rank processes its own 256 pairs.
 
-Timing.  The step is recorded once into a hipGraph (train_step.GraphedTrainStep) and replayed.  Every step takes
-the next of --batches (default 4) DISTINCT resident batches: one device-to-device copy into the graph's input block,
-inside the timed region (what a loader's hand-over costs).  A timed block is EXACTLY --steps steps between
+Timing.  The step is recorded into hipGraphs (train_step.GraphedTrainStep) and replayed.  Every step takes the next of
+--batches (default 4) DISTINCT resident batches; each batch sits in its own input slot of the step (one recorded graph per
+slot: a loader stages batch i + 1 into the next slot while slot i runs), so a step starts with no copy of its inputs.
+`copy_per_step` is the one-slot form of earlier rounds (one device-to-device copy into the single input block inside the
+timed region).  A timed block is EXACTLY --steps steps between
 barrier + synchronize on both sides, max over ranks; the block is repeated until >= 0.5 s of timed region and
 `ms_per_step` / `value` are the MEDIAN block (`ms_per_step_min`, `repeats` beside them).  Secondary results, same step:
 `single_batch_replay` (one batch resident in the input block, no copy: round 1's number), `uniform_ids` (token ids
@@ -387,6 +389,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches rotated through the step's input block")
+    ap.add_argument("--one-slot", action="store_true",
+                    help="record ONE step graph and copy every batch into its input block (the copy_per_step form) instead of one graph per resident batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the single-batch / uniform-id / all-distinct secondary results")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
@@ -468,20 +472,24 @@ def main():
     stepper = None
     if use_graph:
         try:
-            stepper = GraphedTrainStep(model, opt, args, ratings, grad_sync=grad_sync)
+            stepper = GraphedTrainStep(model, opt, args, ratings, grad_sync=grad_sync, slots=1 if a.one_slot else len(batches))
         except Exception as e:      # a capture the runtime refuses must not cost the measurement: launch eagerly instead
             use_graph = False
             launch_note = f"hipGraph capture failed ({type(e).__name__}: {str(e)[:120]}); eager launches"
             torch.cuda.synchronize()
 
-    def make_runner(bs, st=None, sync=None):
-        """step(i) over the resident batches `bs`: len(bs) == 1 replays the batch already in the input block."""
+    def make_runner(bs, st=None, sync=None, copy_per_step=False):
+        """step(i) over the resident batches `bs`: batch k lives in input slot k of the step (staged here, outside the timed
+        region); with fewer slots than batches -- or copy_per_step -- every step copies its batch into slot 0 first."""
         st = stepper if st is None else st
         sync = grad_sync if sync is None else sync
         if use_graph:
-            if len(bs) == 1:
-                st(*bs[0])               # resident from here on
-                return lambda i: st()
+            if len(bs) <= st.slots and not copy_per_step:
+                for k, b in enumerate(bs):
+                    st.stage(k, *b)      # resident from here on
+                torch.cuda.synchronize()
+                n = len(bs)
+                return lambda i: st(slot=i % n)
             blobs = [st.pack(*b) for b in bs]
             return lambda i: st(packed=blobs[i % len(blobs)])
         return lambda i: train_step(model, opt, bs[i % len(bs)][0], bs[i % len(bs)][1], grad_sync=sync)
@@ -516,6 +524,12 @@ def main():
         variants["single_batch_replay"] = {"ms_per_step": round(1e3 * statistics.median(one) / a.steps, 4),
                                            "ms_per_step_min": round(1e3 * min(one) / a.steps, 4), "repeats": len(one),
                                            "note": "one batch resident in the step's input block, no per-step copy (round 1's line)"}
+        if use_graph and stepper.slots > 1:
+            cp = timed_blocks(make_runner(batches, copy_per_step=True), min_s=0.25)
+            variants["copy_per_step"] = {"ms_per_step": round(1e3 * statistics.median(cp) / a.steps, 4),
+                                         "ms_per_step_min": round(1e3 * min(cp) / a.steps, 4), "repeats": len(cp),
+                                         "note": "one input slot: every step copies its batch device-to-device into the graph's "
+                                                 "input block inside the timed region (the headline of rounds 2 and 3)"}
         for kind in ("uniform_ids", "all_distinct"):
             vb = [batch_on(cfg, sd, device, ids=kind.replace("_ids", "")) for sd in seeds]
             blk = timed_blocks(make_runner(vb), min_s=0.25)
@@ -586,7 +600,7 @@ def main():
         model.train()
         sync5 = GradAllReduce(model, comm_dtype=torch.bfloat16)
         try:
-            st5 = GraphedTrainStep(model, opt, args, ratings, grad_sync=sync5) if use_graph else None
+            st5 = GraphedTrainStep(model, opt, args, ratings, grad_sync=sync5, slots=stepper.slots) if use_graph else None
             blk = timed_blocks(make_runner(batches, st=st5, sync=sync5), min_s=0.25)
             variants["cfg5_bf16"] = {"ms_per_step": round(1e3 * statistics.median(blk) / a.steps, 4),
                                      "pairs_per_s": round(cfg["B"] * world * a.steps / statistics.median(blk), 1),
@@ -611,7 +625,8 @@ def main():
             "ranks_seen": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
             "config": {"workload": "DeepCoNN cfg2: batch 256 pairs/GPU, 2x512-token docs, D=300, conv widths 3/5/7 x 50, "
                                    "latent 32, V=50002, fp32, Zipf ids", "global_batch": cfg["B"] * world,
-                       "parallelism": f"dp{world}", "launch": launch_note or ("hipGraph replay" if use_graph else "eager"),
+                       "parallelism": f"dp{world}", "launch": launch_note or (("hipGraph replay, one recorded step per resident input slot (no per-step input copy)"
+                                                  if stepper.slots > 1 else "hipGraph replay") if use_graph else "eager"),
                        "resident_batches": nb,
                        "conv_arithmetic": {"f32": "f32 MFMA (v_mfma_f32_32x32x2_f32)",
                                            "bf16x3": "f32 operands split exactly into 3 bf16 planes, 6 plane products per product on "

@@ -162,6 +162,20 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
     const int nslots = P.ntiles * kTile, wpd = P.wpd;
     float* s_val = s_feat + 2 * P.C;                                   // [2][wpd][nslots]
     int* s_flag = reinterpret_cast<int*>(s_val + 2 * wpd * nslots);    // [2][wpd]
+    // (Measured and dropped, round 3: a two-round-trip form of this kernel -- every slab partial AND its position loaded
+    // unconditionally beside the flags, the ids and the thread's column of W, the id-dependent operands in flight during the
+    // winner scan, the dropout call number prefetched: 25.0 us against 24.6 us for this form.  By elimination the launch is
+    // 11.6 us up to the first barrier, +4.8 for the winner scan and its stores, +7 for the head, +3 for the loss tail; none of
+    // it follows the count of dependent loads.)
+    // the plan's slot tables go through LDS with the flags: the plan is a kernel ARGUMENT, and a per-lane index into an argument
+    // array is a vector load from the kernarg segment at every use
+    __shared__ short s_chan[kMaxSlots];
+    __shared__ unsigned char s_sw[kMaxSlots], s_skz[kMaxSlots];
+    __shared__ int s_choff[RBR_MAX_WIDTHS];
+    __shared__ const float* s_biasp[RBR_MAX_WIDTHS];
+    static_assert(kMaxSlots <= 256, "one thread per slot below");
+    if (t < kMaxSlots) { s_chan[t] = P.slot_chan[t]; s_sw[t] = P.slot_w[t]; s_skz[t] = P.slot_kz[t]; }
+    if (t < RBR_MAX_WIDTHS) { s_choff[t] = P.ch_off[t]; s_biasp[t] = hp.bias.p[t]; }
     for (int i = t; i < 2 * wpd; i += 256) {
         const int side = i >= wpd, w = side ? i - wpd : i;
         s_flag[i] = flags[(side * B + b) * wpd + w];
@@ -173,8 +187,8 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
         const int w = r / nslots, ls = r - w * nslots;
         const long base = ((long)(side * B + b) * wpd + w) * P.nslots_total + (long)P.tile_base * kTile + ls;
         float v = NEG;
-        if (P.slot_chan[ls] >= 0) {
-            const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)P.slot_kz[ls] + 1) : P.L;
+        if (s_chan[ls] >= 0) {
+            const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)s_skz[ls] + 1) : P.L;
             const int fl = s_flag[side * wpd + w];          // 1 computed, 0 all masked (sum exactly 0), kSlabDup: changes nothing
             v = (fl == 1) ? hp.pval[base] : ((fl == 0 && w * kTile < Lv) ? 0.f : NEG);
         }
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
     for (int idx = t; idx < 2 * nslots; idx += 256) {
         const int side = idx >= nslots, ls = side ? idx - nslots : idx;
         const int doc = side * B + b;
-        const int chan = P.slot_chan[ls];
+        const int chan = s_chan[ls];
         if (chan < 0) continue;
         float best = NEG;
         int bw_tile = -1;
@@ -197,8 +211,8 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
             if (s_flag[side * wpd + bw_tile] == 1) bidx = hp.pidx[((long)doc * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
             else bidx = bw_tile * kTile;
         }
-        const int bw = P.slot_w[ls];
-        const float y = best + hp.bias.p[bw][chan - P.ch_off[bw]];
+        const int bw = s_sw[ls];
+        const float y = best + s_biasp[bw][chan - s_choff[bw]];
         const float f = (P.act == RBR_ACT_RELU) ? fmaxf(y, 0.f) : tanhf(y);
         hp.feat[(long)doc * P.C + chan] = f;
         hp.argmax[(long)doc * P.C + chan] = bidx;

@@ -334,6 +334,11 @@ class GraphedForward:
         return self.pred
 
 
+class _StepSlot:
+    """One input block of a GraphedTrainStep and the graph(s) recorded over it."""
+    __slots__ = ("flat", "batch", "ratings", "g_fwd_bwd", "g_update", "static_grads", "loss", "gnorm", "pred")
+
+
 class GraphedTrainStep:
     """train_step() recorded once into a hipGraph and replayed: the step is ~70 short kernels (0.8 ms of GPU
     work at the cfg2 shape), so launching them one by one from Python leaves the GPU waiting on the host.
@@ -344,21 +349,35 @@ class GraphedTrainStep:
     `grad_sync` the step is recorded as two graphs (zero_grad+forward+backward | clip+Adam) sharing one memory
     pool, and the RCCL all-reduce runs eagerly between them.
 
+    `slots` > 1 records the step once per INPUT SLOT: each slot has its own input block, so a loader stages batch
+    i + 1 into slot (i + 1) % slots (one host-to-device copy, `stage` / `slot_inputs`) while slot i % slots is replayed,
+    and the step itself starts with no device-to-device copy of its inputs (`__call__(slot=k)`).  Parameters,
+    optimizer state and the optimizer's own buffers are shared by the slots; every slot keeps its own graph memory.
+
     The optimizer must have been built with make_optimizer(..., capturable=True)."""
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, batch, ratings: torch.Tensor,
-                 max_grad_norm: float = MAX_GRAD_NORM, grad_sync=None, warmup: int = 3, capture_error_mode: str | None = None):
+                 max_grad_norm: float = MAX_GRAD_NORM, grad_sync=None, warmup: int = 3, capture_error_mode: str | None = None,
+                 slots: int = 1):
         if not ratings.is_cuda:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
+        if slots < 1:
+            raise ValueError("slots must be >= 1")
         self.model, self.optimizer, self.grad_sync, self.max_grad_norm = model, optimizer, grad_sync, max_grad_norm
-        # every input of the step lives in ONE block (`_flat`): a loader hands over a batch with a single device-to-device
+        # every input of the step lives in ONE block (`flat`): a loader hands over a batch with a single device-to-device
         # (or host-to-device) copy, and the two towers' inputs are neighbours, so the models stack them as a view
         self._layout = _flat_layout(list(batch) + [ratings])
-        self._flat = torch.empty(self._layout[-1], dtype=torch.uint8, device=ratings.device)
-        views = _flat_views(self._flat, self._layout, list(batch) + [ratings])
-        for v, src in zip(views, list(batch) + [ratings]):
-            v.copy_(src)
-        self.batch, self.ratings = tuple(views[:-1]), views[-1]
+        self._slots = []
+        for _ in range(slots):
+            sl = _StepSlot()
+            sl.flat = torch.empty(self._layout[-1], dtype=torch.uint8, device=ratings.device)
+            views = _flat_views(sl.flat, self._layout, list(batch) + [ratings])
+            for v, src in zip(views, list(batch) + [ratings]):
+                v.copy_(src)
+            sl.batch, sl.ratings = tuple(views[:-1]), views[-1]
+            sl.g_update = sl.static_grads = None
+            self._slots.append(sl)
+        first = self._slots[0]
         # the warm-up steps below must not count as training: parameters and Adam state are put back in place
         # (same storage -- the recorded graph keeps their addresses) once the graph exists
         saved_params = [p.detach().clone() for p in model.parameters()]
@@ -368,32 +387,31 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # warm-up off the default stream: allocator, lazy optimizer state, occupancy queries
             for _ in range(warmup):
-                train_step(model, optimizer, self.batch, self.ratings, max_grad_norm, grad_sync)
+                train_step(model, optimizer, first.batch, first.ratings, max_grad_norm, grad_sync)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        optimizer.zero_grad(set_to_none=True)
         # with a process group alive, RCCL's watchdog thread polls events while we record: only this thread's calls
         # may be policed by the capture ("thread_local"), as torch recommends for captures next to NCCL work
         mode = capture_error_mode or ("thread_local" if grad_sync is not None else "global")
-        self.g_fwd_bwd = torch.cuda.CUDAGraph()
-        self.g_update = None
-        self._static_grads = None
-        if grad_sync is None:
-            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
-                self.loss, self.gnorm, self.pred = train_step(model, optimizer, self.batch, self.ratings, max_grad_norm)
-            self._static_grads = [(p, p.grad) for p in model.parameters()]
-        else:
-            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=mode):
-                optimizer.zero_grad()
-                pred, loss = _forward_loss_backward(model, self.batch, self.ratings)
-                self.loss, self.pred = loss.detach(), pred.detach()
-                if isinstance(optimizer, HipClipAdam):
-                    optimizer.materialize_grads()
-            grad_sync(model)
-            self._static_grads = [(p, p.grad) for p in model.parameters()]
-            self.g_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool(), capture_error_mode=mode):
-                self.gnorm = clip_and_step(model, optimizer, max_grad_norm)
+        for sl in self._slots:
+            optimizer.zero_grad(set_to_none=True)
+            sl.g_fwd_bwd = torch.cuda.CUDAGraph()
+            if grad_sync is None:
+                with torch.cuda.graph(sl.g_fwd_bwd, capture_error_mode=mode):
+                    sl.loss, sl.gnorm, sl.pred = train_step(model, optimizer, sl.batch, sl.ratings, max_grad_norm)
+                sl.static_grads = [(p, p.grad) for p in model.parameters()]
+            else:
+                with torch.cuda.graph(sl.g_fwd_bwd, capture_error_mode=mode):
+                    optimizer.zero_grad()
+                    pred, loss = _forward_loss_backward(model, sl.batch, sl.ratings)
+                    sl.loss, sl.pred = loss.detach(), pred.detach()
+                    if isinstance(optimizer, HipClipAdam):
+                        optimizer.materialize_grads()
+                grad_sync(model)
+                sl.static_grads = [(p, p.grad) for p in model.parameters()]
+                sl.g_update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), capture_error_mode=mode):
+                    sl.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
             for p, v in zip(model.parameters(), saved_params):
                 p.copy_(v)
@@ -403,38 +421,67 @@ class GraphedTrainStep:
                         if torch.is_tensor(v):
                             old = saved_state.get(p, {}).get(k)
                             v.copy_(old) if old is not None else v.zero_()
+        if self._slots[-1].static_grads is not None:
+            for p, g in first.static_grads:
+                p.grad = g
+
+    # slot 0 under the names the one-slot step has always had
+    batch = property(lambda self: self._slots[0].batch)
+    ratings = property(lambda self: self._slots[0].ratings)
+    loss = property(lambda self: self._slots[0].loss)
+    gnorm = property(lambda self: self._slots[0].gnorm)
+    pred = property(lambda self: self._slots[0].pred)
+    g_fwd_bwd = property(lambda self: self._slots[0].g_fwd_bwd)
+    g_update = property(lambda self: self._slots[0].g_update)
+    _flat = property(lambda self: self._slots[0].flat)
+
+    @property
+    def slots(self) -> int:
+        return len(self._slots)
+
+    def slot_inputs(self, slot: int = 0):
+        """(batch views, ratings view, the whole block as uint8) of input slot `slot`: what a loader writes into."""
+        sl = self._slots[slot]
+        return sl.batch, sl.ratings, sl.flat
 
     def pack(self, batch, ratings: torch.Tensor) -> torch.Tensor:
         """`batch` + `ratings` as one block in the layout of the step's input buffers (what a loader would stage on the
         device); hand it to __call__(packed=...)."""
-        blob = torch.empty_like(self._flat)
+        blob = torch.empty_like(self._slots[0].flat)
         for v, src in zip(_flat_views(blob, self._layout, list(batch) + [ratings]), list(batch) + [ratings]):
             v.copy_(src)
         return blob
 
-    def __call__(self, batch=None, ratings: torch.Tensor | None = None, packed: torch.Tensor | None = None):
-        """Runs one step on `batch` / `packed` (None: the batch already in the static buffers).  Returns the graph's
-        static (loss, gnorm, pred) tensors -- overwritten by the next replay."""
+    def stage(self, slot: int, batch=None, ratings: torch.Tensor | None = None, packed: torch.Tensor | None = None) -> None:
+        """Copies a batch into input slot `slot` on the current stream (no replay)."""
+        sl = self._slots[slot]
         if packed is not None:
-            if packed.shape != self._flat.shape or packed.dtype != torch.uint8:
+            if packed.shape != sl.flat.shape or packed.dtype != torch.uint8:
                 raise RuntimeError("packed batch does not match the step's input layout (use GraphedTrainStep.pack)")
-            self._flat.copy_(packed, non_blocking=True)      # one copy launch for all inputs
+            sl.flat.copy_(packed, non_blocking=True)      # one copy launch for all inputs
         if batch is not None:
-            for dst, src in zip(self.batch, batch):
+            for dst, src in zip(sl.batch, batch):
                 if dst is not src:
                     dst.copy_(src, non_blocking=True)
-        if ratings is not None and ratings is not self.ratings:
-            self.ratings.copy_(ratings, non_blocking=True)
-        self.g_fwd_bwd.replay()
-        if self._static_grads is not None:
+        if ratings is not None and ratings is not sl.ratings:
+            sl.ratings.copy_(ratings, non_blocking=True)
+
+    def __call__(self, batch=None, ratings: torch.Tensor | None = None, packed: torch.Tensor | None = None, slot: int = 0):
+        """Runs one step on `batch` / `packed` (None: the batch already in the slot's input block).  Returns the slot's
+        static (loss, gnorm, pred) tensors -- overwritten by the next replay of that slot."""
+        sl = self._slots[slot]
+        if batch is not None or ratings is not None or packed is not None:
+            self.stage(slot, batch, ratings, packed)
+        sl.g_fwd_bwd.replay()
+        if sl.static_grads is not None:
             # the graphs read and write the gradient tensors they were recorded with; an eager step in between (a ragged
             # last batch) re-points p.grad elsewhere, so hand the recorded tensors back before anything looks at p.grad
-            for p, g in self._static_grads:
+            for p, g in sl.static_grads:
                 p.grad = g
-        if self.g_update is not None:
+        if sl.g_update is not None:
             tap = getattr(self.grad_sync, "tap", None)
             if tap is not None:
                 tap.mark_replayed()          # the replayed backward refilled the tap buffers (distributed.TapExchange)
             self.grad_sync(self.model)
-            self.g_update.replay()
-        return self.loss, self.gnorm, self.pred
+            sl.g_update.replay()
+        return sl.loss, sl.gnorm, sl.pred

@@ -252,8 +252,12 @@ class ReviewExperiment:
         start = time.time()
         self.model.train()
         for i, batch in enumerate(loader):
-            inputs, ratings = self._to_device(batch)
-            loss, gnorm = self._step(inputs, ratings)
+            staged = self._step_from_host(batch)
+            if staged is not None:
+                loss, gnorm, ratings = staged
+            else:
+                inputs, ratings = self._to_device(batch)
+                loss, gnorm = self._step(inputs, ratings)
             self.updates += 1
             if self.step_losses is not None:
                 self.step_losses.append(loss.detach().clone())
@@ -273,6 +277,20 @@ class ReviewExperiment:
                 sq_err.zero_()
                 steps = count = 0
                 start = time.time()
+
+    def _step_from_host(self, batch):
+        """`fast_step` with the recorded step in hand: a loader batch of the recorded shape goes host-to-device straight into
+        the step's input block (GraphedTrainStep.stage) and the step is replayed -- no intermediate device tensors, no
+        device-to-device copies.  None: not applicable (first batch, ragged batch, a model whose inputs are derived on the
+        device), the caller takes the _to_device + _step route."""
+        if not self.args.fast_step or self._graphed is None or self.kind == "simple_siamese":
+            return None
+        key = tuple((t.shape, t.dtype) for t in batch)
+        if key != self._graphed_key:
+            return None
+        self._graphed.stage(0, tuple(batch[:-1]), batch[-1])
+        loss, gnorm, _ = self._graphed(slot=0)
+        return loss.clone(), gnorm.clone(), self._graphed.ratings
 
     def _step(self, inputs, ratings):
         """One optimisation step; with `fast_step` the step recorded for this batch shape is replayed (a ragged last

@@ -167,13 +167,16 @@ def test_fused_path_reports_out_of_range_ids():
         _lib.lib().rbr_set_conv_mode(0)
 
 
-def _graphed_vs_golden(model, g, args, ratings, cap_args, cap_ratings, tol_max=1e-3):
+def _graphed_vs_golden(model, g, args, ratings, cap_args, cap_ratings, tol_max=1e-3, slots=1):
     from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer
     model.train()
     opt = make_optimizer(model, hip_clip_adam=True)
-    stepper = GraphedTrainStep(model, opt, cap_args, cap_ratings)      # recorded on a DIFFERENT batch
+    stepper = GraphedTrainStep(model, opt, cap_args, cap_ratings, slots=slots)      # recorded on a DIFFERENT batch
+    for k in range(slots):
+        stepper.stage(k, args, ratings)
     for step in range(3):
-        loss, gnorm, pred = stepper(args, ratings)
+        # slots > 1: the fixture's batch sits in every input slot and the slots' graphs take turns (no per-step copy)
+        loss, gnorm, pred = stepper(args, ratings) if slots == 1 else stepper(slot=step % slots)
         torch.cuda.synchronize()
         if step == 0:
             assert max_err(pred.cpu().numpy(), g["pred"]) <= 1e-4
@@ -184,15 +187,17 @@ def _graphed_vs_golden(model, g, args, ratings, cap_args, cap_ratings, tol_max=1
     return opt
 
 
-def test_graphed_hipclipadam_cfg2_matches_reference(golden_dir):
-    """The chain bench.py times -- GraphedTrainStep(model, HipClipAdam) replaying the fused step -- on the cfg2 fixture: loss,
-    clipped norm, predictions and the parameters after 1 and 3 steps against the reference's recording."""
+@pytest.mark.parametrize("slots", [1, 2])
+def test_graphed_hipclipadam_cfg2_matches_reference(golden_dir, slots):
+    """The chain bench.py times -- GraphedTrainStep(model, HipClipAdam) replaying the fused step, one recorded graph per input
+    slot -- on the cfg2 fixture: loss, clipped norm, predictions and the parameters after 1 and 3 steps against the
+    reference's recording."""
     g = golden(golden_dir, "deepconn_cfg2")
     cfg = synth.DEEPCONN_CFGS["cfg2"]
     model = _deepconn(cfg)
     args, ratings = _batch(cfg, 1)
     cap_args, cap_r = _batch(cfg, 77)
-    opt = _graphed_vs_golden(model, g, args, ratings, cap_args, cap_r)
+    opt = _graphed_vs_golden(model, g, args, ratings, cap_args, cap_r, slots=slots)
     table = model.word_embeddings.embedding.weight
     assert table in opt._row_grads, "the benched step is expected to hand the table gradient over in row form"
 

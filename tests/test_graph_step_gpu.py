@@ -53,6 +53,45 @@ def test_graph_replay_matches_eager_steps(name, conv_mode):
         assert float(d.max()) <= 1e-3 and float(d.pow(2).mean().sqrt()) <= 1e-4, n
 
 
+@pytest.mark.parametrize("hip_opt", [False, True])
+def test_input_slots_replay_matches_eager_steps(hip_opt):
+    """slots=2: the step recorded once per input slot.  Batches staged into alternating slots ahead of their replay (the
+    loader's hand-over) and replayed without a copy give the eager steps' results; a slot replayed twice re-runs its batch."""
+    from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
+    cfg = synth.DEEPCONN_CFGS["small"]
+    dev = torch.device("cuda", 0)
+    batches = _batches(cfg, [21, 22, 23, 24, 25], dev)
+    m_e = build_deepconn(cfg, dev); m_g = build_deepconn(cfg, dev)
+    m_e.train(); m_g.train()
+    o_e = make_optimizer(m_e, hip_clip_adam=hip_opt)
+    o_g = make_optimizer(m_g, capturable=True, hip_clip_adam=hip_opt)
+    cap_args, cap_r = _batches(cfg, [99], dev)[0]
+    stepper = GraphedTrainStep(m_g, o_g, cap_args, cap_r, slots=2)
+    assert stepper.slots == 2
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        assert torch.equal(pe, pg)
+    stepper.stage(0, *batches[0])
+    for k, (args, r) in enumerate(batches):
+        if k + 1 < len(batches):
+            stepper.stage((k + 1) % 2, *batches[k + 1])        # the next batch goes into the other slot first
+        le, ge, pe_ = train_step(m_e, o_e, args, r)
+        lg, gg, pg_ = stepper(slot=k % 2)
+        torch.cuda.synchronize()
+        assert abs(float(le) - float(lg)) <= 1e-5 * max(1.0, abs(float(le))), k
+        assert abs(float(ge) - float(gg)) <= 1e-4 * max(1.0, abs(float(ge))), k
+        assert torch.allclose(pe_, pg_, atol=1e-5, rtol=1e-5)
+    # the last batch once more from the slot it already sits in, against an eager step on it
+    le, ge, _ = train_step(m_e, o_e, *batches[-1])
+    lg, gg, _ = stepper(slot=(len(batches) - 1) % 2)
+    assert abs(float(le) - float(lg)) <= 1e-5 * max(1.0, abs(float(le)))
+    for (n, pe), pg in zip(m_e.named_parameters(), m_g.parameters()):
+        d = (pe - pg).abs()
+        assert float(d.max()) <= 1e-3 and float(d.pow(2).mean().sqrt()) <= 1e-4, n
+    # slot views are the loader's targets: writing through them is what stage() does
+    b, r, flat = stepper.slot_inputs(1)
+    assert flat.dtype == torch.uint8 and b[0].shape == batches[0][0][0].shape and r.shape == batches[0][1].shape
+
+
 def test_graphed_forward_replays_the_eval_forward():
     """GraphedForward: the recorded eval forward gives the eager forward's predictions bit for bit on the recorded batch,
     on another batch of the same shape (handed over packed), and after the parameters changed in place; a batch of
