@@ -56,11 +56,24 @@ def run(name, model, args, ratings, B, flops_fwd, bytes_fwd_per_pair):
         for _ in range(n):
             model(*args)
         torch.cuda.synchronize()
-        fwd = (time.perf_counter() - t0) / n
+        fwd_eager = fwd = (time.perf_counter() - t0) / n
+        fwd_graph = None
+        if "--no-graph" not in sys.argv:      # the same forward replayed from a hipGraph: GPU time without the host's launch cost
+            from review_based_recommender_amd.train_step import GraphedForward
+            gf = GraphedForward(model, args)
+            for _ in range(3):
+                gf()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                gf()
+            torch.cuda.synchronize()
+            fwd_graph = fwd = (time.perf_counter() - t0) / n
     print(json.dumps({"model": name, "conv_precision": PRECISION or "bf16x3 (default)", "train_graph_ms": None if graph_ms is None else round(graph_ms, 3),
                       "train_graph_pairs_per_s": None if graph_ms is None else round(B / graph_ms * 1e3, 1),
                       "train_ms": round(step * 1e3, 3), "train_pairs_per_s": round(B / step, 1),
                       "fwd_ms": round(fwd * 1e3, 3), "fwd_pairs_per_s": round(B / fwd, 1),
+                      "fwd_eager_ms": round(fwd_eager * 1e3, 3), "fwd_launch": "hipGraph replay" if fwd_graph is not None else "eager",
                       "fwd_TFLOPs_algorithmic": round(flops_fwd / fwd / 1e12, 2),
                       # algorithmic bytes of one forward (ids + masks + gathered rows) against the HBM peak
                       "roofline": {"bound": "hbm", "achieved": round(bytes_fwd_per_pair * B / fwd / 1e9, 1), "peak": 8000.0,

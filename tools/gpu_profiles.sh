@@ -15,7 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -o r -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-variants > $O/pmc_$n.log 2>&1
   echo "pmc $n rc=$?"
 done
-for k in clip_adam_kernel grad_sqnorm g_times_w gather_pool dw_partial4 prod_gemm_b16 build_g head_fwd_pool; do
+for k in clip_adam grad_sqnorm g_times_w gather_pool dw_partial4 prod_gemm_b16 build_g head_fwd_pool; do
   python tools/pmc_summary.py $k $O/r03_${k}_pmc.json $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_sum > /dev/null 2>&1 || echo "pmc summary $k failed"
 done
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_sum
