@@ -253,6 +253,19 @@ int rbr_textcnn_bwd_taps(const rbr_textcnn_desc* d, const int64_t* ids, const ui
 size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* d, int32_t n_sets);
 int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
                                  const float* const* W, void* ws, float* dtable, void* stream);
+/* Owner partition of the same rebuild (rank r of n_sets builds only the rows of the tokens t with t % n_sets == r; the ranks
+ * exchange the slabs afterwards -- distributed.OwnerExchange -- so sort and row build shrink to 1 / n_sets per rank):
+ *   rbr_textcnn_taps_owner_rows(d, n_sets)  : rows of a slab = ceil(V / n_sets); row i of rank r's slab is token i * n_sets + r
+ *                                             (rows past the vocabulary, and tokens without taps, are zero rows);
+ *   rbr_textcnn_dtable_from_taps_owner      : OVERWRITES slab [rows, D] with the MEAN over the sets; same `tok` / `val` / W / ws
+ *                                             (rbr_textcnn_dtable_from_taps_ws_bytes) as above.  The rank's taps are compacted
+ *                                             (stably) before the sort, which is sized for twice the even share of the taps:
+ *                                             *overflow (device, caller-zeroed, sticky) is set to 1 when the rank owns more --
+ *                                             its slab is then incomplete and the step must be discarded. */
+int32_t rbr_textcnn_taps_owner_rows(const rbr_textcnn_desc* d, int32_t n_sets);
+int rbr_textcnn_dtable_from_taps_owner(const rbr_textcnn_desc* d, int32_t n_sets, int32_t rank, const int32_t* tok,
+                                       const float* val, const float* const* W, void* ws, float* slab, int32_t* overflow,
+                                       void* stream);
 int rbr_textcnn_bwd(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                     const float* table, const float* packed, const float* feat, const int32_t* argmax,
                     const float* d_feat, float* const* dW, float* const* dbias, float* dtable, float* dgate,

@@ -123,6 +123,8 @@ SIGNATURES = {
     "rbr_textcnn_bwd_taps": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_i32p, c_f32p, c_i32p, c_f32p, c_stream]),
     "rbr_textcnn_dtable_from_taps_ws_bytes": (C.c_size_t, [_DESC, i32]),
     "rbr_textcnn_dtable_from_taps": (C.c_int, [_DESC, i32, c_i32p, c_f32p, _PP, C.c_void_p, c_f32p, c_stream]),
+    "rbr_textcnn_taps_owner_rows": (i32, [_DESC, i32]),
+    "rbr_textcnn_dtable_from_taps_owner": (C.c_int, [_DESC, i32, i32, c_i32p, c_f32p, _PP, C.c_void_p, c_f32p, c_i32p, c_stream]),
     "rbr_textcnn_bwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, _PP, _PP,
                                   c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_datt_local_gate_prod_ws_bytes": (C.c_size_t, [i32, i32, i32, i32, i32]),

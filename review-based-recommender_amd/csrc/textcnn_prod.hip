@@ -524,6 +524,93 @@ __global__ __launch_bounds__(256) void taps_keys_kernel(const ProdBwdArgs A, lon
     }
 }
 
+// ---- owner partition of the rebuild: rank r turns only the taps of the tokens t with t % n_sets == r into rows (local row
+// t / n_sets of its slab); the slabs are exchanged afterwards (distributed.OwnerExchange).  The rank's taps are first
+// compacted -- stably, in two passes over fixed chunks, so a run repeats bit for bit -- to the front of the key / payload
+// arrays; what follows (sort, bounds, rows) runs on `cap_own` entries and ceil(V / n_sets) rows instead of all of them.
+constexpr int kOwnChunks = 2048;
+// entries the owner's sort is sized for: twice the even share (the token -> owner map is t % n_sets; the Zipf head makes the
+// shares uneven) plus slack; never more than all of them
+inline long taps_owner_cap(long total, int n_sets) { return std::min(total, 2 * ((total + n_sets - 1) / n_sets) + 4096); }
+__device__ __forceinline__ long own_chunk(long total) { return ((total + kOwnChunks - 1) / kOwnChunks + 255) / 256 * 256; }
+
+__global__ __launch_bounds__(256) void taps_owner_count_kernel(long total, int n_sets, int rank, const int* __restrict__ tok,
+                                                               int* __restrict__ blk_cnt) {
+    __shared__ int s_c[kWavesPerWG];
+    const long chunk = own_chunk(total), lo = (long)blockIdx.x * chunk, hi = min(total, lo + chunk);
+    int c = 0;
+    for (long k = lo + threadIdx.x; k < hi; k += 256) {
+        const int t = tok[k];
+        c += (t >= 0 && t % n_sets == rank) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+}
+
+// key = local row t / n_sets; the entries past the rank's count up to cap_own get the key v_own (behind every row).
+// *overflow = 1 when the rank owns more than cap_own taps (the surplus is dropped: the caller must treat the step as failed).
+__global__ __launch_bounds__(256) void taps_owner_keys_kernel(const ProdBwdArgs A, long n_items, int n_sets, int rank, int v_own,
+                                                              long cap_own, const int* __restrict__ tok,
+                                                              const float* __restrict__ val, const int* __restrict__ blk_cnt,
+                                                              int* __restrict__ keys, unsigned long long* __restrict__ pay,
+                                                              int* __restrict__ overflow) {
+    __shared__ long s_red[2][kWavesPerWG];
+    __shared__ int s_wcnt[kWavesPerWG];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long total = n_items * n_sets;
+    long before = 0, all = 0;
+    for (int i = tid; i < kOwnChunks; i += 256) {
+        const int c = blk_cnt[i];
+        all += c;
+        if (i < (int)blockIdx.x) before += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { s_red[0][wave] = before; s_red[1][wave] = all; }
+    __syncthreads();
+    before = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+    all = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    if (blockIdx.x == 0 && tid == 0 && all > cap_own) *overflow = 1;
+    const long chunk = own_chunk(total), lo = (long)blockIdx.x * chunk, hi = min(total, lo + chunk);
+    long run = before;                                         // output position of the chunk's next kept entry
+    for (long k0 = lo; k0 < hi; k0 += 256) {                   // workgroup-uniform trip count
+        const long k = k0 + tid;
+        int t = -1;
+        if (k < hi) t = tok[k];
+        const bool keep = t >= 0 && t % n_sets == rank;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int wbase = 0, wall = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerWG; ++w) { if (w < wave) wbase += s_wcnt[w]; wall += s_wcnt[w]; }
+        if (keep) {
+            const long pos = run + wbase + __popcll(m & ((1ull << lane) - 1));
+            if (pos < cap_own) {
+                const long e = k % n_items;
+                const long o = e / A.KF;
+                const int j = (int)(e - o * A.KF), c = (int)(o % A.C);
+                int w = 0;
+#pragma unroll
+                for (int q = 1; q < RBR_MAX_WIDTHS; ++q)
+                    if (q < A.n_widths && c >= A.ch_off[q]) w = q;
+                const int col = A.poff[w] + min(j, A.kz[w] - 1) * A.ch[w] + (c - A.ch_off[w]);
+                keys[pos] = t / n_sets;
+                pay[pos] = ((unsigned long long)(unsigned)col << 32) | (unsigned)__float_as_int(val[k]);
+            }
+        }
+        run += wall;
+        __syncthreads();
+    }
+    for (long pos = min(all, cap_own) + (long)blockIdx.x * 256 + tid; pos < cap_own; pos += (long)gridDim.x * 256) {
+        keys[pos] = v_own;
+        pay[pos] = 0ull;
+    }
+}
+
 // first / one-past-last sorted position of every token that has taps (start1 = first + 1, 0 = none)
 __global__ __launch_bounds__(256) void taps_bounds_kernel(long total, int V, const int* __restrict__ keys, int* __restrict__ start1,
                                                           int* __restrict__ end) {
@@ -1459,7 +1546,7 @@ bool taps_args(const rbr_textcnn_desc* d, ProdBwdArgs& A, int& cp_real, int& KG)
     A.KG = KG;
     return true;
 }
-struct TapsLayout { size_t keys_in, keys, pay_in, pay, start1, end, hot_count, hot_list, split_arrived, split_rows, WT, temp, total; size_t temp_bytes; int KGW, max_split; };
+struct TapsLayout { size_t keys_in, keys, pay_in, pay, start1, end, hot_count, hot_list, split_arrived, split_rows, WT, blk_cnt, temp, total; size_t temp_bytes; int KGW, max_split; };
 bool taps_layout(const rbr_textcnn_desc* d, int n_sets, long n_items, int cp_real, int KG, TapsLayout& T) {
     if (d->D % 4 != 0 || n_sets <= 0) return false;
     T.KGW = ((KG / 4 + kWavesPerWG - 1) / kWavesPerWG) * 4;
@@ -1482,6 +1569,7 @@ bool taps_layout(const rbr_textcnn_desc* d, int n_sets, long n_items, int cp_rea
     T.split_arrived = o; o += align256((size_t)T.max_split * 2 * sizeof(int));                  // contiguous with split_rows: zeroed together
     T.split_rows = o; o += align256((size_t)T.max_split * KG * sizeof(unsigned long long));
     T.WT = o;      o += align256((size_t)cp_real * d->D * sizeof(float));
+    T.blk_cnt = o; o += align256((size_t)(kOwnChunks + 64) * sizeof(int));      // owner partition: chunk counts, then the overflow flag
     T.temp = o;    o += align256(T.temp_bytes) + 256;
     T.total = o;
     return true;
@@ -1512,14 +1600,18 @@ extern "C" size_t rbr_textcnn_dtable_from_taps_ws_bytes(const rbr_textcnn_desc* 
     return T.total;
 }
 
-extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
-                                            const float* const* W, void* ws, float* dtable, void* stream) {
+namespace {
+// own_rank < 0: every token's row into out [V, D].  own_rank >= 0: the rows of the tokens t % n_sets == own_rank into
+// out [ceil(V / n_sets), D] (row t / n_sets), `overflow` set when the rank's taps exceed the bound the sort is sized for.
+int taps_rebuild(const rbr_textcnn_desc* d, int n_sets, int own_rank, const int32_t* tok, const float* val, const float* const* W,
+                 void* ws, float* out, int32_t* overflow, hipStream_t st) {
     ProdBwdArgs A; int cp_real, KG; TapsLayout T;
     if (!taps_args(d, A, cp_real, KG)) return RBR_ERR_BAD_ARG;
     const long n_items = (long)A.n_docs * A.C * A.KF;
     if (!taps_layout(d, n_sets, n_items, cp_real, KG, T)) { set_error("tap exchange does not support this shape"); return RBR_ERR_UNSUPPORTED; }
-    if (!tok || !val || !W || !ws || !dtable) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipStream_t st = (hipStream_t)stream;
+    if (!tok || !val || !W || !ws || !out) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    const bool own = own_rank >= 0;
+    if (own && (own_rank >= n_sets || !overflow)) { set_error("taps owner rebuild: rank %d of %d, overflow flag %p", own_rank, n_sets, (void*)overflow); return RBR_ERR_BAD_ARG; }
     char* base = static_cast<char*>(ws);
     int* keys_in = reinterpret_cast<int*>(base + T.keys_in);
     int* keys = reinterpret_cast<int*>(base + T.keys);
@@ -1529,14 +1621,25 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
     int* end = reinterpret_cast<int*>(base + T.end);
     float* WT = reinterpret_cast<float*>(base + T.WT);
     const long total = n_items * n_sets;
-    A.cap = d->V;
-    hipLaunchKernelGGL(taps_keys_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, A, n_items, n_sets,
-                       d->V, tok, val, keys_in, pay_in);
-    RBR_CHECK_LAUNCH("textcnn taps keys launch");
+    const int Vloc = own ? (d->V + n_sets - 1) / n_sets : d->V;                  // rows this call builds
+    const long n_sort = own ? rbr::taps_owner_cap(total, n_sets) : total;        // entries that go through the sort
+    A.cap = Vloc;
+    if (own) {
+        int* blk_cnt = reinterpret_cast<int*>(base + T.blk_cnt);
+        hipLaunchKernelGGL(taps_owner_count_kernel, dim3(kOwnChunks), dim3(256), 0, st, total, n_sets, own_rank, tok, blk_cnt);
+        RBR_CHECK_LAUNCH("textcnn taps owner count launch");
+        hipLaunchKernelGGL(taps_owner_keys_kernel, dim3(kOwnChunks), dim3(256), 0, st, A, n_items, n_sets, own_rank, Vloc, n_sort, tok, val,
+                           blk_cnt, keys_in, pay_in, overflow);
+        RBR_CHECK_LAUNCH("textcnn taps owner keys launch");
+    } else {
+        hipLaunchKernelGGL(taps_keys_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, A, n_items, n_sets,
+                           d->V, tok, val, keys_in, pay_in);
+        RBR_CHECK_LAUNCH("textcnn taps keys launch");
+    }
     int bits = 1;
-    while ((1L << bits) <= d->V) ++bits;                 // keys are in [0, V]
+    while ((1L << bits) <= Vloc) ++bits;                 // keys are in [0, Vloc]
     size_t temp_bytes = T.temp_bytes;
-    if (int e = check_hip(rocprim::radix_sort_pairs(base + T.temp, temp_bytes, keys_in, keys, pay_in, pay, (size_t)total, 0, bits, st),
+    if (int e = check_hip(rocprim::radix_sort_pairs(base + T.temp, temp_bytes, keys_in, keys, pay_in, pay, (size_t)n_sort, 0, bits, st),
                           "textcnn taps radix sort"))
         return e;
     int* hot_count = reinterpret_cast<int*>(base + T.hot_count);
@@ -1548,7 +1651,7 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
                       {(long)(align256((size_t)d->V * sizeof(int)) / sizeof(int)), 64, (long)((T.WT - T.split_arrived) / sizeof(int))}};
         if (int e = zero_regions(z, st)) return e;
     }
-    hipLaunchKernelGGL(taps_bounds_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, total, d->V, keys,
+    hipLaunchKernelGGL(taps_bounds_kernel, dim3((unsigned)std::min<long>((n_sort + 255) / 256, 8192)), dim3(256), 0, st, n_sort, Vloc, keys,
                        start1, end);
     RBR_CHECK_LAUNCH("textcnn taps bounds launch");
     PackJob J{};
@@ -1557,14 +1660,31 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
     PtrArray wp{};
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
     hipLaunchKernelGGL(taps_wt_kernel, dim3((unsigned)std::min<long>(((long)cp_real * d->D + 255) / 256, 1024)), dim3(256), 0, st, J, wp, WT,
-                       d->V, start1, end, hot_count, hot_list);
+                       Vloc, start1, end, hot_count, hot_list);
     RBR_CHECK_LAUNCH("textcnn taps weights launch");
     const size_t lds = (size_t)KG * 8 + (size_t)T.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
-    const int n_row_wgs = std::min(d->V, 8192), n_cold_wgs = (d->V + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(taps_rows_kernel, dim3((unsigned)(n_row_wgs + n_cold_wgs)), dim3(256), lds, st, A, T.KGW, d->V, hot_count, hot_list,
-                       start1, end, pay, 1.f / (kTapScale * (float)n_sets), WT, dtable, split_rows, split_arrived, n_row_wgs);
+    const int n_row_wgs = std::min(Vloc, 8192), n_cold_wgs = (Vloc + kWavesPerWG - 1) / kWavesPerWG;
+    hipLaunchKernelGGL(taps_rows_kernel, dim3((unsigned)(n_row_wgs + n_cold_wgs)), dim3(256), lds, st, A, T.KGW, Vloc, hot_count, hot_list,
+                       start1, end, pay, 1.f / (kTapScale * (float)n_sets), WT, out, split_rows, split_arrived, n_row_wgs);
     RBR_CHECK_LAUNCH("textcnn taps rows launch");
     return 0;
+}
+}  // namespace
+
+extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, const int32_t* tok, const float* val,
+                                            const float* const* W, void* ws, float* dtable, void* stream) {
+    return taps_rebuild(d, n_sets, -1, tok, val, W, ws, dtable, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int32_t rbr_textcnn_taps_owner_rows(const rbr_textcnn_desc* d, int32_t n_sets) {
+    return (d && n_sets > 0) ? (d->V + n_sets - 1) / n_sets : 0;
+}
+
+extern "C" int rbr_textcnn_dtable_from_taps_owner(const rbr_textcnn_desc* d, int32_t n_sets, int32_t rank, const int32_t* tok,
+                                                  const float* val, const float* const* W, void* ws, float* slab,
+                                                  int32_t* overflow, void* stream) {
+    if (rank < 0) { set_error("taps owner rebuild: rank %d", rank); return RBR_ERR_BAD_ARG; }
+    return taps_rebuild(d, n_sets, rank, tok, val, W, ws, slab, overflow, (hipStream_t)stream);
 }
 
 namespace rbr {

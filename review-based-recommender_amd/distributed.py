@@ -56,11 +56,19 @@ class TapExchange:
     Handles ONE un-gated conv call over the table per step (DeepCoNN++); a second call, or a model whose table also
     receives dense gradient pieces, falls back to the dense all-reduce (GradAllReduce does that when `pending` is False)."""
 
-    def __init__(self, table: nn.Parameter, group=None):
+    def __init__(self, table: nn.Parameter, group=None, owner: bool = False, optimizer=None):
+        """owner=True: the OWNER-PARTITIONED rebuild.  Every rank still receives all taps, but turns only the taps of "its" tokens
+        (token t belongs to rank t % N) into gradient rows -- sort and row build shrink to 1/N per rank -- and the ranks then
+        all-gather their slabs of ceil(V/N) rows: every rank ends up with the same averaged gradient, row t at
+        [t % N][t // N].  `optimizer` (a train_step.HipClipAdam) takes it in that layout (functional.RowGradient over a static
+        token -> row map: no permuting copy); any other optimizer gets the dense [V, D] tensor."""
         self.table = table
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.owner = bool(owner)
+        self.optimizer = optimizer
+        self.slabs = self.row_map = self.sq = self.overflow = None
         self.n = 0
         self.tok = self.val = self.dtable = self.ws = None
         self.desc = self.weights = None
@@ -136,6 +144,8 @@ class TapExchange:
         from . import _lib
         L_ = _lib.lib()
         dev = self.tok.device
+        if self.owner:
+            return self._finish_owner(L_, dev)
         if self.dtable is None:
             self.dtable = torch.empty_like(self.table)
             self.ws = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(self.desc), self.world), dtype=torch.uint8,
@@ -153,17 +163,69 @@ class TapExchange:
         self.calls = 0
 
 
+    def _finish_owner(self, L_, dev) -> None:
+        import ctypes as C
+        from . import _lib, functional as RF
+        V, D = int(self.table.shape[0]), int(self.table.shape[1])
+        if self.slabs is None:
+            v_own = int(L_.rbr_textcnn_taps_owner_rows(C.byref(self.desc), self.world))
+            self.v_own = v_own
+            # [rank][row], one extra row per rank whose first element carries the sum of squares of the rank's rows (the clip's
+            # norm needs nothing else from the other ranks); the all-gather fills every rank's part
+            self.slabs = torch.zeros(self.world, v_own + 1, D, dtype=torch.float32, device=dev)
+            t = torch.arange(V, device=dev)
+            self.row_map = ((t % self.world) * (v_own + 1) + t // self.world).to(torch.int32)
+            self.sq = torch.zeros(self.world, dtype=torch.float32, device=dev)
+            self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.ws = torch.empty(L_.rbr_textcnn_dtable_from_taps_ws_bytes(C.byref(self.desc), self.world), dtype=torch.uint8,
+                                  device=dev)
+        v_own = self.v_own
+        own = self.slabs[self.rank]
+        _lib.check(L_.rbr_textcnn_dtable_from_taps_owner(C.byref(self.desc), self.world, self.rank,
+                                                         _lib.dev_ptr(self.tok, torch.int32, "tap tokens"),
+                                                         _lib.dev_ptr(self.val, torch.float32, "tap values"),
+                                                         _lib.ptr_array(self.weights, torch.float32, "conv weight"),
+                                                         self.ws.data_ptr(), _lib.dev_ptr(own, torch.float32, "slab"),
+                                                         _lib.dev_ptr(self.overflow, torch.int32, "overflow"),
+                                                         _lib.current_stream()), "rbr_textcnn_dtable_from_taps_owner")
+        rows = own[:v_own]
+        own[v_own, 0] = torch.linalg.vector_norm(rows).square()
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.slabs.view(-1), own.reshape(-1), group=self.group)      # in place: own is its slice
+        else:
+            dist.all_gather(list(self.slabs.view(self.world, -1).unbind(0)), own.reshape(-1).clone(), group=self.group)
+        self.sq.copy_(self.slabs[:, v_own, 0])
+        rg = RF.RowGradient(self.table, self.slabs.view(-1, D), self.sq, self.row_map.data_ptr(), (self.row_map, self.slabs))
+        dense_part = self.table.grad if self.calls > 1 else None      # a second conv's part, already averaged densely
+        taken = False
+        if dense_part is None and self.optimizer is not None and hasattr(self.optimizer, "put_exchanged_rows"):
+            taken = self.optimizer.put_exchanged_rows(self.table, rg)
+        if not taken:
+            dense = rg.to_dense()
+            self.table.grad = dense if dense_part is None else dense.add_(dense_part)
+        self.desc = self.weights = None
+        self.calls = 0
+
+    def check(self) -> None:
+        """Owner mode: raises if some step's taps exceeded the bound the owner's sort is sized for (a synchronisation point:
+        call it where the trainer reads the loss anyway)."""
+        if self.overflow is not None and int(self.overflow.item()) != 0:
+            raise RuntimeError("TapExchange(owner): a rank owned more taps than twice the even share; that step's table "
+                               "gradient was incomplete -- use the replicated rebuild or the dense all-reduce for this data")
+
+
 class GradAllReduce:
     """Callable `grad_sync(model)` hook for train_step(): averages .grad over the process group."""
 
     def __init__(self, model: nn.Module, group=None, comm_dtype: Optional[torch.dtype] = None,
-                 tap_table: Optional[nn.Parameter] = None):
+                 tap_table: Optional[nn.Parameter] = None, owner: bool = False, optimizer=None):
         """`tap_table`: the word-table parameter whose gradient is exchanged in tap form (TapExchange) instead of being
-        all-reduced densely; None keeps the dense all-reduce for every parameter."""
+        all-reduced densely; None keeps the dense all-reduce for every parameter.  `owner` / `optimizer`: the
+        owner-partitioned rebuild of TapExchange and the optimizer that takes its row-form result."""
         self.tap = None
         if tap_table is not None and dist.get_world_size(group) > 1:
             from . import functional as RF
-            self.tap = TapExchange(tap_table, group)
+            self.tap = TapExchange(tap_table, group, owner=owner, optimizer=optimizer)
             RF.set_tap_sink(self.tap)          # keyed by the table: other models' convs never reach this sink
         self.group = group
         self.world = dist.get_world_size(group)

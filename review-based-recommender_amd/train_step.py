@@ -92,6 +92,18 @@ class HipClipAdam(torch.optim.Optimizer):
             p.grad = dense if p.grad is None else p.grad + dense
         self._row_grads[p] = rg
 
+    def put_exchanged_rows(self, table, rg) -> bool:
+        """A data-parallel exchange (distributed.TapExchange, owner mode) hands over the AVERAGED gradient of `table` in row form:
+        the next clip_and_step reads it through rg's token -> row map.  False: not a table this optimizer can take that way."""
+        p = next((q for g in self.param_groups for q in g["params"] if q.data_ptr() == table.data_ptr()), None)
+        if p is None or p.dim() != 2 or p.shape[1] % 4 != 0 or p.dtype != torch.float32 or not p.is_cuda \
+                or os.environ.get("RBR_ROW_GRADS", "1") == "0":
+            return False
+        self._row_grads.clear()           # one row-form table per launch pair
+        self._row_grads[p] = rg
+        p.grad = None
+        return True
+
     def close(self) -> None:
         """Unregisters the row-gradient hand-off (the tables get dense gradients again)."""
         for p in self._row_tables:

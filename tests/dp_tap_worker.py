@@ -40,6 +40,7 @@ def main():
         return tuple(b[k].to(dev) for k in ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids")), b["ratings"].to(dev)
 
     args, ratings = batch(10 + rank)                       # every rank its own shard
+    owner = os.environ.get("RBR_TEST_EXCHANGE", "taps") == "owner"      # the owner-partitioned rebuild + slab all-gather
 
     # dense all-reduce of every gradient
     m_d = build()
@@ -50,10 +51,15 @@ def main():
 
     # tap exchange of the table gradient
     m_t = build()
-    sync_t = GradAllReduce(m_t, tap_table=m_t.word_embeddings.embedding.weight)
+    o_t = make_optimizer(m_t, hip_clip_adam=True)
+    sync_t = GradAllReduce(m_t, tap_table=m_t.word_embeddings.embedding.weight, owner=owner, optimizer=o_t if owner else None)
     F.mse_loss(m_t(*args), ratings).backward()
     assert m_t.word_embeddings.embedding.weight.grad is None, "the table gradient must come from the exchange"
     sync_t(m_t)
+    if owner:
+        assert m_t.word_embeddings.embedding.weight.grad is None and len(o_t._row_grads) == 1, "row form expected"
+        o_t.materialize_grads()                            # the dense view of the exchanged rows, for the comparison below
+        sync_t.tap.check()
     for k, p in m_t.named_parameters():
         scale = float(ref[k].abs().max()) + 1e-12
         err = float((p.grad - ref[k]).abs().max())
@@ -67,8 +73,8 @@ def main():
     assert all(int(v) == int(allv[0]) for v in allv), [int(v) for v in allv]
 
     # three optimisation steps, eager and replayed as hipGraphs, against the dense data-parallel step
-    o_d, o_t = make_optimizer(m_d, hip_clip_adam=True), make_optimizer(m_t, hip_clip_adam=True)
-    m_d.zero_grad(); m_t.zero_grad()
+    o_d = make_optimizer(m_d, hip_clip_adam=True)
+    m_d.zero_grad(); o_t.zero_grad()
     stepper = GraphedTrainStep(m_t, o_t, args, ratings, grad_sync=sync_t)
     for step in range(3):
         a2, r2 = batch(20 + 7 * step + rank)
@@ -102,10 +108,13 @@ def main():
         assert float(d.max()) <= 1e-3 and float(d.pow(2).mean().sqrt()) <= 1e-4, (k, float(d.max()))
     if rank == 0:
         print("largest parameter difference after 3 steps (max, rms, name):", worst, flush=True)
+    if owner:
+        sync_t.tap.check()
+        assert m_t.word_embeddings.embedding.weight.grad is None, "owner mode: the optimizer reads the exchanged rows in place"
     RF.set_tap_sink(None)
     dist.barrier()
     if rank == 0:
-        print("TAP EXCHANGE OK", flush=True)
+        print("TAP EXCHANGE OK" + (" (owner)" if owner else ""), flush=True)
     dist.destroy_process_group()
 
 

@@ -9,10 +9,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_tap_exchange_matches_dense_allreduce():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("exchange", ["taps", "owner"])
+def test_tap_exchange_matches_dense_allreduce(exchange):
+    """taps: every rank rebuilds the whole averaged table gradient from the gathered taps.  owner: rank r rebuilds the rows of
+    the tokens t % N == r, the slabs are all-gathered and HipClipAdam reads them in place (row form)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", RBR_TEST_EXCHANGE=exchange)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(HERE, "dp_tap_worker.py")]
+           "--master-port", "29533" if exchange == "taps" else "29537", os.path.join(HERE, "dp_tap_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "TAP EXCHANGE OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
@@ -81,3 +84,26 @@ def test_rebuild_from_taps_matches_float64_reference_and_is_order_free():
     assert torch.isfinite(got).all()
     assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
     assert float(got[counts == 0].abs().max()) == 0.0
+    # the owner partition of the same rebuild: rank r's slab holds the rows of the tokens t % n_sets == r, the same bits as the
+    # replicated rebuild (fixed-point sums for the hot rows; the cold rows are summed in array order, and the stable compaction
+    # + stable sort keep a token's taps in the order the replicated sort leaves them in)
+    v_own = L_.rbr_textcnn_taps_owner_rows(C.byref(d), n_sets)
+    assert v_own == (V + n_sets - 1) // n_sets
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    merged = torch.full((v_own * n_sets, D), float("nan"), device=dev)
+    for r in range(n_sets):
+        slab = torch.full((v_own, D), float("nan"), device=dev)
+        _lib.check(L_.rbr_textcnn_dtable_from_taps_owner(C.byref(d), n_sets, r, tok.data_ptr(), val.data_ptr(), W, wsb.data_ptr(),
+                                                         slab.data_ptr(), flag.data_ptr(), st), "owner rebuild")
+        merged[r::n_sets] = slab
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert torch.equal(merged[:V], outs[0])
+    assert float(merged[V:].abs().max()) == 0.0 if merged.shape[0] > V else True
+    # a rank that owns more taps than the sort is sized for reports it instead of building a wrong slab silently
+    tok_skew = torch.where(tok >= 0, (tok // n_sets) * n_sets, torch.full_like(tok, n_sets))      # every entry a tap on a token of rank 0
+    slab = torch.empty(v_own, D, device=dev)
+    _lib.check(L_.rbr_textcnn_dtable_from_taps_owner(C.byref(d), n_sets, 0, tok_skew.data_ptr(), val.data_ptr(), W, wsb.data_ptr(),
+                                                     slab.data_ptr(), flag.data_ptr(), st), "owner rebuild (skewed)")
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
