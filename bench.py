@@ -178,44 +178,56 @@ def cpu_baseline(cfg, budget_s=20.0):
     }
 
 
-def verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=False):
-    """Start-up self-check of the tap exchange (distributed.TapExchange) on this job's own ranks: one backward whose
-    gradients are all-reduced densely, the same backward with the table gradient exchanged as taps; the two table
-    gradients must agree on every rank, otherwise the job falls back to the dense all-reduce.  Returns the note that goes
-    into the JSON line."""
+def verify_tap_exchange(model, args, ratings, grad_sync, dist, mode="auto", optimizer=None):
+    """Start-up self-check of the tap exchanges (distributed.TapExchange: "taps" = every rank rebuilds the whole averaged
+    gradient from the gathered taps; "owner" = rank r rebuilds the rows of its tokens and the slabs are all-gathered) on this
+    job's own ranks: one backward whose gradients are all-reduced densely, the same backward with the table gradient
+    exchanged; the table gradients must agree on every rank, otherwise the job falls back to the dense all-reduce.
+    mode "auto" additionally TIMES every exchange that passed, and the dense all-reduce, and keeps the fastest.
+    Returns the note that goes into the JSON line."""
+    import time as _t
+
     import torch.nn.functional as F
     from review_based_recommender_amd import functional as RF
     from review_based_recommender_amd.distributed import GradAllReduce
     table = model.word_embeddings.embedding.weight
+    tap = grad_sync.tap
     was_training = model.training
     model.eval()                                   # no dropout: both passes see the same forward
-    ok = True
-    tap_desc = tap_weights = None
+    candidates = {"auto": ["taps", "owner"], "taps": ["taps"], "owner": ["owner"]}[mode]
+    passed, errs, desc_w = [], {}, None
     try:
         RF.set_tap_sink(None)
         model.zero_grad(set_to_none=True)
         F.mse_loss(model(*args), ratings).backward()
         GradAllReduce(model)(model)
         ref = table.grad.clone()
-        RF.set_tap_sink(grad_sync.tap)
-        model.zero_grad(set_to_none=True)
-        F.mse_loss(model(*args), ratings).backward()
-        tap_desc, tap_weights = grad_sync.tap.desc, grad_sync.tap.weights
-        grad_sync(model)
-        err = float((table.grad - ref).abs().max())
-        ok = err <= 1e-7 + 2e-5 * float(ref.abs().max())
-    except Exception as e:                          # any refusal of the path: dense exchange
-        ok, err = False, repr(e)[:100]
-    flag = torch.tensor([1 if ok else 0], device=table.device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    ok = int(flag.item()) == 1
-    note = None
-    if ok and choose_by_time:
-        # which exchange is faster HERE depends on the links of this node: time both on the job's own ranks.  The tap
-        # path replaces the local table-gradient chain (~0.1 ms), so it is charged its time minus that.
-        import time as _t
-        tap = grad_sync.tap
-
+    except Exception as e:
+        ref, errs["dense reference"] = None, repr(e)[:100]
+    for m in candidates if ref is not None else []:
+        ok = True
+        try:
+            tap.owner, tap.optimizer = (m == "owner"), None          # no optimizer: the exchange leaves a dense .grad to compare
+            RF.set_tap_sink(tap)
+            model.zero_grad(set_to_none=True)
+            F.mse_loss(model(*args), ratings).backward()
+            desc_w = (tap.desc, tap.weights)
+            grad_sync(model)
+            if m == "owner":
+                tap.check()
+            err = float((table.grad - ref).abs().max())
+            ok = err <= 1e-7 + 2e-5 * float(ref.abs().max())
+            errs[m] = f"{err:.1e}"
+        except Exception as e:                      # any refusal of the path: not a candidate
+            ok, errs[m] = False, repr(e)[:100]
+        flag = torch.tensor([1 if ok else 0], device=table.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            passed.append(m)
+    chosen, timing = (passed[0] if passed else None), ""
+    if passed and mode == "auto":
+        # which exchange is faster HERE depends on the links of this node: time them on the job's own ranks.  The tap
+        # paths replace the local table-gradient chain (~0.1 ms), so they are charged their time minus that.
         def timed(fn, k=5):
             fn()
             dist.barrier(); torch.cuda.synchronize()
@@ -225,37 +237,43 @@ def verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=Fa
             torch.cuda.synchronize()
             return (_t.perf_counter() - t0) / k
 
-        def taps_once():
-            tap.desc, tap.weights, tap.calls = desc_w[0], desc_w[1], 1
-            for h in tap.start():
-                h.wait()
-            tap.finish()
+        def once(m):
+            def fn():
+                tap.owner = (m == "owner")
+                tap.desc, tap.weights, tap.calls = desc_w[0], desc_w[1], 1
+                for h in tap.start():
+                    h.wait()
+                tap.finish()
+            return fn
 
-        desc_w = (tap_desc, tap_weights)
         dummy = torch.empty_like(table)
         op = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
-        t_taps = timed(taps_once)
-        t_dense = timed(lambda: dist.all_reduce(dummy, op=op))
-        tt = torch.tensor([t_taps, t_dense], dtype=torch.float64, device=table.device)
+        ts = [timed(once(m)) for m in passed] + [timed(lambda: dist.all_reduce(dummy, op=op))]
+        tt = torch.tensor(ts, dtype=torch.float64, device=table.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_taps, t_dense = float(tt[0]), float(tt[1])
-        if t_taps - 1.0e-4 > t_dense:
-            ok = False
-            note = (f"RCCL all-reduce of every gradient, fp32 (timed at start-up: dense table all-reduce {t_dense * 1e3:.3f} ms vs "
-                    f"tap exchange + rebuild {t_taps * 1e3:.3f} ms)")
-        else:
-            timing = f"; timed at start-up: {t_taps * 1e3:.3f} ms vs {t_dense * 1e3:.3f} ms for the dense all-reduce"
-    else:
-        timing = ""
+        ts = [float(x) for x in tt]
+        cost = {m: t - 1.0e-4 for m, t in zip(passed, ts)}
+        cost["dense"] = ts[-1]
+        chosen = min(cost, key=cost.get)
+        timing = "; timed at start-up: " + ", ".join(f"{m} {t * 1e3:.3f} ms" for m, t in zip(passed + ["dense all-reduce"], ts))
+        if chosen == "dense":
+            chosen = None
     model.zero_grad(set_to_none=True)
     model.train(was_training)
-    if ok:
-        return (f"taps of the word-table gradient all-gathered (fp32, {grad_sync.tap.n * 8 / 1e6:.1f} MB per rank instead of a "
-                f"{table.numel() * 4 / 1e6:.0f} MB all-reduce), the other gradients all-reduced; checked against the dense "
-                f"all-reduce at start-up (max |diff| {err:.1e}){timing}")
+    if chosen is not None:
+        tap.owner = chosen == "owner"
+        tap.optimizer = optimizer if tap.owner else None
+        RF.set_tap_sink(tap)
+        what = ("taps of the word-table gradient all-gathered" if chosen == "taps" else
+                "taps of the word-table gradient all-gathered, rank r rebuilds the rows of the tokens t % N == r, the slabs are "
+                "all-gathered and the optimizer reads them in row form")
+        return (f"{what} (fp32, {tap.n * 8 / 1e6:.1f} MB of taps per rank instead of a {table.numel() * 4 / 1e6:.0f} MB all-reduce), "
+                f"the other gradients all-reduced; checked against the dense all-reduce at start-up (max |diff| {errs[chosen]}){timing}")
     RF.set_tap_sink(None)
     grad_sync.tap = None
-    return note or f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {err})"
+    if passed:
+        return f"RCCL all-reduce of every gradient, fp32{timing}"
+    return f"RCCL all-reduce of every gradient, fp32 (tap exchange failed its start-up check: {errs})"
 
 
 def time_gemm_launches(model, args, reps=50):
@@ -398,9 +416,10 @@ def main():
                     help="arithmetic of the token-product GEMM (default bf16x3: exact three-plane split, f32-class accuracy)")
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="wire format of the word-table gradient all-reduce (N > 1); fp32 is exact")
-    ap.add_argument("--exchange", choices=["auto", "taps", "dense"], default="auto",
-                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank, rebuilt on every rank) or all-reduce "
-                         "the dense 60 MB gradient; auto times both on the job's own ranks at start-up and keeps the faster one")
+    ap.add_argument("--exchange", choices=["auto", "taps", "owner", "dense"], default="auto",
+                    help="N > 1, word-table gradient: all-gather its taps (4.3 MB per rank) and rebuild the gradient on every rank "
+                         "(taps) or by owner (owner: rank r builds the rows of tokens t %% N == r, slabs all-gathered), or all-reduce "
+                         "the dense 60 MB gradient; auto times all three on the job's own ranks at start-up and keeps the fastest")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -450,11 +469,12 @@ def main():
     batches = [batch_on(cfg, sd, device) for sd in seeds]
     args, ratings = batches[0]
     if world > 1:
-        use_taps = a.comm_dtype == "fp32" and a.exchange in ("taps", "auto")
+        use_taps = a.comm_dtype == "fp32" and a.exchange in ("taps", "owner", "auto")
         grad_sync = GradAllReduce(model, comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else None,
                                   tap_table=model.word_embeddings.embedding.weight if use_taps else None)
         if use_taps:
-            exchange_note = verify_tap_exchange(model, args, ratings, grad_sync, dist, choose_by_time=(a.exchange == "auto"))
+            exchange_note = verify_tap_exchange(model, args, ratings, grad_sync, dist, mode=a.exchange,
+                                                optimizer=opt if not a.torch_optim else None)
 
     def barrier():
         if world > 1:

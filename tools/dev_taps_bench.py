@@ -1,5 +1,7 @@
-"""Dev: cost of rebuilding the averaged table gradient from n_sets ranks' taps (rbr_textcnn_dtable_from_taps) on one GPU,
-cfg2 shape, taps taken from n_sets different synthetic batches.  python tools/dev_taps_bench.py [n_sets ...]"""
+"""Dev: cost of rebuilding the averaged table gradient from n_sets ranks' taps on one GPU, cfg2 shape, taps taken from n_sets
+different synthetic batches: the replicated rebuild (rbr_textcnn_dtable_from_taps) and the compute legs of the owner-partitioned
+one (rbr_textcnn_dtable_from_taps_owner for the busiest rank, the slab's sum of squares, and the optimizer's row-form pass over
+the gathered slabs against its dense pass).  python tools/dev_taps_bench.py [n_sets ...]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -44,3 +46,30 @@ for n_sets in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]:
     print(f"n_sets={n_sets}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per rebuild (events: median {per[10]:.1f}, max {per[-1]:.1f}; "
           f"host call median {sorted(host)[10] * 1e6:.0f}, max {max(host) * 1e6:.0f} us); union tokens {int((tok >= 0).sum())} taps, "
           f"{int(torch.unique(tok[tok >= 0]).numel())} distinct; payload {n * 8 / 1e6:.1f} MB per rank", flush=True)
+
+    # ---- owner partition: every rank's share of the taps, and the rebuild of the busiest one
+    own_cnt = [int(((tok >= 0) & (tok % n_sets == r)).sum()) for r in range(n_sets)]
+    worst = max(range(n_sets), key=lambda r: own_cnt[r])
+    v_own = L_.rbr_textcnn_taps_owner_rows(C.byref(d), n_sets)
+    slab = torch.empty(v_own, D, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def owner_once():
+        assert L_.rbr_textcnn_dtable_from_taps_owner(C.byref(d), n_sets, worst, tok.data_ptr(), val.data_ptr(), W, wsb.data_ptr(),
+                                                     slab.data_ptr(), flag.data_ptr(), st) == 0
+    for _ in range(3):
+        owner_once()
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    for _ in range(20):
+        owner_once()
+    e1.record()
+    for _ in range(20):
+        sq = torch.linalg.vector_norm(slab).square()
+    e2.record()
+    torch.cuda.synchronize()
+    cap = min(n_sets * n, 2 * ((n_sets * n + n_sets - 1) // n_sets) + 4096)
+    print(f"  owner: shares of the {int((tok >= 0).sum())} taps by rank {own_cnt} (sort sized for {cap}; overflow flag {int(flag.item())}); "
+          f"rebuild of rank {worst}'s {v_own} rows {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, slab norm {e1.elapsed_time(e2) / 20 * 1e3:.1f} us; "
+          f"slab all-gather payload {(v_own + 1) * D * 4 / 1e6:.2f} MB per rank", flush=True)
