@@ -88,3 +88,56 @@ def test_hip_clip_adam_with_more_than_64_tensors():
         assert abs(float(na) - float(nb)) <= 1e-5 * float(nb)
     for pa, pb in zip(ps_a, ps_b):
         assert float((pa - pb).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("max_norm", [None, 0.5])
+@pytest.mark.parametrize("D", [300, 20])
+def test_exchanged_rows_in_owner_layout_match_the_dense_gradient(max_norm, D):
+    """HipClipAdam.put_exchanged_rows: the averaged table gradient in the layout the owner-partitioned exchange leaves it in
+    (distributed.TapExchange: N slabs of ceil(V/N) + 1 rows, token t at [t % N][t // N], the extra row of slab r carrying the
+    sum of squares of that slab) read through the static token -> row map, against the same gradient as a dense .grad:
+    the same parameters and Adam state bit for bit without clipping (D = 300: the wave-per-row path of the kernel, D = 20:
+    its generic path), to rounding with it (the norm is summed from N partials instead of over the dense tensor)."""
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.train_step import HipClipAdam
+    dev = torch.device("cuda", 0)
+    V, N = 5003, 3
+    gen = torch.Generator().manual_seed(5)
+    table0 = torch.randn(V, D, generator=gen).to(dev)
+    other0 = torch.randn(130, generator=gen).to(dev)
+    v_own = (V + N - 1) // N
+    t = torch.arange(V, device=dev)
+    row_map = ((t % N) * (v_own + 1) + t // N).to(torch.int32)
+    models = []
+    for _ in range(2):
+        ps = [table0.clone().requires_grad_(True), other0.clone().requires_grad_(True)]
+        models.append((ps, HipClipAdam(ps, lr=2e-3, row_grads=False)))
+    for step in range(3):
+        g = torch.randn(V, D, generator=gen).to(dev) * 0.1
+        g[torch.rand(V, generator=gen).to(dev) < 0.3] = 0
+        g_other = torch.randn(130, generator=gen).to(dev)
+        (pd, od), (pr, orr) = models
+        pd[0].grad, pd[1].grad = g.clone(), g_other.clone()
+        slabs = torch.zeros(N, v_own + 1, D, device=dev)
+        for r in range(N):
+            mine = g[r::N]
+            slabs[r, :mine.shape[0]] = mine
+            slabs[r, v_own, 0] = torch.linalg.vector_norm(slabs[r, :v_own]).square()
+        sq = slabs[:, v_own, 0].contiguous()
+        rg = RF.RowGradient(pr[0], slabs.view(-1, D), sq, row_map.data_ptr(), (row_map, slabs))
+        assert orr.put_exchanged_rows(pr[0], rg)
+        assert pr[0].grad is None
+        pr[1].grad = g_other.clone()
+        nd = od.clip_and_step(max_norm)
+        nr = orr.clip_and_step(max_norm)
+        torch.cuda.synchronize()
+        assert abs(float(nd) - float(nr)) <= 1e-5 * float(nd)
+        for a, b in zip(pd, pr):
+            if max_norm is None:
+                assert torch.equal(a, b)
+                assert torch.equal(od.state[a]["exp_avg"], orr.state[b]["exp_avg"])
+                assert torch.equal(od.state[a]["exp_avg_sq"], orr.state[b]["exp_avg_sq"])
+            else:
+                assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+        orr.zero_grad(); od.zero_grad()
+    assert float(torch.equal(rg.to_dense(), g) if max_norm is None else True)
