@@ -61,6 +61,14 @@ typedef struct rbr_textcnn_desc {
  * output, so a 32-token slab that is all padding (halo included) and FOLLOWS another such slab cannot change max / first argmax
  * and is not computed.  Exact; valid-padded or width-1 banks only (the flag is ignored otherwise). */
 #define RBR_CONV_PAD_RUNS 1
+/* RBR_CONV_GATE_SPLIT(k), 1 <= k < n_widths (token-product formulation only): the banks [0, k) and [k, n_widths) have a gate of
+ * their own -- `gate` (and `dgate`) are then [2][n_docs][L], plane 0 for the first group.  D-ATT's two gated convs of a tower
+ * over the same tokens (dual_att/layers.py:43-53 and 81-89: the 1-wide local conv with the per-token gate, the 2/3/4-wide
+ * global convs with the per-document gate; a 1-wide 'same' conv IS a valid conv) become ONE conv call: one token list, one
+ * product-table GEMM, one gather launch, one G and one sparse product in the backward.  Entry points of the dense formulation
+ * return RBR_ERR_UNSUPPORTED for a split gate. */
+#define RBR_CONV_GATE_SPLIT(k) (((k) & 0xf) << 8)
+#define RBR_CONV_GATE_SPLIT_OF(flags) (((flags) >> 8) & 0xf)
 
 int rbr_version(void);
 const char* rbr_last_error(void);

@@ -64,6 +64,11 @@ class RowGrad(C.Structure):       # rbr_row_grad
 G_BUILD, G_PRODUCT, G_ACCUMULATE, G_ROWS, G_ZEROED = 1, 2, 4, 8, 16      # RBR_G_* of rbr_hip.h
 
 
+def conv_gate_split(k: int) -> int:
+    """RBR_CONV_GATE_SPLIT(k) of rbr_hip.h."""
+    return (int(k) & 0xF) << 8
+
+
 class AttnGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dW_rv", "dW_id", "dh", "db1", "db2", "debd")]
 

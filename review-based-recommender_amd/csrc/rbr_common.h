@@ -49,6 +49,7 @@ struct ConvPlan {
     unsigned char slot_kz[kMaxSlots];  // kernel width (0 = padding slot)
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
+    int gate_split;     // RBR_CONV_GATE_SPLIT: first bank of the second gate plane (0: one gate for every bank)
     int pad_runs;       // RBR_CONV_PAD_RUNS in force (un-masked, valid-padded or width-1 conv): token id of the padding, else -1
 };
 

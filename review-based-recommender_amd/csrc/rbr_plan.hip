@@ -37,6 +37,10 @@ static bool validate(const rbr_textcnn_desc* d) {
     }
     if (d->pad_mode != RBR_PAD_SAME && d->pad_mode != RBR_PAD_VALID) { set_error("pad_mode %d", d->pad_mode); return false; }
     if (d->act != RBR_ACT_RELU && d->act != RBR_ACT_TANH) { set_error("act %d", d->act); return false; }
+    if (RBR_CONV_GATE_SPLIT_OF(d->flags) >= d->n_widths) {
+        set_error("RBR_CONV_GATE_SPLIT(%d) with %d banks", RBR_CONV_GATE_SPLIT_OF(d->flags), d->n_widths);
+        return false;
+    }
     return true;
 }
 
@@ -77,6 +81,7 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans, int tiles_per_group)
         p.group = g;
         p.ntiles = std::min(per_group, tiles_total - p.tile_base);
         p.pad_mode = d->pad_mode; p.act = d->act;
+        p.gate_split = RBR_CONV_GATE_SPLIT_OF(d->flags);
         p.pad_runs = ((d->flags & RBR_CONV_PAD_RUNS) && d->padding_idx >= 0 && (d->pad_mode == RBR_PAD_VALID || KF == 1)) ? d->padding_idx : -1;
         p.n_widths = d->n_widths;
         for (int w = 0; w < d->n_widths; ++w) { p.kz[w] = d->kz[w]; p.ch[w] = d->ch[w]; p.ch_off[w] = ch_off[w]; }

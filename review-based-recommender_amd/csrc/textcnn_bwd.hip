@@ -37,6 +37,7 @@ struct BwdArgs {
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS];
     int rank_off[RBR_MAX_WIDTHS];   // first slot (kz-sorted channel order) of bank w in the packed image
     int NCH, DPC;                   // document chunks of the dW kernels and documents per chunk
+    int gate_split;                 // RBR_CONV_GATE_SPLIT: banks >= this read plane 1 of `gate` (0: one plane)
     int doc_centric;                // 1: dw_doc_kernel (short documents), 0: dw_partial_kernel
     int dev_flags;                  // tuning aid (RBR_DEV_DX_ABLATE): 1 = no atomics, 2 = no accumulation phase
 };
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
     __shared__ float s_g[kDocsPerBatch];
     const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int w = bank_of(A, c);
+    const long gplane = (A.gate_split > 0 && w >= A.gate_split) ? (long)A.n_docs * A.L : 0;      // the bank's gate plane
     const int kz = A.kz[w];
     const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
     const int doc_begin = chunk * A.DPC;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
                     const long tok = (long)(b0 + dl) * L + p;
                     if (mask == nullptr || mask[tok]) {
                         row = ids[tok] * (long)D;
-                        sc = (gate != nullptr) ? g * gate[tok] : g;
+                        sc = (gate != nullptr) ? g * gate[gplane + tok] : g;
                     }
                 }
                 s_row[e] = row;
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
     __shared__ __attribute__((aligned(16))) float s_red[512];      // [kz][D], used when dpar > 1, i.e. kz * D/4 <= 128
     const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int w = bank_of(A, c);
+    const long gplane = (A.gate_split > 0 && w >= A.gate_split) ? (long)A.n_docs * A.L : 0;      // the bank's gate plane
     const int kz = A.kz[w];
     const int padl = (A.pad_mode == RBR_PAD_SAME) ? (kz - 1) / 2 : 0;
     const int doc_begin = chunk * A.DPC;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const
                 const long tok = (long)(b0 + dl) * L + p;
                 if (mask == nullptr || mask[tok]) {
                     row = ids[tok] * (long)D;
-                    sc = (gate != nullptr) ? g * gate[tok] : g;
+                    sc = (gate != nullptr) ? g * gate[gplane + tok] : g;
                 }
             }
             s_row[e] = row;
@@ -656,7 +659,9 @@ static int fill_args(const rbr_textcnn_desc* d, BwdArgs& A) {
             if (d->kz[v] < d->kz[w] || (d->kz[v] == d->kz[w] && v < w)) r += d->ch[v];
         A.rank_off[w] = r;
     }
-    A.doc_centric = (d->L <= kDocMaxL && p.C * p.KF <= kDocItems && d->n_docs >= 64) ? 1 : 0;
+    A.gate_split = RBR_CONV_GATE_SPLIT_OF(d->flags);
+    // (the document-centric kernel stages gate * row once for all channels: one gate plane only)
+    A.doc_centric = (d->L <= kDocMaxL && p.C * p.KF <= kDocItems && d->n_docs >= 64 && A.gate_split == 0) ? 1 : 0;
     if (A.doc_centric) {
         A.NCH = std::min(128, (d->n_docs + 15) / 16);       // many small chunks: one workgroup per (slice, chunk)
     } else {
@@ -729,6 +734,7 @@ extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids,
 extern "C" int rbr_textcnn_bwd_dtable(const rbr_textcnn_desc* d, const int64_t* ids, const uint8_t* mask, const float* gate,
                                       const float* table, const float* packed, const float* feat, const int32_t* argmax,
                                       const float* d_feat, float* dtable, float* dgate, void* stream) {
+    if (d && gate != nullptr && RBR_CONV_GATE_SPLIT_OF(d->flags)) { set_error("rbr_textcnn_bwd_dtable: RBR_CONV_GATE_SPLIT needs the token-product formulation"); return RBR_ERR_UNSUPPORTED; }
     BwdArgs A;
     if (int e = fill_args(d, A)) return e;
     if (!ids || !table || !packed || !feat || !argmax || !d_feat) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }

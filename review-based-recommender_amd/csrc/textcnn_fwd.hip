@@ -827,6 +827,7 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
         const int r = run_token_product(d, ids64, mask, gate, table, W, pval, pidx, ws, st);
         if (r != 0) return r == 1 ? 0 : r;
     }
+    if (gate != nullptr && plans[0].gate_split > 0) { set_error("rbr_textcnn_conv_fwd: RBR_CONV_GATE_SPLIT needs the token-product formulation"); return RBR_ERR_UNSUPPORTED; }
     if (int e = scan_tiles(plans[0], mask, sched, st)) return e;
     return run_conv_groups(plans, ng, ids64, mask, gate, table, packed, pval, pidx, sched, st);
 }

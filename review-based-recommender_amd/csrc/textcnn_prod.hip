@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
     const unsigned short* T16 = static_cast<const unsigned short*>(Tv);
     __shared__ int s_row[kWavesPerWG][kTile + kMaxKF];
     __shared__ float s_gate[kWavesPerWG][kTile + kMaxKF];
+    __shared__ float s_gate_b[kWavesPerWG][kTile + kMaxKF];       // RBR_CONV_GATE_SPLIT: the gate of the banks >= P.gate_split
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_active = sched[2 * (long)P.total_wt];
     const int slot_in_list = blockIdx.x * kWavesPerWG + wave;
@@ -195,17 +196,21 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
     for (int r = lane; r < XR; r += 64) {
         const int p = l0 - P.P + r;
         int row = A.zrow;
-        float gv = 1.f;
+        float gv = 1.f, gvb = 1.f;
         if (p >= 0 && p < L) {
             const long tok = (long)doc * L + p;
             if (mask == nullptr || mask[tok]) {
                 const int rr = row_of_token[ids[tok]];
                 row = rr >= 0 ? rr : A.zrow;
-                if (gate != nullptr) gv = gate[tok];
+                if (gate != nullptr) {
+                    gv = gate[tok];
+                    if (P.gate_split > 0) gvb = gate[(long)P.n_docs * L + tok];
+                }
             }
         }
         s_row[wave][r] = row;
         s_gate[wave][r] = gv;
+        s_gate_b[wave][r] = gvb;
     }
     __builtin_amdgcn_wave_barrier();
     const int ps = lane >> 4, ql = lane & 15;
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
         const int off = (P.pad_mode == RBR_PAD_SAME) ? (P.KF - kz) / 2 : 0;      // frame tap of the bank's tap 0
         const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;          // pool length of this bank
         const int nquads = (ch + 3) >> 2;
+        const float* sg = (P.gate_split > 0 && w >= P.gate_split) ? s_gate_b[wave] : s_gate[wave];     // wave-uniform
         for (int qb = 0; qb < nquads; qb += 16) {
             const int q = qb + ql;
             const bool valid = q < nquads;
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
                             } else {
                                 v = *reinterpret_cast<const f32x4u*>(tcol + (long)s_row[wave][r] * A.pitch + j * ch);
                             }
-                            const float gv = s_gate[wave][r];
+                            const float gv = sg[r];
                             y[u].x = fmaf(v.x, gv, y[u].x); y[u].y = fmaf(v.y, gv, y[u].y);
                             y[u].z = fmaf(v.z, gv, y[u].z); y[u].w = fmaf(v.w, gv, y[u].w);
                         }
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, cons
 struct ProdBwdArgs {
     int n_docs, L, C, KF, KG, D, cap, padding_idx, pad_mode, act;
     int t_pitch;                    // floats per row of the forward's product table T (gated convs: d(gate) reads it)
+    int gate_split;                 // RBR_CONV_GATE_SPLIT: banks >= this read / write plane 1 of gate / dgate (0: one plane)
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
 };
@@ -327,14 +334,15 @@ __global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const
     const int row = row_of_token[t];
     if (row < 0) return;
     const int col = A.poff[w] + j * A.ch[w] + (c - A.ch_off[w]);
+    const long gtok = (A.gate_split > 0 && w >= A.gate_split) ? (long)A.n_docs * A.L + tok : tok;      // the bank's gate plane
     if (dgate != nullptr) {
         const long at = (long)row * A.t_pitch + col;
         const float tv = t_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(T)[at] << 16) : T[at];
-        atomicAdd(dgate + tok, g * tv);
+        atomicAdd(dgate + gtok, g * tv);
     }
     if (G == nullptr) return;
     // the pad token's row stays in G (the weight gradient needs it); its TABLE row gets no gradient: g_times_w zeroes it
-    atomicAdd(G + (long)row * A.KG + col, (gate != nullptr) ? g * gate[tok] : g);
+    atomicAdd(G + (long)row * A.KG + col, (gate != nullptr) ? g * gate[gtok] : g);
 }
 
 constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of the table row
@@ -1213,6 +1221,7 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     ProdBwdArgs A{};
     A.n_docs = d->n_docs; A.L = d->L; A.C = plans[0].C; A.KF = plans[0].KF; A.KG = B.KG; A.D = d->D; A.cap = Lo.cap;
     A.padding_idx = d->padding_idx; A.pad_mode = d->pad_mode; A.act = d->act; A.n_widths = d->n_widths;
+    A.gate_split = RBR_CONV_GATE_SPLIT_OF(d->flags);
     {
         ConvPlan pp[kMaxGroups];
         if (!build_plans(&Lo.dp, pp, kProdGroupTiles)) return RBR_ERR_BAD_ARG;
@@ -1229,7 +1238,7 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
         if ((want_g && !(phases & kGZeroed)) || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
             hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4,
                                (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate,
-                               dgate != nullptr ? (long)d->n_docs * d->L : 0L);
+                               dgate != nullptr ? (long)d->n_docs * d->L * (RBR_CONV_GATE_SPLIT_OF(d->flags) ? 2 : 1) : 0L);
             RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;

@@ -573,8 +573,9 @@ def _join(event) -> None:
 
 
 def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor], weights: Sequence[torch.Tensor],
-            biases: Sequence[torch.Tensor], *, gate: Optional[torch.Tensor] = None, pad_mode: int = PAD_SAME,
-            act: int = ACT_RELU, padding_idx: Optional[int] = 0, return_argmax: bool = False, pad_runs: bool = False):
+            biases: Sequence[torch.Tensor], *, gate=None, pad_mode: int = PAD_SAME,
+            act: int = ACT_RELU, padding_idx: Optional[int] = 0, return_argmax: bool = False, pad_runs: bool = False,
+            gate_split: int = 0):
     """Fused WordEmbedding -> masked_tensor -> MyConv1d -> act -> MaxPool1d(seq_len).
 
     table [V,D] f32; ids [n_docs,L] int64; mask [n_docs,L] bool or None; weights[w] [C_w,D,kz_w];
@@ -584,8 +585,25 @@ def textcnn(table: torch.Tensor, ids: torch.Tensor, mask: Optional[torch.Tensor]
     kernel_sizes = tuple(int(w.shape[2]) for w in weights)
     flags = _lib.CONV_PAD_RUNS if (pad_runs and mask is None and padding_idx is not None
                                    and os.environ.get("RBR_PAD_RUNS", "1") != "0") else 0
+    if gate_split:
+        # two gates (RBR_CONV_GATE_SPLIT): banks [0, gate_split) under gate[0], the rest under gate[1]; token-product path only
+        if not (isinstance(gate, (tuple, list)) and len(gate) == 2 and 0 < gate_split < len(weights)):
+            raise RuntimeError("gate_split needs gate=(gate_a, gate_b) and 0 < gate_split < number of banks")
+        gate = torch.stack([gate[0], gate[1]])          # [2, n_docs, L]; its backward hands each gate its plane
+        flags |= _lib.conv_gate_split(gate_split)
     feat, argmax = _TextCNN.apply(table, gate, ids, mask, kernel_sizes, pad_mode, act, padding_idx, flags, *weights, *biases)
     return (feat, argmax) if return_argmax else feat
+
+
+def textcnn_product_applies(table: torch.Tensor, ids: torch.Tensor, weights: Sequence[torch.Tensor], pad_mode: int, act: int,
+                            padding_idx: Optional[int]) -> bool:
+    """True when textcnn() over these shapes runs the token-product formulation, forward AND table-gradient backward (the only
+    one that takes a split gate)."""
+    V, D = table.shape
+    desc = _lib.make_desc(ids.shape[0], ids.shape[1], D, V, [int(w.shape[2]) for w in weights], [int(w.shape[0]) for w in weights],
+                          pad_mode, act, padding_idx, 0)
+    L_ = _lib.lib()
+    return bool(table.is_cuda and L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc)) > 0 and L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) > 0)
 
 
 _HEAD_NAMES = ("Wu", "bu", "Eu", "Wi", "bi", "Ei", "h", "g", "ub", "ib")

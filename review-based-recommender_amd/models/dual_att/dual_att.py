@@ -3,6 +3,8 @@ state_dict keys (models/dual_att/dual_att.py:19-61), running on the HIP kernels 
 
 The reference file's legacy `__main__` block (dual_att.py:63-150; undefined ReviewData / CNNDLGA) and its
 unused nltk / pandas imports are not part of the model and have no counterpart here."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -31,6 +33,21 @@ class DualAtt(nn.Module):
         """`tabs`: four aliases of the word table (RF.table_fanout), one per table-consuming op of the tower."""
         pad = self.word_embeddings.padding_idx
         rows = RF.datt_token_rows(docs, tabs[0].shape[0])      # distinct-token maps, once per tower: both gates work on them
+        convs = [local.conv[0], glob.conv1[0], glob.conv2[0], glob.conv3[0]]
+        weights = [c.weight for c in convs]
+        if (local.conv[0].kernel_size[0] == 1 and os.environ.get("RBR_DATT_MERGED", "1") != "0"
+                and RF.textcnn_product_applies(tabs[1], docs, weights, RF.PAD_VALID, RF.ACT_TANH, pad)):
+            # The tower's two gated convs read the same tokens: as ONE conv call of four banks -- the 1-wide local conv ('same'
+            # = 'valid' at width 1) under the local gate, the 2/3/4-wide global convs under the global gate
+            # (RBR_CONV_GATE_SPLIT) -- they share the token list, the product-table GEMM, the gather launch, and in the
+            # backward G and the sparse product.  Same results (layers.py:43-53,81-89); channels come back local first.
+            gate_l = RF.datt_gate(tabs[0], local.attn[0].weight, local.attn[0].bias, docs, is_global=False, padding_idx=pad,
+                                  rows=rows)
+            gate_g = RF.datt_gate(tabs[2], glob.attn[0].weight, glob.attn[0].bias, docs, is_global=True, padding_idx=pad,
+                                  rows=rows)
+            feat = RF.textcnn(tabs[1], docs, None, weights, [c.bias for c in convs], gate=(gate_l, gate_g), gate_split=1,
+                              pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=pad, pad_runs=local.window_size <= 17)
+            return feat, None                                   # [bz, l_out + 3 * g_out]: cat((local, global), 1) already
         return local.encode(tabs[0:2], docs, pad, rows=rows), glob.encode(tabs[2:4], docs, pad, rows=rows)
 
     def _fc(self, feat):
@@ -56,5 +73,12 @@ class DualAtt(nn.Module):
         # the fc is ONE module shared by both towers (dual_att.py:31,51,57): both sides go through its two GEMMs (and their
         # backward) as a single 2*bz batch, user rows first
         # cat((local, global), 1) per tower (dual_att.py:50,56), user rows over item rows: one launch (RF.block_cat)
-        feats = self._fc(RF.block_cat(u_loc, u_glo, i_loc, i_glo))          # [2*bz, hidden_2], user rows first
+        if u_glo is None and i_glo is None:
+            feats = self._fc(RF.stack_rows(u_loc, i_loc))                   # the merged conv's rows are the towers' cat already
+        else:
+            if u_glo is None:
+                u_loc, u_glo = u_loc[:, :self.u_local_atten.out_size], u_loc[:, self.u_local_atten.out_size:]
+            if i_glo is None:
+                i_loc, i_glo = i_loc[:, :self.i_local_atten.out_size], i_loc[:, self.i_local_atten.out_size:]
+            feats = self._fc(RF.block_cat(u_loc, u_glo, i_loc, i_glo))      # [2*bz, hidden_2], user rows first
         return RF.pair_dot(feats).view(-1)                                  # sum(u_feat * i_feat, 1)  (dual_att.py:58)

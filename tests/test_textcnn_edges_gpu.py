@@ -205,3 +205,74 @@ def test_padding_runs_are_encoded_once_and_exactly(kind):
         assert torch.equal(outs[0][1], outs[1][1])
     finally:
         _lib.lib().rbr_set_conv_mode(0)
+
+
+@pytest.mark.parametrize("runs", [False, True])
+def test_split_gate_conv_equals_the_two_gated_convs(runs):
+    """RBR_CONV_GATE_SPLIT: D-ATT's two gated convs of a tower (1-wide local conv under the per-token gate, 2/3/4-wide global convs
+    under the per-document gate; dual_att/layers.py:43-53,81-89) as ONE four-bank conv call.  Features and first argmax are the
+    bits of the two separate calls; every gradient (table, both gates, weights, biases) agrees to summation order."""
+    from review_based_recommender_amd import _lib, functional as RF
+    _lib.lib().rbr_set_conv_mode(2)
+    try:
+        g = torch.Generator().manual_seed(21)
+        n_docs, L, E, V = 48, 160, 100, 900
+        ids = torch.randint(1, V, (n_docs, L), generator=g)
+        lens = torch.randint(0, L + 1, (n_docs,), generator=g)
+        lens[0], lens[1], lens[2] = 0, L, 3
+        ids[torch.arange(L)[None, :] >= lens[:, None]] = 0
+        ids = ids.to(DEV)
+        wl = (torch.randn(1, E, 5, generator=g) * 0.1).to(DEV)
+        wgl = (torch.randn(1, E, L, generator=g) * 0.02).to(DEV)
+
+        def leaves():
+            gg = torch.Generator().manual_seed(22)
+            table = torch.randn(V, E, generator=gg).to(DEV).requires_grad_(True)
+            ws = [(torch.randn(56, E, 1, generator=gg) * 0.05).to(DEV).requires_grad_(True)] + \
+                 [(torch.randn(24, E, k, generator=gg) * 0.05).to(DEV).requires_grad_(True) for k in (2, 3, 4)]
+            bs = [(torch.randn(w.shape[0], generator=gg) * 0.1).to(DEV).requires_grad_(True) for w in ws]
+            return table, ws, bs
+
+        def gates(table):
+            ga = RF.datt_gate(table, wl, torch.zeros(1, device=DEV), ids, is_global=False, padding_idx=0)
+            gb = RF.datt_gate(table, wgl, torch.zeros(1, device=DEV), ids, is_global=True, padding_idx=0)
+            return ga, gb
+
+        d_out = torch.randn(n_docs, 56 + 72, generator=g).to(DEV)
+        # merged
+        t1, ws1, bs1 = leaves()
+        ga, gb = gates(t1.detach())
+        ga, gb = ga.detach().requires_grad_(True), gb.detach().requires_grad_(True)
+        f1, am1 = RF.textcnn(t1, ids, None, ws1, bs1, gate=(ga, gb), gate_split=1, pad_mode=RF.PAD_VALID, act=RF.ACT_TANH,
+                             padding_idx=0, return_argmax=True, pad_runs=runs)
+        (f1 * d_out).sum().backward()
+        # separate
+        t2, ws2, bs2 = leaves()
+        ha, hb = ga.detach().clone().requires_grad_(True), gb.detach().clone().requires_grad_(True)
+        fa, ama = RF.textcnn(t2, ids, None, ws2[:1], bs2[:1], gate=ha, pad_mode=RF.PAD_SAME, act=RF.ACT_TANH, padding_idx=0,
+                             return_argmax=True, pad_runs=runs)
+        fb, amb = RF.textcnn(t2, ids, None, ws2[1:], bs2[1:], gate=hb, pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=0,
+                             return_argmax=True, pad_runs=runs)
+        f2 = torch.cat([fa, fb], 1)
+        (f2 * d_out).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(f1, f2)
+        assert torch.equal(am1, torch.cat([ama, amb], 1))
+
+        def close(a, b, what):
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (what, float((a - b).abs().max()), scale)
+        close(t1.grad, t2.grad, "table")
+        close(ga.grad, ha.grad, "local gate")
+        close(gb.grad, hb.grad, "global gate")
+        for k in range(4):
+            close(ws1[k].grad, ws2[k].grad, f"W{k}")
+            close(bs1[k].grad, bs2[k].grad, f"b{k}")
+        # the dense formulation refuses a split gate instead of ignoring it
+        _lib.lib().rbr_set_conv_mode(1)
+        with pytest.raises(RuntimeError):
+            with torch.no_grad():
+                RF.textcnn(t1, ids, None, ws1, bs1, gate=(ga.detach(), gb.detach()), gate_split=1, pad_mode=RF.PAD_VALID,
+                           act=RF.ACT_TANH, padding_idx=0)
+    finally:
+        _lib.lib().rbr_set_conv_mode(0)
