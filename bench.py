@@ -55,7 +55,7 @@ WORKLOAD = "cfg2"
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0 # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBPS = 8000.0         # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured with a float4 copy)
-MIN_TIMED_S = 0.5
+MIN_TIMED_S = float(os.environ.get("RBR_BENCH_MIN_TIMED_S", "0.5"))
 
 
 def conv_fwd_flops(cfg) -> float:
@@ -535,8 +535,12 @@ def main():
             if len(out) >= target:
                 return out
 
-    headline = timed_blocks(make_runner(batches))
+    headline = timed_blocks(make_runner(batches), max_repeats=2000)
     med, best = statistics.median(headline), min(headline)
+    if os.environ.get("RBR_BENCH_DRIFT") and rank == 0:
+        q = max(1, len(headline) // 8)
+        print("drift (ms/step, eighths of the timed region):",
+              [round(1e3 * statistics.median(headline[k * q:(k + 1) * q]) / a.steps, 4) for k in range(8)], file=sys.stderr, flush=True)
 
     variants = {}
     if not a.no_variants:
