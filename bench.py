@@ -535,6 +535,23 @@ def main():
             if len(out) >= target:
                 return out
 
+    # Every timed measurement starts from the SAME model: the step gets cheaper as the repeated synthetic batches are overfitted
+    # (dead ReLUs carry no taps), so a measurement taken after another one would be flattered.
+    with torch.no_grad():
+        init_params = [p.detach().clone() for p in model.parameters()]
+
+    def reset_model():
+        """Parameters back to their initial values, Adam state to zero (in place: recorded graphs keep their addresses)."""
+        with torch.no_grad():
+            for p, v in zip(model.parameters(), init_params):
+                p.copy_(v)
+            for st_ in opt.state.values():
+                for v in st_.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.synchronize()
+
+    reset_model()
     headline = timed_blocks(make_runner(batches), max_repeats=2000)
     med, best = statistics.median(headline), min(headline)
     if os.environ.get("RBR_BENCH_DRIFT") and rank == 0:
@@ -544,11 +561,13 @@ def main():
 
     variants = {}
     if not a.no_variants:
+        reset_model()
         one = timed_blocks(make_runner(batches[:1]), min_s=0.25)
         variants["single_batch_replay"] = {"ms_per_step": round(1e3 * statistics.median(one) / a.steps, 4),
                                            "ms_per_step_min": round(1e3 * min(one) / a.steps, 4), "repeats": len(one),
                                            "note": "one batch resident in the step's input block, no per-step copy (round 1's line)"}
         if use_graph and stepper.slots > 1:
+            reset_model()
             cp = timed_blocks(make_runner(batches, copy_per_step=True), min_s=0.25)
             variants["copy_per_step"] = {"ms_per_step": round(1e3 * statistics.median(cp) / a.steps, 4),
                                          "ms_per_step_min": round(1e3 * min(cp) / a.steps, 4), "repeats": len(cp),
@@ -556,6 +575,7 @@ def main():
                                                  "input block inside the timed region (the headline of rounds 2 and 3)"}
         for kind in ("uniform_ids", "all_distinct"):
             vb = [batch_on(cfg, sd, device, ids=kind.replace("_ids", "")) for sd in seeds]
+            reset_model()
             blk = timed_blocks(make_runner(vb), min_s=0.25)
             ids_all = torch.cat([vb[0][0][0], vb[0][0][1]])
             msk = torch.cat([vb[0][0][2], vb[0][0][3]])
@@ -625,6 +645,7 @@ def main():
         sync5 = GradAllReduce(model, comm_dtype=torch.bfloat16)
         try:
             st5 = GraphedTrainStep(model, opt, args, ratings, grad_sync=sync5, slots=stepper.slots) if use_graph else None
+            reset_model()
             blk = timed_blocks(make_runner(batches, st=st5, sync=sync5), min_s=0.25)
             variants["cfg5_bf16"] = {"ms_per_step": round(1e3 * statistics.median(blk) / a.steps, 4),
                                      "pairs_per_s": round(cfg["B"] * world * a.steps / statistics.median(blk), 1),
