@@ -19,6 +19,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 64x64 output tile per workgroup (4 waves x 32x32 MFMA tile), K in chunks of 32 staged through LDS
 // (row stride 36 floats = 4*odd: conflict-free ds_read_b128).  Sizes here are tiny (<= 1 GFLOP), so the
 // kernel is written for generality (any strides / bounds), not for the last 20 % of the MFMA roofline.
+// (Measured and dropped, round 3: 32x32 tiles with K split over the workgroup's four waves, each wave through an LDS region of its
+// own and the partial tiles meeting in wave order, for the shapes that leave the chip idle under 64x64 tiles -- D-ATT's fc is 128
+// tiles, its weight gradients 64.  18.2 us against 17.8 us per launch: a wave then issues the loads and LDS writes of a whole
+// 32x32 tile per chunk, one dword at a time, and that instruction stream costs what the shorter MFMA chain saves.)
 constexpr int GK = 32, GS = 36;
 
 struct Epi {
