@@ -723,8 +723,9 @@ def main():
                 "kernel": ("prod_gemm_kernel<60> (v_mfma_f32_32x32x2_f32)" if precision == "f32" else
                            "rows_to_b16_kernel + prod_gemm_b16s_kernel (bf16 storage: compact bf16 row copy, v_mfma_f32_32x32x16_bf16, "
                            "bf16 product table)" if (precision == "bf16" and os.environ.get("RBR_B16_STORAGE", "1") != "0") else
-                           f"prod_gemm_b16_kernel<{nprod}> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product)")
-                          + ": T = table[distinct tokens] @ Wprod, rows gathered by LDS-DMA",
+                           f"prod_gemm_b16d_kernel<{nprod}, 8> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product; token "
+                           f"rows loaded into registers, weight planes through LDS)")
+                          + ": T = table[distinct tokens] @ Wprod",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": measured_traffic(gemm_pmc) or measured_traffic("r02_prod_gemm_b16_pmc.json"),
                 "traffic_source": f"profiles/{gemm_pmc} (r02_ when this round's pass is absent)",

@@ -35,6 +35,7 @@
 #include "textcnn_b16.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace rbr {
 
@@ -186,6 +187,162 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
         if (dr < rows_left) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) out[(size_t)dr * g.pitch + t * 32] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- token rows straight into registers
+// The same GEMM with the A operand (the token rows) loaded from global memory into the registers of the lane that multiplies
+// them -- lane (row r32, half h) of a wave reads its 8 floats of a 16-deep step as two dwordx4, three steps ahead, through a
+// ring of four register sets -- instead of through the LDS ring: the kernel above is bound by the CU's LDS-fill path, and the
+// rows were 8 of the 20 KiB a stage moves through it.  Only the weight fragments still go through LDS (48 KiB).  Same values
+// into the same MFMAs in the same order: the same bits.  Measured at cfg2 (1008 -> 504 workgroups): 61.0 us (rows through LDS)
+// -> 59.0 (rows in registers, NT = 4) -> 56.8 (NT = 8) -> 55.4 us with the next stage's split spread between this stage's MFMAs.
+// SQ counters of the NT = 8 form: the matrix pipe busy 58 % of the CUs' cycles (1.82 M MFMAs x 32 cycles), 2.5 VALU
+// instructions per MFMA that co-execute with it for 6 % of its cycles only, and a clock of ~1.7 GHz under this load (what
+// "2.5 PF at 2.4 GHz" prices the kernel against is not a clock the chip holds here).
+// NT = 32-column tiles per wave: 4 (one 128-column group per workgroup, 4 stages) or 8 (TWO adjacent groups, 3 stages: the
+// rows' loads and their split into planes -- 3.7 VALU instructions per MFMA at NT = 4, by the SQ counters, with the matrix pipe
+// busy 56 % of the CU's cycles -- are shared by twice the columns).
+template <int NT> struct B16d {
+    static constexpr int kStages = NT == 4 ? 4 : 3;
+    static constexpr int kStageBytes = (NT / 4) * kB16BBytes;
+    static constexpr int kLds = kStages * kStageBytes;
+    static constexpr int kOps = 2 + 3 * (NT / 4);              // vector-memory instructions per wave and stage
+};
+
+template <int NPROD, int NT>
+__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16d_kernel(const B16Gemm g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    using Cfg = B16d<NT>;
+    constexpr int S = Cfg::kStages, NG = NT / 4;
+    constexpr int NPLANES = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    const int n = min(*g.counter, g.cap);
+    const int gpw = (g.ngroups + NG - 1) / NG;                   // workgroups per row block
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int mblock = (jj / gpw) * 8 + xcd, ng = (jj - (jj / gpw) * gpw) * NG;
+    const int m0 = mblock * kB16BM;
+    if (m0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = g.D;
+    unsigned char* const Bbuf = smem;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int row = m0 + wave * 32 + r32;
+    const float* const arow = (row < n) ? g.table + g.tok_of_row[row] * (long)D + 8 * h : nullptr;
+    const int nch = g.nchunks;
+    const unsigned char* bsrc[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)       // a second group past the last one re-reads the last (its tiles are never stored)
+        bsrc[q] = g.bimg + ((size_t)min(ng + q, g.ngroups - 1) * nch) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
+    f32x4 ring0[S], ring1[S];                  // [slot]: floats 0..3 / 4..7 of the lane's 8 (compile-time slots only)
+    auto issue_a = [&](int c, f32x4& x0, f32x4& x1) {          // ALWAYS two loads (clamped source past the end / outside the rows)
+        const int cs = min(c, nch - 1), col = cs * kB16KC + 8 * h;
+        const float* s0 = (arow != nullptr && col + 4 <= D) ? arow + cs * kB16KC : g_b16_zero;
+        const float* s1 = (arow != nullptr && col + 8 <= D) ? arow + cs * kB16KC + 4 : g_b16_zero;
+        x0 = *reinterpret_cast<const f32x4*>(s0);
+        x1 = *reinterpret_cast<const f32x4*>(s1);
+    };
+    auto issue_b = [&](int c, int slot) {
+        const int cs = min(c, nch - 1);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            unsigned char* B = Bbuf + slot * Cfg::kStageBytes + q * kB16BBytes + wave * 3 * kB16BFrag;
+            const unsigned char* s_ = bsrc[q] + (size_t)cs * kB16BBytes;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) b16_dma16(s_ + t * kB16BFrag, B + t * kB16BFrag);
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bf16x8 a_hi, a_mid, a_lo;                  // planes of the stage being multiplied
+    bf16x8 n_hi, n_mid, n_lo;                  // ... of the next one: split between this stage's MFMAs, handed over at its end
+    auto split_rows = [&](const f32x4 x0, const f32x4 x1) {
+        unsigned h4[4], m4[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0};
+        split_pair<NPLANES>(x0.x, x0.y, h4[0], m4[0], l4[0]);
+        split_pair<NPLANES>(x0.z, x0.w, h4[1], m4[1], l4[1]);
+        split_pair<NPLANES>(x1.x, x1.y, h4[2], m4[2], l4[2]);
+        split_pair<NPLANES>(x1.z, x1.w, h4[3], m4[3], l4[3]);
+        const u32x4 ah = {h4[0], h4[1], h4[2], h4[3]}, am = {m4[0], m4[1], m4[2], m4[3]}, al = {l4[0], l4[1], l4[2], l4[3]};
+        n_hi = __builtin_bit_cast(bf16x8, ah);
+        n_mid = n_lo = n_hi;
+        if (NPLANES >= 2) n_mid = __builtin_bit_cast(bf16x8, am);
+        if (NPLANES >= 3) n_lo = __builtin_bit_cast(bf16x8, al);
+    };
+    auto mma_tile = [&](const unsigned char* B, int t) {       // t: tile of the workgroup's NT (group t / 4, tile t % 4 of it)
+        const unsigned char* bf = B + (t >> 2) * kB16BBytes + ((t & 3) * 3) * kB16BFrag;
+        const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(bf);
+        if (NPROD == 6) {       // small terms first
+            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+            const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(bf + 2 * kB16BFrag);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc[t], 0, 0, 0);
+        } else if (NPROD == 3) {
+            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[t], 0, 0, 0);
+    };
+    // stage c with its ring slot Sc = c % S as a compile-time number: the rows of stage c + 1 sit in slot (Sc + 1) % S, the
+    // loads of stage c + S - 1 go to slot (Sc + S - 1) % S (the slot stage c - 1 has just left)
+    auto stage = [&](int c, auto Sc_) {
+        constexpr int Sc = decltype(Sc_)::value;
+        if (S == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // stage c landed: two younger stages x 5 instructions
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               //                  one younger stage x 8
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* B = Bbuf + Sc * Cfg::kStageBytes + lane * 16;
+        mma_tile(B, 0);
+        issue_a(c + S - 1, ring0[(Sc + S - 1) % S], ring1[(Sc + S - 1) % S]);
+        mma_tile(B, 1);
+        issue_b(c + S - 1, (Sc + S - 1) % S);
+        split_rows(ring0[(Sc + 1) % S], ring1[(Sc + 1) % S]);   // VALU work with no MFMA of this stage depending on it ...
+#pragma unroll
+        for (int t = 2; t < NT; ++t) mma_tile(B, t);
+        // ... which the scheduler is asked to spread between them: one MFMA, then two VALU instructions, over the stage
+#pragma unroll
+        for (int k = 0; k < NT * (NPROD == 6 ? 6 : NPROD == 3 ? 3 : 1); ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        a_hi = n_hi; a_mid = n_mid; a_lo = n_lo;
+    };
+#pragma unroll
+    for (int c = 0; c < S - 1; ++c) { issue_a(c, ring0[c], ring1[c]); issue_b(c, c); }
+    split_rows(ring0[0], ring1[0]);
+    a_hi = n_hi; a_mid = n_mid; a_lo = n_lo;
+    if (S == 4) {
+        for (int c = 0; c < nch; c += 4) {                       // workgroup-uniform guards
+            stage(c, std::integral_constant<int, 0>{});
+            if (c + 1 < nch) stage(c + 1, std::integral_constant<int, 1>{});
+            if (c + 2 < nch) stage(c + 2, std::integral_constant<int, 2>{});
+            if (c + 3 < nch) stage(c + 3, std::integral_constant<int, 3 % S>{});
+        }
+    } else {
+        for (int c = 0; c < nch; c += 3) {
+            stage(c, std::integral_constant<int, 0>{});
+            if (c + 1 < nch) stage(c + 1, std::integral_constant<int, 1>{});
+            if (c + 2 < nch) stage(c + 2, std::integral_constant<int, 2>{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = g.T + (size_t)(m0 + wave * 32 + 4 * h) * g.pitch + ng * kB16BN + r32;
+    const int rows_left = n - (m0 + wave * 32 + 4 * h);
+    const int tiles_ok = min(NT, (g.ngroups - ng) * 4);          // the tiles of a second group that does not exist are dropped
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (dr < rows_left) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < tiles_ok) out[(size_t)dr * g.pitch + t * 32] = acc[t][r];
         }
     }
 }
@@ -415,6 +572,29 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     }
     const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;           // whole XCD rounds
     const dim3 grid((unsigned)(mblocks * g.ngroups)), block(kB16Threads);
+    // two or more 128-column groups: the form with the token rows in registers and two groups per workgroup (prod_gemm_b16d_kernel)
+    static const bool direct_ok = getenv("RBR_GEMM_ROWS_IN_LDS") == nullptr || atoi(getenv("RBR_GEMM_ROWS_IN_LDS")) == 0;
+    if (direct_ok && g.ngroups >= 2) {
+        static bool attr_d = false;
+        if (!attr_d) {
+            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<6, 8>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<6> LDS")) return e;
+            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<3, 8>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<3> LDS")) return e;
+            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<1, 8>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<1> LDS")) return e;
+            attr_d = true;
+        }
+        const dim3 grid_d((unsigned)(mblocks * ((g.ngroups + 1) / 2)));
+        switch (prod_precision()) {
+            case RBR_PROD_BF16X3: hipLaunchKernelGGL((prod_gemm_b16d_kernel<6, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
+            case RBR_PROD_BF16X2: hipLaunchKernelGGL((prod_gemm_b16d_kernel<3, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
+            case RBR_PROD_BF16: hipLaunchKernelGGL((prod_gemm_b16d_kernel<1, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
+            default: set_error("prod_b16_gemm called in f32 mode"); return RBR_ERR_BAD_ARG;
+        }
+        RBR_CHECK_LAUNCH("textcnn prod_gemm_b16d launch");
+        return 0;
+    }
     switch (prod_precision()) {
         case RBR_PROD_BF16X3: hipLaunchKernelGGL(prod_gemm_b16_kernel<6>, grid, block, kB16Lds, st, g); break;
         case RBR_PROD_BF16X2: hipLaunchKernelGGL(prod_gemm_b16_kernel<3>, grid, block, kB16Lds, st, g); break;
