@@ -200,7 +200,9 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
 // -> 59.0 (rows in registers, NT = 4) -> 56.8 (NT = 8) -> 55.4 us with the next stage's split spread between this stage's MFMAs.
 // SQ counters of the NT = 8 form: the matrix pipe busy 58 % of the CUs' cycles (1.82 M MFMAs x 32 cycles), 2.5 VALU
 // instructions per MFMA that co-execute with it for 6 % of its cycles only, and a clock of ~1.7 GHz under this load (what
-// "2.5 PF at 2.4 GHz" prices the kernel against is not a clock the chip holds here).
+// "2.5 PF at 2.4 GHz" prices the kernel against is not a clock the chip holds here).  Dropped: 256 rows x 256 columns per
+// workgroup, one workgroup of 8 waves per CU (the stage's fragments filled once for twice the rows, 4 stages): 88 us -- as with
+// round 2's 256-row item, eight waves at one barrier per step lose more than the halved fills give.
 // NT = 32-column tiles per wave: 4 (one 128-column group per workgroup, 4 stages) or 8 (TWO adjacent groups, 3 stages: the
 // rows' loads and their split into planes -- 3.7 VALU instructions per MFMA at NT = 4, by the SQ counters, with the matrix pipe
 // busy 56 % of the CU's cycles -- are shared by twice the columns).
