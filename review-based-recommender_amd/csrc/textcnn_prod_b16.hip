@@ -202,7 +202,9 @@ __global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16
 // instructions per MFMA that co-execute with it for 6 % of its cycles only, and a clock of ~1.7 GHz under this load (what
 // "2.5 PF at 2.4 GHz" prices the kernel against is not a clock the chip holds here).  Dropped: 256 rows x 256 columns per
 // workgroup, one workgroup of 8 waves per CU (the stage's fragments filled once for twice the rows, 4 stages): 88 us -- as with
-// round 2's 256-row item, eight waves at one barrier per step lose more than the halved fills give.
+// round 2's 256-row item, eight waves at one barrier per step lose more than the halved fills give; and 256 rows x 128 columns
+// with four waves of TWO row tiles each (every weight fragment read from LDS feeds two MFMA chains: half the LDS reads and fills
+// per MFMA, rows one step ahead in a two-slot register ring): 86 us.
 // NT = 32-column tiles per wave: 4 (one 128-column group per workgroup, 4 stages) or 8 (TWO adjacent groups, 3 stages: the
 // rows' loads and their split into planes -- 3.7 VALU instructions per MFMA at NT = 4, by the SQ counters, with the matrix pipe
 // busy 56 % of the CU's cycles -- are shared by twice the columns).
