@@ -576,9 +576,12 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     }
     const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;           // whole XCD rounds
     const dim3 grid((unsigned)(mblocks * g.ngroups)), block(kB16Threads);
-    // two or more 128-column groups: the form with the token rows in registers and two groups per workgroup (prod_gemm_b16d_kernel)
+    // The form with the token rows in registers and two 128-column groups per workgroup (prod_gemm_b16d_kernel) where it was
+    // measured to win: six or more groups (three workgroups per row block: cfg2's 167 row blocks fill the 512 workgroup slots
+    // once) and a K of at least 12 steps.  NARRE cfg3 (4 groups: 314 workgroups) 36.5 us against 32.0, D-ATT's merged conv (9
+    // groups but K = 100: 7 steps) 61 against 58 -- those keep the kernel above.
     static const bool direct_ok = getenv("RBR_GEMM_ROWS_IN_LDS") == nullptr || atoi(getenv("RBR_GEMM_ROWS_IN_LDS")) == 0;
-    if (direct_ok && g.ngroups >= 2) {
+    if (direct_ok && g.ngroups >= 6 && g.nchunks >= 12) {
         static bool attr_d = false;
         if (!attr_d) {
             if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<6, 8>),
