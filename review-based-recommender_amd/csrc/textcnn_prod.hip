@@ -175,6 +175,10 @@ typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(2)));  // fou
 // the same row segments, 100 bytes at 4-byte alignment, are fetched by wider and fewer lanes.  The f32 kernel's counters
 // (profiles/r03_gather_pool_pmc.json) say what bounds it instead: its L2 requests equal the distinct 128-byte lines of the
 // rows a tile reads (the L1 absorbs the kz-fold re-reads), 27 % of them miss, and T (44 MB; 22 MB in bf16) fits no XCD's L2.)
+// (Also measured and dropped: the tap loop unrolled by a compile-time width.  As compiled, every tap of the guarded loop below is a
+// block of its own -- two loads, wait, four FMAs -- so a lane has two loads in flight; unrolled, eight, at 151 registers instead of
+// 62: 53 us against 44 at cfg2, 218 against 152 for D-ATT.  Eight waves per SIMD with two loads each already keep the L2 at its
+// rate; fewer waves with more loads each do not.)
 template <bool TB16>
 __global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
