@@ -721,8 +721,7 @@ def main():
             out["roofline_gemm"] = {
                 "bound": "mfma",
                 "kernel": ("prod_gemm_kernel<60> (v_mfma_f32_32x32x2_f32)" if precision == "f32" else
-                           "rows_to_b16_kernel + prod_gemm_b16s_kernel (bf16 storage: compact bf16 row copy, v_mfma_f32_32x32x16_bf16, "
-                           "bf16 product table)" if (precision == "bf16" and os.environ.get("RBR_B16_STORAGE", "1") != "0") else
+                           "prod_gemm_b16sd_kernel (bf16 storage: rows rounded in registers, v_mfma_f32_32x32x16_bf16, bf16 product table)" if (precision == "bf16" and os.environ.get("RBR_B16_STORAGE", "1") != "0") else
                            f"prod_gemm_b16d_kernel<{nprod}, 8> (v_mfma_f32_32x32x16_bf16, {nprod} plane products per f32 product; token "
                            f"rows loaded into registers, weight planes through LDS)")
                           + ": T = table[distinct tokens] @ Wprod",

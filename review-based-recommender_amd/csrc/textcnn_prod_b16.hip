@@ -533,6 +533,116 @@ B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d) {
     return J;
 }
 
+// The bf16-storage GEMM with the token rows loaded from the f32 table into registers and rounded there (no compact bf16 copy, no
+// rows_to_b16 launch), two 128-column groups per workgroup, 32-deep stages: per stage a lane loads its 16 floats (4 dwordx4), a
+// wave fills one hi-plane fragment per group and k-half, and multiplies 16 MFMAs.  Same roundings, same MFMA order per
+// accumulator as prod_gemm_b16s_kernel: the same bf16 T.
+constexpr int kB16sdStages = 3;
+constexpr int kB16sdStageBytes = 2 * kB16sBBytes;                // 16 KiB: [group][k-half][tile]
+constexpr int kB16sdLds = kB16sdStages * kB16sdStageBytes;       // 48 KiB
+
+__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16sd_kernel(const B16Gemm g, unsigned short* __restrict__ T16, int nchunks16) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int S = kB16sdStages, NG = 2, NT = 8;
+    const int n = min(*g.counter, g.cap);
+    const int gpw = (g.ngroups + NG - 1) / NG;
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int mblock = (jj / gpw) * 8 + xcd, ng = (jj - (jj / gpw) * gpw) * NG;
+    const int m0 = mblock * kB16BM;
+    if (m0 >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = g.D;
+    unsigned char* const Bbuf = smem;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int row = m0 + wave * 32 + r32;
+    const float* const arow = (row < n) ? g.table + g.tok_of_row[row] * (long)D + 8 * h : nullptr;
+    const int nch = (D + kB16sKC - 1) / kB16sKC;               // 32-deep stages
+    const unsigned char* bsrc[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        bsrc[q] = g.bimg + ((size_t)min(ng + q, g.ngroups - 1) * nchunks16) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
+    f32x4 ring[S][4];                      // [slot][k-half * 2 + (floats 0..3 | 4..7)]
+    auto issue_a = [&](int c, f32x4 (&x)[4]) {             // ALWAYS four loads (clamped source past the row / outside the rows)
+        const int cs = min(c, nch - 1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int col = cs * kB16sKC + kh * 16 + 8 * h + 4 * f;
+                const float* s_ = (arow != nullptr && col + 4 <= D) ? arow + cs * kB16sKC + kh * 16 + 4 * f : g_b16_zero;
+                x[kh * 2 + f] = *reinterpret_cast<const f32x4*>(s_);
+            }
+    };
+    auto issue_b = [&](int c, int slot) {
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            unsigned char* B = Bbuf + slot * kB16sdStageBytes + q * kB16sBBytes + wave * kB16BFrag;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const int c16 = min(2 * min(c, nch - 1) + kh, nchunks16 - 1);      // past the image: finite weights, zero rows
+                b16_dma16(bsrc[q] + (size_t)c16 * kB16BBytes, B + kh * 4 * kB16BFrag);
+            }
+        }
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    bf16x8 a0, a1, n0, n1;
+    auto round_rows = [&](const f32x4 (&x)[4]) {
+        const u32x4 p0 = {pack_bf16(x[0].x, x[0].y), pack_bf16(x[0].z, x[0].w), pack_bf16(x[1].x, x[1].y), pack_bf16(x[1].z, x[1].w)};
+        const u32x4 p1 = {pack_bf16(x[2].x, x[2].y), pack_bf16(x[2].z, x[2].w), pack_bf16(x[3].x, x[3].y), pack_bf16(x[3].z, x[3].w)};
+        n0 = __builtin_bit_cast(bf16x8, p0);
+        n1 = __builtin_bit_cast(bf16x8, p1);
+    };
+    auto stage = [&](int c, auto Sc_) {
+        constexpr int Sc = decltype(Sc_)::value;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage c landed: one younger stage x 8 instructions
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned char* B = Bbuf + Sc * kB16sdStageBytes + lane * 16;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, *reinterpret_cast<const bf16x8*>(B + (t >> 2) * kB16sBBytes + (t & 3) * kB16BFrag),
+                                                             acc[t], 0, 0, 0);
+            if (t == 0) issue_a(c + S - 1, ring[(Sc + S - 1) % S]);
+            if (t == 1) issue_b(c + S - 1, (Sc + S - 1) % S);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(B + (t >> 2) * kB16sBBytes + (4 + (t & 3)) * kB16BFrag),
+                                                             acc[t], 0, 0, 0);
+        round_rows(ring[(Sc + 1) % S]);
+        a0 = n0; a1 = n1;
+    };
+#pragma unroll
+    for (int c = 0; c < S - 1; ++c) { issue_a(c, ring[c]); issue_b(c, c); }
+    round_rows(ring[0]);
+    a0 = n0; a1 = n1;
+    for (int c = 0; c < nch; c += 3) {                           // workgroup-uniform guards
+        stage(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nch) stage(c + 1, std::integral_constant<int, 1>{});
+        if (c + 2 < nch) stage(c + 2, std::integral_constant<int, 2>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned short* out = T16 + (size_t)(m0 + wave * 32 + 4 * h) * g.pitch + ng * kB16BN + (r32 & ~1);
+    const int rows_left = n - (m0 + wave * 32 + 4 * h);
+    const int tiles_ok = min(NT, (g.ngroups - ng) * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float mine = acc[t][r];
+            const float other = __shfl_xor(mine, 1);
+            if (!(r32 & 1) && dr < rows_left && t < tiles_ok)
+                *reinterpret_cast<unsigned*>(out + (size_t)dr * g.pitch + t * 32) = pack_bf16(mine, other);
+        }
+    }
+}
+
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
                   const float* table, const void* bimg, void* Tv, void* a16, hipStream_t st) {
     if (((uintptr_t)table & 15) != 0) { set_error("word table must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
@@ -548,6 +658,20 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
             if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16s_kernel),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kB16sLds), "prod_gemm_b16s LDS")) return e;
             attr_s = true;
+        }
+        // six or more column groups (cfg2): the rows straight from the f32 table into registers, no compact copy, two groups per
+        // workgroup -- 25.4 us against 8.4 (rows_to_b16) + 24.1, the step of the class 0.329 -> 0.313 ms.  RBR_B16_ROWS_COPY=1: the
+        // two-launch form below (which smaller shapes keep: they do not fill the chip with half the workgroups).
+        static const bool sd_ok = getenv("RBR_B16_ROWS_COPY") == nullptr || atoi(getenv("RBR_B16_ROWS_COPY")) == 0;
+        if (sd_ok && g.ngroups >= 6) {
+            B16Gemm gd{};
+            gd.counter = counter; gd.tok_of_row = tok_of_row; gd.table = table; gd.bimg = g.bimg; gd.T = nullptr;
+            gd.cap = cap; gd.D = d->D; gd.pitch = pitch; gd.ngroups = g.ngroups; gd.nchunks = g.nchunks16;
+            const int mb = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
+            hipLaunchKernelGGL(prod_gemm_b16sd_kernel, dim3((unsigned)(mb * ((g.ngroups + 1) / 2))), dim3(kB16Threads), kB16sdLds, st, gd,
+                               g.T, g.nchunks16);
+            RBR_CHECK_LAUNCH("textcnn prod_gemm_b16sd launch");
+            return 0;
         }
         const long segs = (long)cap * (g.Dp / 8);
         hipLaunchKernelGGL(rows_to_b16_kernel, dim3((unsigned)std::min<long>((segs + 255) / 256, 4096)), dim3(256), 0, st, counter, cap, d->D,
