@@ -326,7 +326,7 @@ def time_optimizer_launches(cfg, device, clipping=True, n_sets=3, reps=45):
         o = make_optimizer(m, hip_clip_adam=True)
         a, r = batch_on(cfg, 200 + k, device)
         o.zero_grad()
-        _forward_loss_backward(m, a, r)
+        _forward_loss_backward(m, a, r, o)
         rows = [(rg.rows, rg.rows.clone()) for rg in o._row_grads.values()] if isinstance(o, HipClipAdam) else []
         dense = [(p.grad, p.grad.clone()) for p in m.parameters() if p.grad is not None]
         sets.append((m, o, rows + dense))
@@ -387,6 +387,237 @@ def dense_mode_env() -> bool:
     return os.environ.get("RBR_CONV_MODE") == "dense"
 
 
+
+# --------------------------------------------------------------------------- the other BASELINE configs, in the same line
+def _gpu_delay_calibration():
+    """GPU milliseconds per million torch.cuda._sleep cycles (the spin kernel's clock differs between parts)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1_000_000)
+    torch.cuda.synchronize()
+    e0.record()
+    torch.cuda._sleep(4_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    return max(e0.elapsed_time(e1) / 4.0, 1e-4)
+
+
+def queued_kernel_pass(run_step, n_steps, ms_per_mcycle):
+    """HIP events around every C-ABI call (_lib.TIMER) of `n_steps` EAGER steps, each enqueued behind a spin kernel that holds the
+    GPU back for longer than the host needs to enqueue the whole step: when the kernels run, the queue is full, so an event
+    interval holds the kernel (and the cache state the step's own order leaves), not the host's launch gaps.  Calls that are
+    ONE launch are therefore kernel times.  Returns ({call name: (calls, mean ms)}, host ms per eager step)."""
+    from review_based_recommender_amd import _lib
+    run_step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_step(1)
+    host_ms = (time.perf_counter() - t0) * 1e3          # host time to enqueue one eager step
+    torch.cuda.synchronize()
+    cycles = int((1.5 * host_ms + 0.5) / ms_per_mcycle * 1e6)
+    _lib.TIMER.start()
+    for i in range(n_steps):
+        torch.cuda._sleep(cycles)
+        run_step(2 + i)
+        torch.cuda.synchronize()
+    _lib.TIMER.stop()
+    return _lib.TIMER.summary(), host_ms
+
+
+def price_kernel(name, ms, shape):
+    """Roofline object of the C-ABI call `name` (one kernel launch; the optimizer: a launch pair) that took `ms`: algorithmic
+    bytes / FLOPs of that launch (`shape`: distinct tokens, positions, columns of the product table, ...)
+    over the HIP-event time."""
+    nd, pos, cp, D, C_, tb = (shape[k] for k in ("distinct", "positions", "cp", "D", "C", "t_bytes"))
+    slabs = shape["slabs"]
+
+    def hbm(by, what):
+        return {"bound": "hbm", "kernel": what, "bytes_per_launch": by, "achieved": round(by / ms / 1e6, 1), "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s", "frac": round(by / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+
+    if name == "textcnn_prod_pool":
+        return hbm(nd * cp * tb + pos * (8 + 1 + 4 * shape["gates"]) + slabs * C_ * 8.0,
+                   "gather_pool_kernel: per active 32-token slab, the sum of the kz product-table rows of every position, running max / "
+                   "first argmax; bytes = every product-table row once + ids, masks, gates + the slab partials it writes")
+    if name == "textcnn_bwd_g_product":
+        return hbm(nd * cp * 4.0 + cp * D * 4.0 + nd * D * 4.0,
+                   "g_times_w_kernel: word-table gradient rows = G[distinct tokens] @ Wprod^T as a sparse row product; bytes = G once + "
+                   "Wprod^T once + one gradient row per distinct token")
+    if name == "clip_adam_step":
+        return hbm(24.0 * shape["n_par"] + 12.0 * shape["grad_elems"],
+                   "grad_sqnorm_kernel + clip_adam_kernel (rbr_clip_adam_step[_rows]: clip_grad_norm_ + Adam over every parameter "
+                   "tensor; a launch PAIR); bytes = p, m, v read + written + every existing gradient element read twice, written once")
+    if name == "textcnn_prod_table":
+        nprod = shape["nprod"]
+        fl = 2.0 * nd * D * cp
+        f32 = shape["precision"] == "f32"
+        peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
+        what = ("prod_gemm_kernel: T = table[distinct tokens] @ Wprod on v_mfma_f32_32x32x2_f32" if f32 else
+                f"prod_gemm_b16* kernel: T = table[distinct tokens] @ Wprod, {nprod} bf16 plane product(s) per f32 product on "
+                "v_mfma_f32_32x32x16_bf16")
+        return {"bound": "mfma", "kernel": what, "flops_per_launch": nprod * fl, "algorithmic_flops_per_launch": fl,
+                "achieved": round(nprod * fl / ms / 1e9, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(nprod * fl / ms / 1e9 / peak, 4)}
+    return None
+
+
+SINGLE_KERNEL_CALLS = ("textcnn_prod_pool", "textcnn_bwd_g_product", "textcnn_prod_table", "clip_adam_step")
+
+
+def secondary_configs(device, a, precision0):
+    """BASELINE.json configs[1] in the bf16 class, configs[2] (NARRE cfg3: bf16 class -- the dtype BASELINE names -- and f32
+    class) and configs[3] (D-ATT cfg4): the trainer step of each (dropout 0.5, clip, Adam; GraphedTrainStep + HipClipAdam, one
+    recorded graph per resident batch, as the headline), timed the headline's way, with the kernel launches of a replay, the
+    step's longest single kernel priced against its roofline (HIP events, queued_kernel_pass) and max |pred - fixture| on the
+    config's golden batch (tests/golden/*.npz: the reference's own forward) so every number carries its parity class."""
+    import contextlib
+    import io
+
+    import numpy as np
+
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
+
+    def quiet(fn, *args):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fn(*args)
+
+    def on_dev(b, keys):
+        return tuple(b[k].to(device) for k in keys), b["ratings"].to(device)
+
+    def deepconn(cfg):
+        m = build_model(cfg, device)
+        keys = ("u_docs", "i_docs", "u_masks", "i_masks", "u_ids", "i_ids")
+        return (m, lambda sd: on_dev(synth.deepconn_batch(cfg, sd), keys),
+                lambda args: (torch.cat([args[0], args[1]]), torch.cat([args[2], args[3]])),
+                dict(kz=cfg["kz"], ch=[cfg["H"] // len(cfg["kz"])] * len(cfg["kz"]), D=cfg["D"], gates=0))
+
+    def narre(cfg):
+        from review_based_recommender_amd.models.narre.narre import NARRE
+        m = quiet(NARRE, cfg["U"], cfg["I"], cfg["V"], cfg["kz"], cfg["H"], cfg["D"], cfg["A"], cfg["K"], cfg["R"], cfg["T"], 0.5,
+                  0, 0, 0, None, "CNN")
+        m.load_state_dict(synth.narre_params(cfg, 0))
+        keys = ("u_text", "i_text", "u_masks", "i_masks", "u_id", "i_id", "reuid", "reiid")
+        return (m.to(device), lambda sd: on_dev(synth.narre_batch(cfg, sd), keys),
+                lambda args: (torch.cat([args[0], args[1]]).view(-1, cfg["T"]), torch.cat([args[2], args[3]]).view(-1, cfg["T"])),
+                dict(kz=cfg["kz"], ch=[cfg["H"] // len(cfg["kz"])] * len(cfg["kz"]), D=cfg["D"], gates=0))
+
+    def datt(cfg):
+        from review_based_recommender_amd.models.dual_att.dual_att import DualAtt
+        m = quiet(DualAtt, cfg["V"], cfg["L"], cfg["win"], cfg["l_out"], cfg["g_out"], cfg["E"], cfg["h1"], cfg["h2"], 0.5, None)
+        m.load_state_dict(synth.datt_params(cfg, 0, table_scale=0.3))          # as the fixture
+        return (m.to(device), lambda sd: on_dev(synth.datt_batch(cfg, sd), ("u_docs", "i_docs")),
+                lambda args: (torch.cat([args[0], args[1]]), None),
+                dict(kz=[1, 2, 3, 4], ch=[cfg["l_out"]] + [cfg["g_out"]] * 3, D=cfg["E"], gates=1))
+
+    specs = [
+        ("deepconn_cfg2_bf16", "DeepCoNN cfg2 (BASELINE configs[1]'s shape) in the bf16 class: B=256, 2x512 tokens, D=300, widths 3/5/7 x 50",
+         deepconn, synth.DEEPCONN_CFGS["cfg2"], "bf16", "deepconn_cfg2", 256),
+        ("narre_cfg3_bf16", "NARRE cfg3 (BASELINE configs[2]): B=256, 10 reviews x 50 tokens per side, D=300, width 3 x 150, bf16 class",
+         narre, synth.NARRE_CFGS["cfg3"], "bf16", "narre_cfg3", 256),
+        ("narre_cfg3_f32", "NARRE cfg3, f32 class (bf16x3: exact three-plane split)", narre, synth.NARRE_CFGS["cfg3"], None,
+         "narre_cfg3", 256),
+        ("datt_cfg4_f32", "D-ATT cfg4 (BASELINE configs[3]): B=512, 2x1024 tokens, E=100, local 200 + global 3x100 channels, f32 class",
+         datt, synth.DATT_CFGS["cfg4"], None, "datt_cfg4", 512),
+    ]
+    ms_per_mcycle = _gpu_delay_calibration()
+    out = {}
+    for key, label, build, cfg, prec, fixture, B in specs:
+        t_cfg = time.perf_counter()
+        try:
+            RF.set_prod_precision(prec)
+            cls = RF.get_prod_precision()
+            model, bat, tok, conv = build(cfg)
+            # ---- parity class of this configuration: eval forward on the golden batch against the reference's recording
+            g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+            gargs, _ = bat(1)
+            model.eval()
+            with torch.no_grad():
+                o = model(*gargs)
+                pred = (o[0] if isinstance(o, tuple) else o).float().cpu().numpy()
+            err = float(np.abs(pred.astype(np.float64) - g["pred_eval"].astype(np.float64)).max())
+            tol = 3e-2 if cls == "bf16" else 1e-4
+            # ---- the timed step
+            model.train()
+            opt = make_optimizer(model, hip_clip_adam=True)
+            nb = max(1, a.batches)
+            bs = [bat(1 + j) for j in range(nb)]
+            with torch.no_grad():
+                init = [p.detach().clone() for p in model.parameters()]
+
+            def reset():
+                with torch.no_grad():
+                    for p, v in zip(model.parameters(), init):
+                        p.copy_(v)
+                    for st_ in opt.state.values():
+                        for v in st_.values():
+                            if torch.is_tensor(v):
+                                v.zero_()
+                torch.cuda.synchronize()
+
+            stepper = GraphedTrainStep(model, opt, bs[0][0], bs[0][1], slots=nb, keep_graph=True)
+            launches = stepper.kernel_launches()
+            for k, b in enumerate(bs):
+                stepper.stage(k, *b)
+            reset()
+            for i in range(a.warmup):
+                stepper(slot=i % nb)
+            blocks, k = [], 0
+            while True:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.steps):
+                    stepper(slot=(k + i) % nb)
+                torch.cuda.synchronize()
+                blocks.append(time.perf_counter() - t0)
+                k += a.steps
+                if len(blocks) >= 3 and sum(blocks) >= 0.25:
+                    break
+            med = statistics.median(blocks)
+            # ---- kernel pass: the same step launched eagerly behind a spin kernel (full queue), HIP events per C-ABI call
+            reset()
+            n_pass = 6
+            ksum, host_ms = queued_kernel_pass(lambda i: train_step(model, opt, bs[i % nb][0], bs[i % nb][1]), n_pass, ms_per_mcycle)
+            ids, msk = tok(bs[0][0])
+            live = ids[msk] if msk is not None else ids.reshape(-1)
+            n_par = sum(p.numel() for p in model.parameters())
+            table = next(p for n_, p in model.named_parameters() if n_.startswith("word_embeddings"))
+            distinct = int(torch.unique(live).numel())
+            row_form = len(getattr(opt, "_row_grads", {})) > 0
+            shape = dict(distinct=distinct, positions=int(ids.numel()), cp=sum(k_ * c_ for k_, c_ in zip(conv["kz"], conv["ch"])),
+                         D=conv["D"], C=sum(conv["ch"]), t_bytes=2 if cls == "bf16" else 4,
+                         slabs=int(ids.shape[0]) * ((int(ids.shape[1]) + 31) // 32), gates=conv["gates"],
+                         nprod={"f32": 1, "bf16x3": 6, "bf16x2": 3, "bf16": 1}[cls], precision=cls, n_par=n_par,
+                         grad_elems=(n_par - table.numel() + distinct * conv["D"]) if row_form else n_par)
+            single = {n_: v for n_, v in ksum.items() if n_ in SINGLE_KERNEL_CALLS}
+            dom = max(single, key=lambda n_: single[n_][1]) if single else None
+            roof = None
+            if dom is not None:
+                roof = price_kernel(dom, single[dom][1], shape)
+                roof.update({"call": dom, "avg_launch_ms": round(single[dom][1], 4), "launches_timed": single[dom][0],
+                             "calls_per_step": round(single[dom][0] / float(n_pass), 2),
+                             "timing": "HIP events around the C-ABI call in eager steps enqueued behind a spin kernel (full queue)",
+                             "traffic": None})
+            out[key] = {
+                "workload": label, "ms_per_step": round(1e3 * med / a.steps, 4), "ms_per_step_min": round(1e3 * min(blocks) / a.steps, 4),
+                "pairs_per_s": round(B * a.steps / med, 1), "repeats": len(blocks), "launches_per_step": launches,
+                "launch": f"hipGraph replay, {nb} resident batches, one recorded step per input slot", "conv_arithmetic": cls,
+                "max_abs_pred_err_vs_fixture": float(f"{err:.3e}"), "fixture": f"tests/golden/{fixture}.npz (pred_eval: the reference's forward)",
+                "parity_tolerance": tol, "parity_ok": bool(err <= tol), "distinct_tokens": distinct, "positions": shape["positions"],
+                "roofline": roof,
+                "kernels_ms": {n_: round(v[1] * v[0] / float(n_pass), 4)
+                               for n_, v in sorted(ksum.items(), key=lambda kv: -kv[1][1] * kv[1][0])[:8]},
+                "kernels_ms_note": "per step: mean HIP-event ms of the call x calls per step (a multi-launch call holds all its launches)",
+                "eager_host_ms_per_step": round(host_ms, 3), "wall_s": None}
+            del stepper, opt, model, bs, init
+        except Exception as e:          # one configuration must not cost the line
+            out[key] = {"workload": label, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if "wall_s" in out[key]:
+            out[key]["wall_s"] = round(time.perf_counter() - t_cfg, 1)
+    RF.set_prod_precision(None if precision0 == "bf16x3" else precision0)
+    return out
+
+
 def self_launch(a) -> int:
     """--gpus N > 1 from a plain invocation: start the N ranks as a child torch.distributed.run (this process has
     not touched the GPU, and never does), relay its output and return its exit code."""
@@ -423,6 +654,8 @@ def main():
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.Adam(fused) instead of the two-launch HipClipAdam")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` object (cfg2 in the bf16 class, NARRE cfg3 in both classes, D-ATT cfg4)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -787,6 +1020,10 @@ def main():
                                        "parts_bytes": {k: round(v) for k, v in parts.items()},
                                        "note": "unique HBM bytes of a step / 8 TB/s over the measured step; the conv-stage kernels are "
                                                "bound by L2 requests (rows re-read from L2 / Infinity Cache), not by these bytes"}
+        if world == 1 and not a.no_configs:
+            stepper = None                      # the headline's graphs and their memory pools are not needed any more
+            torch.cuda.empty_cache()
+            out["configs"] = secondary_configs(device, a, precision)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
         print(json.dumps(out), flush=True)

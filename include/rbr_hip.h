@@ -269,7 +269,9 @@ int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n_sets, cons
  *                                             (rbr_textcnn_dtable_from_taps_ws_bytes) as above.  The rank's taps are compacted
  *                                             (stably) before the sort, which is sized for twice the even share of the taps:
  *                                             *overflow (device, caller-zeroed, sticky) is set to 1 when the rank owns more --
- *                                             its slab is then incomplete and the step must be discarded. */
+ *                                             its slab is then incomplete: the caller sends the flag along with the slab and,
+ *                                             when ANY rank raised it, every rank rebuilds that step with
+ *                                             rbr_textcnn_dtable_from_taps instead (distributed.TapExchange._finish_owner). */
 int32_t rbr_textcnn_taps_owner_rows(const rbr_textcnn_desc* d, int32_t n_sets);
 int rbr_textcnn_dtable_from_taps_owner(const rbr_textcnn_desc* d, int32_t n_sets, int32_t rank, const int32_t* tok,
                                        const float* val, const float* const* W, void* ws, float* slab, int32_t* overflow,
@@ -317,8 +319,9 @@ int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const float* u_feat
  * max over all slabs), the head above (drop: a given multiplier, or p_drop > 0: drawn in-kernel as rbr_pair_head_fwd_train
  * does) and -- when target != NULL -- the trainers' nn.MSELoss(mean) (train_deepconn_pp.py:137,164: loss[0], d_pred_unit as
  * rbr_mse_loss_fwd) in ONE launch instead of three.  feat / argmax [2B, C] are written for the backward.  ticket: one int32
- * in device memory, zero before the first call (the launch re-arms it).  RBR_ERR_UNSUPPORTED when the conv has more than 256
- * channel slots. */
+ * in device memory, zero before the first call (the launch re-arms it); calls that may be in flight at the same time (different
+ * streams) need a ticket each -- the binding keeps one per (device, stream).  RBR_ERR_UNSUPPORTED when the conv has more than
+ * 256 channel slots. */
 int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx, const float* const* bias,
                            float* feat, int32_t* argmax, int32_t K, const int64_t* u_id, const int64_t* i_id,
                            const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed, uint64_t* rng_state,

@@ -791,6 +791,7 @@ extern "C" int rbr_datt_global_gate_fwd(int32_t B, int32_t L, int32_t E, const i
 }
 
 extern "C" size_t rbr_datt_gate_bwd_ws_floats(int32_t B, int32_t L, int32_t E, int32_t win, int32_t is_global) {
+    if (B <= 0 || L <= 0 || E <= 0 || win <= 0) return 0;
     return is_global ? (size_t)B + (size_t)E * L : (size_t)B * ((size_t)win * E + 1);
 }
 

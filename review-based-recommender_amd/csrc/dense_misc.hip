@@ -273,7 +273,7 @@ extern "C" int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x
     return launch_gemm(N, OUT, IN, x, IN, 1, W, IN, 1, y, OUT, ep, (hipStream_t)stream);
 }
 
-extern "C" size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT) { return (size_t)N * OUT; }
+extern "C" size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT) { return (N > 0 && OUT > 0) ? (size_t)N * OUT : 0; }
 
 extern "C" int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y,
                               const float* d_y, int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws,
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void dedup_apply_kernel(int B, int L, const lo
 
 }  // namespace rbr
 
-extern "C" size_t rbr_dedup_ws_bytes(int32_t U, int32_t I) { return ((size_t)U + (size_t)I) * sizeof(int); }
+extern "C" size_t rbr_dedup_ws_bytes(int32_t U, int32_t I) { return (U > 0 && I > 0) ? ((size_t)U + (size_t)I) * sizeof(int) : 0; }
 
 extern "C" int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const int64_t* i_ids, int32_t U, int32_t I,
                               const uint8_t* mask_in, void* ws, int64_t* first, uint8_t* mask_out, void* stream) {

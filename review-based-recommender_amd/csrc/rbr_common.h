@@ -18,6 +18,8 @@ constexpr int kMaxTiles = 8;     // channel tiles per launch (8 x 16 accumulator
 constexpr int kMaxGroups = 32;   // launches per conv (<= 5 tiles = 160 channel slots each)
 constexpr int kMaxSlots = kMaxTiles * kTile;
 constexpr int kMaxKF = 9;        // widest conv window
+constexpr int kMaxDim = 1 << 14;      // embedding dimension a descriptor may name
+constexpr int kMaxChannels = kMaxGroups * kMaxTiles * kTile;      // output channels of one conv call (8192)
 constexpr int kMaxPieces = kMaxTiles * kMaxKF;
 constexpr int kWavesPerWG = 4;
 constexpr int kSchedCounters = 64;   // ints behind the work list: [0] active tiles, [1 + g] item counter of group g
@@ -69,6 +71,7 @@ void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // Builds the launch plans for `d`.  Returns the number of groups (0 on error, see rbr_last_error()).
+bool desc_valid(const rbr_textcnn_desc* d);      // shape / range validation of a descriptor (sets the error text)
 int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans /* [kMaxGroups] */, int tiles_per_group = 5);
 constexpr int kProdGroupTiles = 8;   // channel tiles per work item of the token-product GEMM (textcnn_prod.hip)
 

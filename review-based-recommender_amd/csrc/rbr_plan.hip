@@ -21,22 +21,33 @@ int check_hip(hipError_t e, const char* what) {
     return (int)e;
 }
 
-static bool validate(const rbr_textcnn_desc* d) {
+// Every entry point that takes a descriptor goes through this before it reads d->kz / d->ch or multiplies shapes: the limits
+// keep all index arithmetic of plans, layouts and grids inside int / long (tests/asan_fuzz_host.py throws hostile descriptors at
+// a sanitizer build of this code).
+bool desc_valid(const rbr_textcnn_desc* d) {
     if (!d) { set_error("null descriptor"); return false; }
     if (d->n_docs <= 0 || d->L <= 0 || d->D <= 0 || d->V <= 0) {
         set_error("bad shape n_docs=%d L=%d D=%d V=%d", d->n_docs, d->L, d->D, d->V);
         return false;
     }
+    if (d->D > kMaxDim || (long)d->n_docs * d->L >= (1L << 31)) {
+        set_error("shape out of range: D=%d (max %d), n_docs * L = %ld (max 2^31 - 1)", d->D, kMaxDim, (long)d->n_docs * d->L);
+        return false;
+    }
     if (d->n_widths <= 0 || d->n_widths > RBR_MAX_WIDTHS) { set_error("n_widths=%d out of range", d->n_widths); return false; }
+    long c_total = 0;
     for (int w = 0; w < d->n_widths; ++w) {
         if (d->kz[w] <= 0 || d->kz[w] > kMaxKF) { set_error("kernel width %d unsupported (1..%d)", d->kz[w], kMaxKF); return false; }
-        if (d->ch[w] <= 0) { set_error("bank %d has %d channels", w, d->ch[w]); return false; }
+        if (d->ch[w] <= 0 || d->ch[w] > kMaxChannels) { set_error("bank %d has %d channels (1..%d)", w, d->ch[w], kMaxChannels); return false; }
+        c_total += d->ch[w];
         // the reference asserts odd widths for 'same' convs (deepconn/layers.py:39)
         if (d->pad_mode == RBR_PAD_SAME && d->kz[w] % 2 == 0) { set_error("'same' conv needs odd kernel width, got %d", d->kz[w]); return false; }
         if (d->pad_mode == RBR_PAD_VALID && d->kz[w] > d->L) { set_error("valid conv wider than the document"); return false; }
     }
+    if (c_total > kMaxChannels) { set_error("%ld output channels (max %d)", c_total, kMaxChannels); return false; }
     if (d->pad_mode != RBR_PAD_SAME && d->pad_mode != RBR_PAD_VALID) { set_error("pad_mode %d", d->pad_mode); return false; }
     if (d->act != RBR_ACT_RELU && d->act != RBR_ACT_TANH) { set_error("act %d", d->act); return false; }
+    if (d->padding_idx >= d->V) { set_error("padding_idx %d outside a table of %d rows", d->padding_idx, d->V); return false; }
     if (RBR_CONV_GATE_SPLIT_OF(d->flags) >= d->n_widths) {
         set_error("RBR_CONV_GATE_SPLIT(%d) with %d banks", RBR_CONV_GATE_SPLIT_OF(d->flags), d->n_widths);
         return false;
@@ -47,7 +58,7 @@ static bool validate(const rbr_textcnn_desc* d) {
 // Channel slots are ordered by ascending kernel width and cut into tiles of 32: a tile then only
 // streams the taps its widest member needs (3/5/7 x 50 channels -> 27 tap-tiles instead of 30).
 int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans, int tiles_per_group) {
-    if (!validate(d)) return 0;
+    if (!desc_valid(d)) return 0;
     int C = 0, KF = 0;
     int ch_off[RBR_MAX_WIDTHS];
     for (int w = 0; w < d->n_widths; ++w) { ch_off[w] = C; C += d->ch[w]; KF = std::max(KF, d->kz[w]); }

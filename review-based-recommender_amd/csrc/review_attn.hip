@@ -294,8 +294,9 @@ extern "C" int rbr_review_attn2_fwd(int32_t B, int32_t R, int32_t H, int32_t A, 
 }
 
 extern "C" size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t A) {
+    if (B <= 0 || R <= 0 || H <= 0 || A <= 0) return 0;
     const size_t chunks = ((size_t)B * R + kRedRows - 1) / kRedRows;
-    return (size_t)B * R * A + (size_t)B * R + chunks * ((size_t)H * A + (size_t)A * A + 2 * A + 1);
+    return (size_t)B * R * A + (size_t)B * R + chunks * ((size_t)H * A + (size_t)A * A + 2 * (size_t)A + 1);
 }
 
 // the three stages of the backward for `sides` (1 or 2) sides

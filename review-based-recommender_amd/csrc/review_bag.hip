@@ -507,6 +507,7 @@ extern "C" int rbr_additive_attn_fwd(int32_t B, int32_t R, int32_t H, int32_t K,
 }
 
 extern "C" size_t rbr_additive_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t K) {
+    if (B <= 0 || R <= 0 || H <= 0 || K <= 0) return 0;
     return (size_t)B * R * K + (size_t)B * R * H;          // d_pre | x (node dropout applied)
 }
 

@@ -992,6 +992,7 @@ bool prod_applicable(const rbr_textcnn_desc* d) {
     static const char* env = getenv("RBR_CONV_MODE");
     const char* mode = g_conv_mode == 1 ? "dense" : g_conv_mode == 2 ? "product" : g_conv_mode == 0 ? nullptr : env;
     if (mode && !strcmp(mode, "dense")) return false;
+    if (!desc_valid(d)) return false;                      // nothing below may index d->kz / d->ch of an unchecked descriptor
     const long n_pos = (long)d->n_docs * d->L;
     long Cp = 0;
     for (int w = 0; w < d->n_widths; ++w) Cp += (long)d->kz[w] * d->ch[w];
@@ -1690,7 +1691,7 @@ extern "C" int rbr_textcnn_dtable_from_taps(const rbr_textcnn_desc* d, int32_t n
 }
 
 extern "C" int32_t rbr_textcnn_taps_owner_rows(const rbr_textcnn_desc* d, int32_t n_sets) {
-    return (d && n_sets > 0) ? (d->V + n_sets - 1) / n_sets : 0;
+    return (d && d->V > 0 && n_sets > 0) ? (int32_t)(((long)d->V + n_sets - 1) / n_sets) : 0;
 }
 
 extern "C" int rbr_textcnn_dtable_from_taps_owner(const rbr_textcnn_desc* d, int32_t n_sets, int32_t rank, const int32_t* tok,

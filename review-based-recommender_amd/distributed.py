@@ -69,6 +69,8 @@ class TapExchange:
         self.owner = bool(owner)
         self.optimizer = optimizer
         self.slabs = self.row_map = self.sq = self.overflow = None
+        self.overflow_fallbacks = 0   # owner mode: steps whose gradient was rebuilt on every rank because an owner's share overflowed
+        self._test_force_overflow = False
         self.n = 0
         self.tok = self.val = self.dtable = self.ws = None
         self.desc = self.weights = None
@@ -181,6 +183,7 @@ class TapExchange:
                                   device=dev)
         v_own = self.v_own
         own = self.slabs[self.rank]
+        self.overflow.zero_()                      # the flag is sticky inside the library: per step here
         _lib.check(L_.rbr_textcnn_dtable_from_taps_owner(C.byref(self.desc), self.world, self.rank,
                                                          _lib.dev_ptr(self.tok, torch.int32, "tap tokens"),
                                                          _lib.dev_ptr(self.val, torch.float32, "tap values"),
@@ -188,15 +191,43 @@ class TapExchange:
                                                          self.ws.data_ptr(), _lib.dev_ptr(own, torch.float32, "slab"),
                                                          _lib.dev_ptr(self.overflow, torch.int32, "overflow"),
                                                          _lib.current_stream()), "rbr_textcnn_dtable_from_taps_owner")
+        if self._test_force_overflow:              # tests only: exercise the fallback protocol at world sizes that cannot overflow
+            self.overflow.fill_(1)
         rows = own[:v_own]
         own[v_own, 0] = torch.linalg.vector_norm(rows).square()
+        own[v_own, 1] = self.overflow[0].to(torch.float32)      # the rank's overflow flag travels with its slab
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(self.slabs.view(-1), own.reshape(-1), group=self.group)      # in place: own is its slice
         else:
             dist.all_gather(list(self.slabs.view(self.world, -1).unbind(0)), own.reshape(-1).clone(), group=self.group)
+        dense_part = self.table.grad if self.calls > 1 else None      # a second conv's part, already averaged densely
+        # A rank that owned more taps than its sort is sized for (twice the even share: the Zipf head on one owner) dropped the
+        # surplus: its slab is incomplete.  Every rank reads the SAME gathered flags, so all of them take the same branch -- no
+        # rank is left waiting at a collective -- and rebuild this step's gradient the replicated way from the taps they already
+        # hold (bit-identical on every rank).  The read is a host synchronisation per step: the price of the owner mode's
+        # smaller sort, paid only in that mode.
+        if bool((self.slabs[:, v_own, 1] != 0).any().item()):
+            self.overflow_fallbacks += 1
+            if self.overflow_fallbacks == 1 and self.rank == 0:
+                print("[TapExchange] owner rebuild: a rank owned more taps than twice the even share; this step (and any like it) "
+                      "rebuilds the word-table gradient on every rank instead", flush=True)
+            if self.dtable is None:
+                self.dtable = torch.empty_like(self.table)
+            _lib.check(L_.rbr_textcnn_dtable_from_taps(C.byref(self.desc), self.world, _lib.dev_ptr(self.tok, torch.int32, "tap tokens"),
+                                                       _lib.dev_ptr(self.val, torch.float32, "tap values"),
+                                                       _lib.ptr_array(self.weights, torch.float32, "conv weight"),
+                                                       self.ws.data_ptr(), _lib.dev_ptr(self.dtable, torch.float32, "dtable"),
+                                                       _lib.current_stream()), "rbr_textcnn_dtable_from_taps")
+            if dense_part is not None and dense_part is not self.dtable:
+                self.dtable.add_(dense_part)
+            if self.optimizer is not None and hasattr(self.optimizer, "_row_grads"):
+                self.optimizer._row_grads.pop(self.table, None)       # a previous step's exchanged rows must not be read again
+            self.table.grad = self.dtable
+            self.desc = self.weights = None
+            self.calls = 0
+            return
         self.sq.copy_(self.slabs[:, v_own, 0])
         rg = RF.RowGradient(self.table, self.slabs.view(-1, D), self.sq, self.row_map.data_ptr(), (self.row_map, self.slabs))
-        dense_part = self.table.grad if self.calls > 1 else None      # a second conv's part, already averaged densely
         taken = False
         if dense_part is None and self.optimizer is not None and hasattr(self.optimizer, "put_exchanged_rows"):
             taken = self.optimizer.put_exchanged_rows(self.table, rg)
@@ -207,11 +238,10 @@ class TapExchange:
         self.calls = 0
 
     def check(self) -> None:
-        """Owner mode: raises if some step's taps exceeded the bound the owner's sort is sized for (a synchronisation point:
-        call it where the trainer reads the loss anyway)."""
-        if self.overflow is not None and int(self.overflow.item()) != 0:
-            raise RuntimeError("TapExchange(owner): a rank owned more taps than twice the even share; that step's table "
-                               "gradient was incomplete -- use the replicated rebuild or the dense all-reduce for this data")
+        """Owner mode: kept for callers of earlier rounds.  An overflowing step no longer leaves a wrong gradient behind --
+        _finish_owner detects it on every rank from the gathered flags and rebuilds the replicated way -- so there is nothing
+        left to raise; `overflow_fallbacks` counts such steps."""
+        return None
 
 
 class GradAllReduce:

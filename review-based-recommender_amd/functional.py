@@ -4,6 +4,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -368,9 +369,7 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
     acc = _table_acc(S.fanout_acc, dev) if (need_table and bws_bytes) else None
     # compact row gradient: the optimizer that asked for it takes the rows of the batch's tokens, nobody writes (or later
     # reads) the zero rows of a dense [V, D] gradient
-    row_sink = _ROW_GRAD_SINKS.get(table.data_ptr()) if (need_table and bws_bytes and gate is None and acc is None) else None
-    if row_sink is not None and not row_sink.wants_row_grad(table):
-        row_sink = None
+    row_sink = _row_grad_sink_for(table) if (need_table and bws_bytes and gate is None and acc is None) else None
     # the token-list backwards overwrite the whole table gradient; the window scatter accumulates into zeros
     dtable = None
     if need_table and row_sink is None:
@@ -478,9 +477,12 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
                     join = torch.cuda.Event()
                     join.record()
             if need_table:
+                ev3 = TIMER.record("textcnn_bwd_g_product")
                 check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), None, None, None, None, None, None, S.prod_ws.data_ptr(),
                                                         bws.data_ptr(), dev_ptr(out, F32, "dtable"), None, dev_ptr(sq, F32, "sq_part"),
                                                         _lib.G_PRODUCT | (flags & _lib.G_ROWS), st), "rbr_textcnn_bwd_g_product")
+                if ev3 is not None:
+                    ev3.record()
             if ev is not None:
                 ev.record()
             _join(join)
@@ -488,12 +490,29 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
             if acc is not None:          # shared gradient buffer of the step (table_fanout): rows added, buffer handed back
                 dtable = out = acc
                 flags |= _lib.G_ACCUMULATE
-            check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
-                                                    dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
-                                                    dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
-                                                    S.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(out, F32, "dtable"),
-                                                    dev_ptr(dgate, F32, "dgate"), dev_ptr(sq, F32, "sq_part"),
-                                                    _lib.G_BUILD | _lib.G_PRODUCT | flags, st), "rbr_textcnn_bwd_dtable_prod")
+            if ev is not None and out is not None:
+                # timing pass (bench.py): the call's two phases as two calls, so that the sparse product (ONE launch,
+                # g_times_w) gets HIP events of its own -- same kernels, same order, same arguments
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                        dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                        dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                        S.prod_ws.data_ptr(), bws.data_ptr(), None, dev_ptr(dgate, F32, "dgate"),
+                                                        None, _lib.G_BUILD | (flags & _lib.G_ZEROED), st), "rbr_textcnn_bwd_g_build")
+                ev.record()
+                ev = TIMER.record("textcnn_bwd_g_product")
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), None, None, None, None, None, None, S.prod_ws.data_ptr(),
+                                                        bws.data_ptr(), dev_ptr(out, F32, "dtable"), None, dev_ptr(sq, F32, "sq_part"),
+                                                        _lib.G_PRODUCT | (flags & (_lib.G_ROWS | _lib.G_ACCUMULATE)), st),
+                      "rbr_textcnn_bwd_g_product")
+                ev.record()
+                ev = None
+            else:
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), dev_ptr(ids, I64, "ids"), dev_ptr(mask8, U8, "mask"),
+                                                        dev_ptr(gate, F32, "gate"), dev_ptr(feat, F32, "feat"),
+                                                        dev_ptr(argmax, I32, "argmax"), dev_ptr(d_feat, F32, "d_feat"),
+                                                        S.prod_ws.data_ptr(), bws.data_ptr(), dev_ptr(out, F32, "dtable"),
+                                                        dev_ptr(dgate, F32, "dgate"), dev_ptr(sq, F32, "sq_part"),
+                                                        _lib.G_BUILD | _lib.G_PRODUCT | flags, st), "rbr_textcnn_bwd_dtable_prod")
             if ev is not None:
                 ev.record()
             _join(run_dw())
@@ -524,17 +543,34 @@ def _textcnn_backward(S, d_feat, need_table: bool, need_gate: bool):
 
 
 # ---- compact row gradient of an embedding table (consumer: train_step.HipClipAdam) ------------------------------------------
-_ROW_GRAD_SINKS: dict = {}      # word-table data_ptr -> sink: wants_row_grad(table) -> bool, put_row_grad(table, RowGradient)
+# word-table data_ptr -> weakref of the sink: wants_row_grad(table) -> bool, put_row_grad(table, RowGradient).  Weak: a registry
+# entry never keeps an optimizer (and with it the parameters and Adam state it holds) alive, and a sink that was dropped
+# without being unregistered simply disappears (the backward then produces the dense gradient again).
+_ROW_GRAD_SINKS: dict = {}
 
 
 def set_row_grad_sink(table: torch.Tensor, sink) -> None:
-    """Registers `sink` (None: removes it) for the gradient of `table` in compact row form: the token-product conv's backward
-    then hands sink.put_row_grad(table, RowGradient) the rows of the batch's tokens and returns no dense [V, D] gradient
-    (table.grad stays None until someone calls RowGradient.to_dense())."""
+    """Registers `sink` (None: removes it) for the gradient of `table` in compact row form.  A conv backward over `table` hands
+    sink.put_row_grad(table, RowGradient) the rows of the batch's tokens and returns no dense [V, D] gradient ONLY while
+    sink.wants_row_grad(table) answers True for that backward -- the sink says per step whether it is the one that will consume
+    the gradient (train_step.HipClipAdam: inside its row_grad_scope(), which train_step() / GraphedTrainStep open around the
+    forward + backward of a step this optimizer drives).  Every other backward gets the ordinary dense gradient."""
     if sink is None:
         _ROW_GRAD_SINKS.pop(table.data_ptr(), None)
     else:
-        _ROW_GRAD_SINKS[table.data_ptr()] = sink
+        _ROW_GRAD_SINKS[table.data_ptr()] = weakref.ref(sink)
+
+
+def _row_grad_sink_for(table: torch.Tensor):
+    """The live sink that wants THIS backward's gradient of `table` in row form, or None."""
+    ref = _ROW_GRAD_SINKS.get(table.data_ptr())
+    if ref is None:
+        return None
+    sink = ref()
+    if sink is None:                                   # the optimizer is gone: forget the entry
+        _ROW_GRAD_SINKS.pop(table.data_ptr(), None)
+        return None
+    return sink if sink.wants_row_grad(table) else None
 
 
 class RowGradient:
@@ -741,10 +777,14 @@ _TICKETS: dict = {}
 
 
 def _ticket(dev) -> torch.Tensor:
+    """Arrival counter of rbr_pair_head_fwd_pool's MSE reduction (the last pair block to arrive sums the loss and puts the counter
+    back to 0): one per (device, STREAM) -- launches on one stream are ordered, so they may share it; two fused heads in flight
+    on different streams (a side-stream eval beside a training step, a graph replay beside an eager step) must not."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    t = _TICKETS.get(idx)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    t = _TICKETS.get(key)
     if t is None:
-        t = _TICKETS[idx] = torch.zeros(4, dtype=I32, device=dev)
+        t = _TICKETS[key] = torch.zeros(4, dtype=I32, device=dev)
     return t
 
 

@@ -59,14 +59,18 @@ class HipClipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = LR, betas=(0.9, 0.999), eps: float = 1e-8, row_grads: bool = True):
         """row_grads: embedding tables among the parameters (2-D, >= ROW_GRAD_MIN_ROWS rows, row length % 4 == 0) receive the
         gradient of a token-product conv as the rows of the batch's tokens (functional.RowGradient) instead of a dense
-        [V, D] tensor whose other rows are zeros: `.grad` of such a table stays None after backward -- call
-        materialize_grads() to see the dense gradient -- and the clip + Adam launches neither read nor re-write the zero rows.
-        Same parameters and state as with the dense gradient, bit for bit."""
+        [V, D] tensor whose other rows are zeros -- but only for a backward that runs inside this optimizer's row_grad_scope()
+        (train_step() and GraphedTrainStep open it around the forward + backward of a step THIS optimizer will finish): `.grad`
+        of such a table then stays None after backward -- call materialize_grads() to see the dense gradient -- and the clip +
+        Adam launches neither read nor re-write the zero rows.  Same parameters and state as with the dense gradient, bit for
+        bit.  Outside the scope (a hand-written loop, another optimizer on the same model, an external clip_grad_norm_) every
+        backward leaves the ordinary dense .grad."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._ws = None
         self._gnorm = None
         self._row_grads = {}          # parameter -> functional.RowGradient of the last backward
         self._row_tables = []
+        self._row_scope = 0           # > 0: inside row_grad_scope() -- the only time wants_row_grad() says yes
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             row_grads = False         # a data-parallel exchange reads every gradient as a dense .grad
@@ -82,7 +86,19 @@ class HipClipAdam(torch.optim.Optimizer):
 
     # ---- functional.set_row_grad_sink protocol
     def wants_row_grad(self, table) -> bool:
-        return any(table.data_ptr() == p.data_ptr() for p in self._row_tables)
+        return self._row_scope > 0 and any(table.data_ptr() == p.data_ptr() for p in self._row_tables)
+
+    @contextlib.contextmanager
+    def row_grad_scope(self):
+        """with opt.row_grad_scope(): forward; loss.backward() -- the caller's promise that THIS optimizer's clip_and_step() /
+        step() is what consumes the gradients of that backward: its tables then receive their gradient in compact row form.
+        (The registry in functional holds the optimizer weakly and asks wants_row_grad() per backward, so an optimizer that
+        merely exists -- beside torch's Adam on the same model, or after its last step -- changes nothing.)"""
+        self._row_scope += 1
+        try:
+            yield self
+        finally:
+            self._row_scope -= 1
 
     def put_row_grad(self, table, rg) -> None:
         p = next(q for q in self._row_tables if q.data_ptr() == table.data_ptr())
@@ -199,7 +215,10 @@ class HipClipAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        """Plain Adam step (no clipping), for callers that clip separately."""
+        """Plain Adam step (no clipping), for callers that clip separately: `loss.backward(); clip_grad_norm_(...); opt.step()`
+        sees every gradient as a dense .grad, because a backward outside row_grad_scope() never produces the row form.  Should
+        rows be pending all the same (the caller opened the scope and then clipped by hand), they are made dense here first --
+        late for that clip, which is why the scope is train_step()'s business and not a default."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -221,7 +240,7 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     (NARRE: pred, u_att, i_att) contribute their first element.  `grad_sync(model)` is the
     data-parallel gradient all-reduce hook (None on one GPU).  Returns (loss, gnorm, pred) tensors."""
     optimizer.zero_grad()
-    pred, loss = _forward_loss_backward(model, batch, ratings)
+    pred, loss = _forward_loss_backward(model, batch, ratings, optimizer if grad_sync is None else None)
     if grad_sync is not None:
         if isinstance(optimizer, HipClipAdam):
             optimizer.materialize_grads()        # the all-reduce wants every gradient as a dense .grad
@@ -230,18 +249,22 @@ def train_step(model: nn.Module, optimizer: torch.optim.Optimizer, batch, rating
     return loss.detach(), gnorm, pred.detach()
 
 
-def _forward_loss_backward(model: nn.Module, batch, ratings: torch.Tensor):
+def _forward_loss_backward(model: nn.Module, batch, ratings: torch.Tensor, optimizer=None):
     """y = model(*batch); loss = MSELoss()(y, ratings); loss.backward()  (train_deepconn_pp.py:162-165).  The target is
-    announced to the forward (functional.fused_loss): a model whose last launch can compute the loss takes it along."""
+    announced to the forward (functional.fused_loss): a model whose last launch can compute the loss takes it along.
+    `optimizer`: the optimizer whose step follows this backward; a HipClipAdam then takes its tables' gradients in compact row
+    form (its row_grad_scope() is open for exactly this forward + backward)."""
+    scope = optimizer.row_grad_scope() if isinstance(optimizer, HipClipAdam) else contextlib.nullcontext()
     fusable = ratings.is_cuda and ratings.dtype == torch.float32
-    with (RF.fused_loss(ratings) if fusable else contextlib.nullcontext()) as req:
-        out = model(*batch)
-        pred = out[0] if isinstance(out, tuple) else out
-        loss = req.loss_for(pred) if req is not None else None
-    if loss is not None:
-        loss.backward(RF.unit_scalar(pred.device))
-        return pred, loss
-    return pred, _loss_and_backward(pred, ratings)
+    with scope:
+        with (RF.fused_loss(ratings) if fusable else contextlib.nullcontext()) as req:
+            out = model(*batch)
+            pred = out[0] if isinstance(out, tuple) else out
+            loss = req.loss_for(pred) if req is not None else None
+        if loss is not None:
+            loss.backward(RF.unit_scalar(pred.device))
+            return pred, loss
+        return pred, _loss_and_backward(pred, ratings)
 
 
 def _loss_and_backward(pred: torch.Tensor, ratings: torch.Tensor) -> torch.Tensor:
@@ -346,6 +369,26 @@ class GraphedForward:
         return self.pred
 
 
+def _count_kernel_nodes(graph: torch.cuda.CUDAGraph) -> int:
+    """hipGraphGetNodes + hipGraphNodeGetType over the captured hipGraph_t (kernel nodes only: type 0)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    g = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (C.c_void_p * max(1, n.value))()
+    if hip.hipGraphGetNodes(g, nodes, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    kernels = 0
+    for k in range(n.value):
+        ty = C.c_int(-1)
+        if hip.hipGraphNodeGetType(C.c_void_p(nodes[k]), C.byref(ty)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        kernels += int(ty.value == 0)          # hipGraphNodeTypeKernel
+    return kernels
+
+
 class _StepSlot:
     """One input block of a GraphedTrainStep and the graph(s) recorded over it."""
     __slots__ = ("flat", "batch", "ratings", "g_fwd_bwd", "g_update", "static_grads", "loss", "gnorm", "pred")
@@ -370,12 +413,13 @@ class GraphedTrainStep:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer, batch, ratings: torch.Tensor,
                  max_grad_norm: float = MAX_GRAD_NORM, grad_sync=None, warmup: int = 3, capture_error_mode: str | None = None,
-                 slots: int = 1):
+                 slots: int = 1, keep_graph: bool = False):
         if not ratings.is_cuda:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         if slots < 1:
             raise ValueError("slots must be >= 1")
         self.model, self.optimizer, self.grad_sync, self.max_grad_norm = model, optimizer, grad_sync, max_grad_norm
+        self._keep_graph = bool(keep_graph)      # keeps the hipGraph_t behind the executable: kernel_launches() can count its nodes
         # every input of the step lives in ONE block (`flat`): a loader hands over a batch with a single device-to-device
         # (or host-to-device) copy, and the two towers' inputs are neighbours, so the models stack them as a view
         self._layout = _flat_layout(list(batch) + [ratings])
@@ -407,7 +451,7 @@ class GraphedTrainStep:
         mode = capture_error_mode or ("thread_local" if grad_sync is not None else "global")
         for sl in self._slots:
             optimizer.zero_grad(set_to_none=True)
-            sl.g_fwd_bwd = torch.cuda.CUDAGraph()
+            sl.g_fwd_bwd = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
             if grad_sync is None:
                 with torch.cuda.graph(sl.g_fwd_bwd, capture_error_mode=mode):
                     sl.loss, sl.gnorm, sl.pred = train_step(model, optimizer, sl.batch, sl.ratings, max_grad_norm)
@@ -421,7 +465,7 @@ class GraphedTrainStep:
                         optimizer.materialize_grads()
                 grad_sync(model)
                 sl.static_grads = [(p, p.grad) for p in model.parameters()]
-                sl.g_update = torch.cuda.CUDAGraph()
+                sl.g_update = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
                 with torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), capture_error_mode=mode):
                     sl.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
@@ -450,6 +494,15 @@ class GraphedTrainStep:
     @property
     def slots(self) -> int:
         return len(self._slots)
+
+    def kernel_launches(self, slot: int = 0):
+        """Kernel nodes of the recorded step (slot `slot`: forward + backward [+ the update graph of a data-parallel step]): what
+        one replay launches.  Needs keep_graph=True at construction; None when the runtime does not hand the graph out."""
+        sl = self._slots[slot]
+        try:
+            return sum(_count_kernel_nodes(g) for g in (sl.g_fwd_bwd, sl.g_update) if g is not None)
+        except Exception:
+            return None
 
     def slot_inputs(self, slot: int = 0):
         """(batch views, ratings view, the whole block as uint8) of input slot `slot`: what a loader writes into."""

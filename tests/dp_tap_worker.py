@@ -111,6 +111,29 @@ def main():
     if owner:
         sync_t.tap.check()
         assert m_t.word_embeddings.embedding.weight.grad is None, "owner mode: the optimizer reads the exchanged rows in place"
+        # an owner whose share of the taps overflows its sort must not leave a wrong gradient behind, and no
+        # rank may hang.  ONE rank raises the flag here (two ranks cannot overflow for real: the sort is sized for twice the even
+        # share; the kernel-side flag is tested in test_rebuild_from_taps_matches_float64_reference_and_is_order_free): the flag
+        # travels with the slab, BOTH ranks rebuild the step the replicated way, and the step equals the dense data-parallel one.
+        assert sync_t.tap.overflow_fallbacks == 0
+        sync_t.tap._test_force_overflow = (rank == 1)
+        with torch.no_grad():
+            for pd, pt in zip(m_d.parameters(), m_t.parameters()):
+                pt.copy_(pd)
+        a5, r5 = batch(60 + rank)
+        m_d.zero_grad(); o_t.zero_grad()
+        F.mse_loss(m_d(*a5), r5).backward()
+        sync_d(m_d)
+        F.mse_loss(m_t(*a5), r5).backward()
+        sync_t(m_t)
+        torch.cuda.synchronize()
+        assert sync_t.tap.overflow_fallbacks == 1, "every rank must take the fallback when any rank's flag is up"
+        gt = m_t.word_embeddings.embedding.weight.grad
+        assert gt is not None and len(o_t._row_grads) == 0, "the fallback hands over a dense gradient"
+        gd = m_d.word_embeddings.embedding.weight.grad
+        assert float((gt - gd).abs().max()) <= 1e-6 + 2e-5 * float(gd.abs().max())
+        o_t.clip_and_step(5.0)                                 # and the optimizer takes it (dense path)
+        sync_t.tap._test_force_overflow = False
     RF.set_tap_sink(None)
     dist.barrier()
     if rank == 0:

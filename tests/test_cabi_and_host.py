@@ -177,3 +177,41 @@ def test_product_library_holds_no_wrong_result_switches():
     blob = open(lib, "rb").read()
     for name in (b"RBR_DEV_DX_ABLATE", b"RBR_DEV_DX_WIN", b"RBR_DEV_CONV_EXTRA_LDS", b"RBR_DEV_GENERIC_GEMM"):
         assert name not in blob, name
+
+
+def test_row_gradient_hand_off_is_scoped_and_weak():
+    """the compact-row-gradient registry must not (a) keep an optimizer alive, (b) answer for an optimizer that
+    merely exists.  functional keeps a weak reference and asks wants_row_grad() per backward; HipClipAdam says yes only inside
+    its row_grad_scope() (opened by train_step() / GraphedTrainStep around the forward + backward it will finish)."""
+    import gc
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd.train_step import HipClipAdam
+
+    class Sink:
+        def __init__(self):
+            self.armed = False
+
+        def wants_row_grad(self, table):
+            return self.armed
+
+    table = torch.zeros(8, 4)
+    s = Sink()
+    RF.set_row_grad_sink(table, s)
+    assert RF._row_grad_sink_for(table) is None            # registered, not armed: the backward stays dense
+    s.armed = True
+    assert RF._row_grad_sink_for(table) is s
+    del s
+    gc.collect()
+    assert RF._row_grad_sink_for(table) is None            # the registry did not keep it alive ...
+    assert table.data_ptr() not in RF._ROW_GRAD_SINKS      # ... and forgot the dead entry
+
+    p = torch.nn.Parameter(torch.zeros(HipClipAdam.ROW_GRAD_MIN_ROWS, 4))
+    opt = HipClipAdam([p])                                  # a CPU parameter registers nothing, but the scope logic is host-only
+    opt._row_tables.append(p)
+    assert not opt.wants_row_grad(p)
+    with opt.row_grad_scope():
+        assert opt.wants_row_grad(p)
+        with opt.row_grad_scope():
+            assert opt.wants_row_grad(p)
+        assert opt.wants_row_grad(p)
+    assert not opt.wants_row_grad(p)

@@ -71,7 +71,7 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
         for step in range(3):
             args, r = _batch(cfg, 3 + step, edge=(cfgname == "small"))
             oa.zero_grad()
-            _forward_loss_backward(ma, args, r)
+            _forward_loss_backward(ma, args, r, oa)
             assert table_a.grad is None and table_a in oa._row_grads, "the compact row gradient was not handed over"
             dense = oa._row_grads[table_a].to_dense()
             # what the dense backward computes: the same rows, zeros elsewhere (checked against a second, dense backward)
@@ -103,6 +103,47 @@ def test_row_gradient_equals_the_dense_gradient_bit_for_bit(cfgname):
         oa.close()
     finally:
         _lib.lib().rbr_set_conv_mode(0)
+
+
+def test_hipclipadam_then_torch_adam_on_one_model_updates_the_table():
+    """a HipClipAdam that exists beside another optimizer on the same model must not swallow the word-table
+    gradient.  Two graph-replayed HipClipAdam steps, then eager clip_grad_norm_ + torch.optim.Adam steps on the SAME model
+    (tools/bench_models.py's order), against a fresh model that takes the same batches through HipClipAdam (eager) and torch Adam:
+    after every torch step the table has moved, with the gradient of THAT batch (not one batch stale)."""
+    from review_based_recommender_amd.train_step import GraphedTrainStep, make_optimizer, train_step
+    cfg = synth.DEEPCONN_CFGS["cfg1"]
+    keep_rows = None
+    from review_based_recommender_amd.train_step import HipClipAdam
+    keep_rows, HipClipAdam.ROW_GRAD_MIN_ROWS = HipClipAdam.ROW_GRAD_MIN_ROWS, 1
+    try:
+        ma, mb = _deepconn(cfg), _deepconn(cfg)
+        ma.train(); mb.train()
+        ta, tb = ma.word_embeddings.embedding.weight, mb.word_embeddings.embedding.weight
+        batches = [_batch(cfg, 30 + k) for k in range(5)]
+        ga = make_optimizer(ma, hip_clip_adam=True)
+        stepper = GraphedTrainStep(ma, ga, *batches[0])
+        gb = make_optimizer(mb, hip_clip_adam=True)
+        for k in range(2):
+            stepper(*batches[k])
+            train_step(mb, gb, *batches[k])
+        torch.cuda.synchronize()
+        assert float((ta - tb).abs().max()) <= 2.5e-3          # (+-lr steps on rounding-level gradients, as everywhere)
+        # ga stays alive, as in tools/bench_models.py; the eager steps belong to torch's Adam
+        oa, ob = make_optimizer(ma), make_optimizer(mb)
+        for k in range(2, 5):
+            before = ta.detach().clone()
+            train_step(ma, oa, *batches[k])
+            assert ta.grad is not None, "the backward of a torch-Adam step must leave a dense table gradient"
+            train_step(mb, ob, *batches[k])
+            torch.cuda.synchronize()
+            assert float((ta.grad - tb.grad).abs().max()) <= 2e-6 + 2e-3 * float(tb.grad.abs().max()), k
+            moved_a, moved_b = (ta.detach() - before).abs().sum(1) > 0, tb.grad.abs().sum(1) > 0
+            # the rows of THIS batch moved (a fresh Adam moves an element by ~lr wherever its gradient is not vanishingly small)
+            assert not bool((moved_a & ~moved_b).any()) and int(moved_a.sum()) >= 0.98 * int(moved_b.sum()) > 0, \
+                (k, int(moved_a.sum()), int(moved_b.sum()))
+        del stepper
+    finally:
+        HipClipAdam.ROW_GRAD_MIN_ROWS = keep_rows
 
 
 @pytest.mark.parametrize("cfgname,edge", [("small", True), ("cfg1", False), ("cfg2", False)])
