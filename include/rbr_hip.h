@@ -73,6 +73,24 @@ typedef struct rbr_textcnn_desc {
 int rbr_version(void);
 const char* rbr_last_error(void);
 
+/* ---- Pair regions: two independent problems of EQUAL SHAPES through shared launches.
+ * D-ATT's two towers (reference models/dual_att/dual_att.py:45-57: separate parameters and documents, the same op sequence)
+ * are ~40 mostly short kernels each.  Between rbr_pair_begin() and rbr_pair_end() the entry points of this library that launch
+ * through rbr::launch (csrc/rbr_launch.h: every kernel of the D-ATT step -- gates, the token-product conv chain and its backward
+ * -- and the zero fills) do not launch: they RECORD their launches, for problem 0 until rbr_pair_next(), then for problem 1.
+ * rbr_pair_end() zips the two lists: launches i of both problems that are the same kernel over the same grid leave as ONE
+ * launch with gridDim.z = 2 (a workgroup takes its argument set by blockIdx.z); anything that does not line up is launched
+ * one by one in recorded order, so the results never depend on whether pairs formed -- only the launch count and the time do.
+ * Contract: inside a region (a) the two problems must not depend on each other, (b) nothing else may be enqueued on the
+ * streams involved (the recorded launches run at rbr_pair_end, not where they were called), (c) entry points that launch
+ * directly refuse with RBR_ERR_UNSUPPORTED.  The region is per host thread.  rbr_pair_abort() drops an open region (error
+ * paths).  n_paired / n_single (may be NULL): launches that left as pairs / singly.
+ * Reference counterpart: none (the reference runs the towers one after the other, dual_att.py:47-57). */
+int rbr_pair_begin(void);
+int rbr_pair_next(void);
+int rbr_pair_end(int32_t* n_paired, int32_t* n_single);
+void rbr_pair_abort(void);
+
 /* ---- TextCNN encoder: WordEmbedding + masked_tensor + MyConv1d + ReLU/Tanh + MaxPool1d(seq_len)
  *      replaces deepconn/layers.py:22-24 (embedding), deepconn/utils.py:49-61 (masked_fill),
  *      layers.py:46-60 (multi-width conv1d + cat), layers.py:107-109 (ReLU, MaxPool1d) and their

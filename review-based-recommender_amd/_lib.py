@@ -81,6 +81,10 @@ i32 = C.c_int32
 SIGNATURES = {
     "rbr_version": (C.c_int, []),
     "rbr_last_error": (C.c_char_p, []),
+    "rbr_pair_begin": (C.c_int, []),
+    "rbr_pair_next": (C.c_int, []),
+    "rbr_pair_end": (C.c_int, [C.POINTER(i32), C.POINTER(i32)]),
+    "rbr_pair_abort": (None, []),
     "rbr_textcnn_packed_floats": (C.c_size_t, [_DESC]),
     "rbr_textcnn_partial_elems": (C.c_size_t, [_DESC]),
     "rbr_textcnn_pack": (C.c_int, [_DESC, _PP, c_f32p, c_stream]),

@@ -70,7 +70,7 @@ constexpr int kGWin = 256, kGHash = 1024;
 constexpr int kGateWP = 8;       // floats per token row of the tap tables S / c of the token-product local gate (win <= 8)
 constexpr int kGateCopies = 16;  // private copies of the tap-sum table c (summed by gp_csum_kernel)
 
-__global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, int win, int is_global, int nwin,
+__device__ __forceinline__ void gate_bwd_dx_kernel(int B, int L, int E, int win, int is_global, int nwin,
                                                           const long long* __restrict__ ids, const float* __restrict__ w,
                                                           const float* __restrict__ wT, const float* __restrict__ gate,
                                                           const float* __restrict__ dgate, const float* __restrict__ dpre_g,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gate_bwd_dx_kernel(int B, int L, int E, i
 }
 
 // wT[l, e] = w[e, l]   (global gate: coalesced reads of the per-position weight columns)
-__global__ __launch_bounds__(256) void transpose_w_kernel(int E, int L, const float* __restrict__ w, float* __restrict__ wT) {
+__device__ __forceinline__ void transpose_w_kernel(int E, int L, const float* __restrict__ w, float* __restrict__ wT) {
     const long n = (long)E * L;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
         const int l = (int)(k / E), e = (int)(k % E);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void local_gate_bwd_reduce_kernel(int B, int E
 
 // ---------------------------------------------------------------------------------- global gate
 // one workgroup per document: thread l walks its token's row; w is the Conv1d weight [1, E, L]
-__global__ __launch_bounds__(256) void global_gate_fwd_kernel(int B, int L, int E, const long long* __restrict__ ids,
+__device__ __forceinline__ void global_gate_fwd_kernel(int B, int L, int E, const long long* __restrict__ ids,
                                                               const float* __restrict__ table, const float* __restrict__ w,
                                                               const float* __restrict__ b0, float* __restrict__ gate) {
     __shared__ float s_red[256];
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void global_gate_fwd_kernel(int B, int L, int 
 }
 
 // dpre[b] = (sum_l dgate[b,l]) * g (1-g)
-__global__ __launch_bounds__(256) void global_gate_bwd_dpre_kernel(int B, int L, const float* __restrict__ gate,
+__device__ __forceinline__ void global_gate_bwd_dpre_kernel(int B, int L, const float* __restrict__ gate,
                                                                    const float* __restrict__ dgate, float* __restrict__ dpre) {
     __shared__ float s_red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dpre_kernel(int B, int L,
 // dw[e, l] = sum_b dpre[b] * x[b,l,e]  (one workgroup per position l);  block L computes db0.  The 256 threads split
 // into document classes x embedding columns (E = 100: two classes), 8 independent row reads in flight per thread; the
 // classes meet in LDS in fixed order.
-__global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, int E, const long long* __restrict__ ids,
+__device__ __forceinline__ void global_gate_bwd_dw_kernel(int B, int L, int E, const long long* __restrict__ ids,
                                                                  const float* __restrict__ table, const float* __restrict__ dpre,
                                                                  float* __restrict__ dw, float* __restrict__ db0) {
     __shared__ float s_part[256];
@@ -460,11 +460,11 @@ __global__ __launch_bounds__(256) void global_gate_bwd_dw_kernel(int B, int L, i
 // `win` scalars per position from a table that lives in L2.  Backward: c[t][j] = sum of dpre over the positions whose tap j
 // lands on token t (LDS-bucketed per 256-position window, gate_bwd_dx_kernel's c_out mode), then
 //   dtable[t,:] = sum_j c[t][j] w[:,j]   (every row written once),   dw[:,j] = sum_t c[t][j] table[t,:],   db0 = sum_t c[t][pad].
-__global__ __launch_bounds__(256) void gp_mark_kernel(long n, const long long* __restrict__ ids, int* __restrict__ used) {
+__device__ __forceinline__ void gp_mark_kernel(long n, const long long* __restrict__ ids, int* __restrict__ used) {
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) used[ids[k]] = 1;
 }
 
-__global__ __launch_bounds__(256) void gp_compact_kernel(int V, int cap, const int* __restrict__ used, int* __restrict__ row_of_token,
+__device__ __forceinline__ void gp_compact_kernel(int V, int cap, const int* __restrict__ used, int* __restrict__ row_of_token,
                                                          int* __restrict__ tok_of_row, int* __restrict__ counter) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int u = (v < V) ? used[v] : 0;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void gp_compact_kernel(int V, int cap, const i
 
 // S[row][j] = <table[tok_of_row[row], :], w[:, j]>; 16 lanes per row (four rows per wave): a wave per row spent its time in
 // the 48 shuffles that fold eight accumulators over 64 lanes (22 us for 21 k rows of 400 bytes)
-__global__ __launch_bounds__(256) void gp_taps_kernel(int E, int win, int cap, const int* __restrict__ counter,
+__device__ __forceinline__ void gp_taps_kernel(int E, int win, int cap, const int* __restrict__ counter,
                                                       const int* __restrict__ tok_of_row, const float* __restrict__ table,
                                                       const float* __restrict__ w, float* __restrict__ S) {
     const int n = min(*counter, cap);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void gp_taps_kernel(int E, int win, int cap, c
     }
 }
 
-__global__ __launch_bounds__(256) void gp_gate_kernel(int B, int L, int win, const long long* __restrict__ ids,
+__device__ __forceinline__ void gp_gate_kernel(int B, int L, int win, const long long* __restrict__ ids,
                                                       const int* __restrict__ row_of_token, const float* __restrict__ S,
                                                       const float* __restrict__ b0, float* __restrict__ gate) {
     const long n = (long)B * L;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void gp_gate_kernel(int B, int L, int win, con
 }
 
 // c[0][k] += c[1..copies-1][k]   (fixed order)
-__global__ __launch_bounds__(256) void gp_csum_kernel(int cap, const int* __restrict__ counter, float* __restrict__ c) {
+__device__ __forceinline__ void gp_csum_kernel(int cap, const int* __restrict__ counter, float* __restrict__ c) {
     const long n = (long)min(*counter, cap) * kGateWP, stride = (long)cap * kGateWP;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) {
         float s = c[k];
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void gp_csum_kernel(int cap, const int* __rest
 // A is kept per distinct-token ROW ([n_rows, L] f32): building it costs ONE scalar atomic per position instead of a row of E
 // (the f32 atomics are priced per 64-byte request, ~25 G/s chip-wide: the per-window rows of gate_bwd_dx_kernel are 2.9 M
 // requests at cfg4, the scalars 0.5 M), and every table row is then written once, from its non-zeros.
-__global__ __launch_bounds__(256) void gg_zero_kernel(int cap, int L, const int* __restrict__ counter, f32x4g* __restrict__ A,
+__device__ __forceinline__ void gg_zero_kernel(int cap, int L, const int* __restrict__ counter, f32x4g* __restrict__ A,
                                                       int* __restrict__ dense_count) {
     const long n = (long)min(*counter, cap) * L / 4;                    // L % 4 == 0 (checked by the caller)
     const f32x4g z = {0.f, 0.f, 0.f, 0.f};
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void gg_zero_kernel(int cap, int L, const int*
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) A[k] = z;
 }
 
-__global__ __launch_bounds__(256) void gg_scatter_kernel(int B, int L, int pad_idx, const long long* __restrict__ ids,
+__device__ __forceinline__ void gg_scatter_kernel(int B, int L, int pad_idx, const long long* __restrict__ ids,
                                                          const int* __restrict__ row_of_token, const float* __restrict__ dpre,
                                                          float* __restrict__ A) {
     const long n = (long)B * L;
@@ -608,7 +608,7 @@ __device__ __forceinline__ void gg_stretch(float a, int p0, int E, int lane, con
 // entry spent its time on the fixed latencies of 50 k mostly near-empty rows, a wave per entry would walk the hot rows' 1024
 // non-zeros one after the other.
 constexpr int kGgDense = 96, kGgStretch = 16;        // stretches (of 64 positions) of a row held in registers at a time
-__global__ __launch_bounds__(256) void gg_rows_kernel(int V, int L, int E, int pad_idx, const int* __restrict__ row_of_token,
+__device__ __forceinline__ void gg_rows_kernel(int V, int L, int E, int pad_idx, const int* __restrict__ row_of_token,
                                                       const float* __restrict__ A, const float* __restrict__ wT,
                                                       float* __restrict__ dtable, int* __restrict__ dense_count,
                                                       int* __restrict__ dense_list, int accumulate) {
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void gg_rows_kernel(int V, int L, int E, int p
 }
 
 // dense rows: one workgroup of 16 waves per listed token, wave w walks the stretches w, w + 16, ...; partial rows meet in LDS
-__global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const int* __restrict__ row_of_token,
+__device__ __forceinline__ void gg_dense_rows_kernel(int L, int E, const int* __restrict__ row_of_token,
                                                              const float* __restrict__ A, const float* __restrict__ wT,
                                                              float* __restrict__ dtable, const int* __restrict__ dense_count,
                                                              const int* __restrict__ dense_list, int accumulate) {
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(1024) void gg_dense_rows_kernel(int L, int E, const
 }
 
 // dtable[v, :] = sum_j c[row(v)][j] w[:, j]  (0 for absent tokens and the pad row): the whole [V, E] gradient is overwritten
-__global__ __launch_bounds__(256) void gp_dtable_kernel(int V, int E, int win, int pad_idx, const int* __restrict__ row_of_token,
+__device__ __forceinline__ void gp_dtable_kernel(int V, int E, int win, int pad_idx, const int* __restrict__ row_of_token,
                                                         const float* __restrict__ c, const float* __restrict__ w,
                                                         float* __restrict__ dtable, int accumulate) {
     const long n = (long)V * E;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void gp_dtable_kernel(int V, int E, int win, i
 
 // accumulate form: dtable[tok_of_row[row], :] += sum_j c[row][j] w[:, j] over the batch's rows only (the shared gradient buffer of
 // functional.table_fanout): 2.1 M elements at cfg4 instead of the vocabulary's 5 M
-__global__ __launch_bounds__(256) void gp_dtable_rows_kernel(int E, int win, int cap, int pad_idx, const int* __restrict__ counter,
+__device__ __forceinline__ void gp_dtable_rows_kernel(int E, int win, int cap, int pad_idx, const int* __restrict__ counter,
                                                              const int* __restrict__ tok_of_row, const float* __restrict__ c,
                                                              const float* __restrict__ w, float* __restrict__ dtable) {
     const long n = (long)min(*counter, cap) * E;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void gp_dtable_rows_kernel(int E, int win, int
 
 // per-chunk partial of dw[e, j] = sum_rows c[row][j] * table[tok][e]  and  db0 = sum_rows c[row][pad]; 128 rows per workgroup
 constexpr int kGpRows = 128;
-__global__ __launch_bounds__(256) void gp_dw_partial_kernel(int E, int win, int cap, const int* __restrict__ counter,
+__device__ __forceinline__ void gp_dw_partial_kernel(int E, int win, int cap, const int* __restrict__ counter,
                                                             const int* __restrict__ tok_of_row, const float* __restrict__ table,
                                                             const float* __restrict__ c, float* __restrict__ part) {
     __shared__ float s_c[kGpRows * kGateWP];
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void gp_dw_partial_kernel(int E, int win, int 
 }
 
 // one wave per output: lanes stride the chunks that hold rows (ceil(n / 128) of them), shuffle reduction, fixed order
-__global__ __launch_bounds__(256) void gp_dw_final_kernel(int cap, int n_out, const int* __restrict__ counter,
+__device__ __forceinline__ void gp_dw_final_kernel(int cap, int n_out, const int* __restrict__ counter,
                                                           const float* __restrict__ part, float* __restrict__ dw,
                                                           float* __restrict__ db0) {
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -784,9 +784,7 @@ extern "C" int rbr_datt_global_gate_fwd(int32_t B, int32_t L, int32_t E, const i
                                         const float* w, const float* b0, float* gate, void* stream) {
     if (!gate_args_ok(B, L, E, 1)) return RBR_ERR_BAD_ARG;
     if (!ids || !table || !w || !b0 || !gate) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(global_gate_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, L, E,
-                       reinterpret_cast<const long long*>(ids), table, w, b0, gate);
-    RBR_CHECK_LAUNCH("datt global gate fwd launch");
+    if (int e_ = rbr::launch<global_gate_fwd_kernel, 256>(dim3(B), dim3(256), 0, (hipStream_t)stream, "datt global gate fwd launch", B, L, E, reinterpret_cast<const long long*>(ids), table, w, b0, gate)) return e_;
     return 0;
 }
 
@@ -813,11 +811,7 @@ extern "C" int rbr_datt_local_gate_bwd(int32_t B, int32_t L, int32_t E, int32_t 
     RBR_CHECK_LAUNCH("datt local gate bwd reduce launch");
     if (dtable != nullptr) {
         const int nwin = (L + kGWin - 1) / kGWin;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), (size_t)kGWin * win * sizeof(float), st, B,
-                           L, E, win, 0, nwin, ids64, w,
-                           (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable, (const int*)nullptr,
-                           (float*)nullptr, 0L);
-        RBR_CHECK_LAUNCH("datt local gate bwd dx launch");
+        if (int e_ = rbr::launch<gate_bwd_dx_kernel, 256>(dim3((unsigned)(B * nwin)), dim3(256), (size_t)kGWin * win * sizeof(float), st, "datt local gate bwd dx launch", B, L, E, win, 0, nwin, ids64, w, (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, dtable, (const int*)nullptr, (float*)nullptr, 0L)) return e_;
     }
     return 0;
 }
@@ -829,19 +823,13 @@ extern "C" int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const i
     if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
-    hipLaunchKernelGGL(global_gate_bwd_dpre_kernel, dim3(B), dim3(256), 0, st, B, L, gate, dgate, ws);
-    RBR_CHECK_LAUNCH("datt global gate bwd dpre launch");
-    hipLaunchKernelGGL(global_gate_bwd_dw_kernel, dim3(L + 1), dim3(256), 0, st, B, L, E, ids64, table, ws, dw, db0);
-    RBR_CHECK_LAUNCH("datt global gate bwd dw launch");
+    if (int e_ = rbr::launch<global_gate_bwd_dpre_kernel, 256>(dim3(B), dim3(256), 0, st, "datt global gate bwd dpre launch", B, L, gate, dgate, ws)) return e_;
+    if (int e_ = rbr::launch<global_gate_bwd_dw_kernel, 256>(dim3(L + 1), dim3(256), 0, st, "datt global gate bwd dw launch", B, L, E, ids64, table, ws, dw, db0)) return e_;
     if (dtable != nullptr) {
         float* wT = ws + B;
-        hipLaunchKernelGGL(transpose_w_kernel, dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0,
-                           st, E, L, w, wT);
-        RBR_CHECK_LAUNCH("datt global gate transpose launch");
+        if (int e_ = rbr::launch<transpose_w_kernel, 256>(dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0, st, "datt global gate transpose launch", E, L, w, wT)) return e_;
         const int nwin = (L + kGWin - 1) / kGWin;
-        hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, 1, 1, nwin, ids64, w,
-                           (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable, (const int*)nullptr, (float*)nullptr, 0L);
-        RBR_CHECK_LAUNCH("datt global gate bwd dx launch");
+        if (int e_ = rbr::launch<gate_bwd_dx_kernel, 256>(dim3((unsigned)(B * nwin)), dim3(256), 0, st, "datt global gate bwd dx launch", B, L, E, 1, 1, nwin, ids64, w, (const float*)wT, gate, dgate, (const float*)ws, pad_idx, dtable, (const int*)nullptr, (float*)nullptr, 0L)) return e_;
     }
     return 0;
 }
@@ -932,19 +920,11 @@ extern "C" int rbr_datt_local_gate_fwd_prod(int32_t B, int32_t L, int32_t E, int
     const int *counter = M.counter, *row_of_token = M.row_of_token, *tok_of_row = M.tok_of_row;
     if (rows == nullptr) {               // the tower's shared maps (rbr_datt_token_rows) were not handed in: build private ones
         if (int e = zero_words(used, G.row_of_token - G.used, st)) return e;
-        hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos, ids64, used);
-        RBR_CHECK_LAUNCH("datt gate mark launch");
-        hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, G.cap, used,
-                           reinterpret_cast<int*>(base + G.row_of_token), reinterpret_cast<int*>(base + G.tok_of_row),
-                           reinterpret_cast<int*>(base + G.counter));
-        RBR_CHECK_LAUNCH("datt gate compact launch");
+        if (int e_ = rbr::launch<gp_mark_kernel, 256>(dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, "datt gate mark launch", n_pos, ids64, used)) return e_;
+        if (int e_ = rbr::launch<gp_compact_kernel, 256>(dim3((V + 255) / 256), dim3(256), 0, st, "datt gate compact launch", V, G.cap, used, reinterpret_cast<int*>(base + G.row_of_token), reinterpret_cast<int*>(base + G.tok_of_row), reinterpret_cast<int*>(base + G.counter))) return e_;
     }
-    hipLaunchKernelGGL(gp_taps_kernel, dim3((unsigned)std::min((G.cap + 15) / 16, 4096)), dim3(256), 0, st, E, win, G.cap, counter,
-                       tok_of_row, table, w, S);
-    RBR_CHECK_LAUNCH("datt gate taps launch");
-    hipLaunchKernelGGL(gp_gate_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, B, L, win, ids64,
-                       row_of_token, S, b0, gate);
-    RBR_CHECK_LAUNCH("datt gate gather launch");
+    if (int e_ = rbr::launch<gp_taps_kernel, 256>(dim3((unsigned)std::min((G.cap + 15) / 16, 4096)), dim3(256), 0, st, "datt gate taps launch", E, win, G.cap, counter, tok_of_row, table, w, S)) return e_;
+    if (int e_ = rbr::launch<gp_gate_kernel, 256>(dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, "datt gate gather launch", B, L, win, ids64, row_of_token, S, b0, gate)) return e_;
     return 0;
 }
 
@@ -965,26 +945,18 @@ extern "C" int rbr_datt_local_gate_bwd_prod(int32_t B, int32_t L, int32_t E, int
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     if (int e = zero_words(c, (size_t)G.cap * kGateWP * sizeof(float) * kGateCopies, st)) return e;
     const int nwin = (L + kGWin - 1) / kGWin;
-    hipLaunchKernelGGL(gate_bwd_dx_kernel, dim3((unsigned)(B * nwin)), dim3(256), 0, st, B, L, E, win, 0, nwin, ids64, w,
-                       (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, (float*)nullptr, row_of_token, c,
-                       (long)G.cap * kGateWP);
-    RBR_CHECK_LAUNCH("datt gate tap-sum launch");
-    hipLaunchKernelGGL(gp_csum_kernel, dim3((unsigned)std::min((G.cap * kGateWP + 255) / 256, 2048)), dim3(256), 0, st, G.cap, counter, c);
-    RBR_CHECK_LAUNCH("datt gate tap-sum fold launch");
+    if (int e_ = rbr::launch<gate_bwd_dx_kernel, 256>(dim3((unsigned)(B * nwin)), dim3(256), 0, st, "datt gate tap-sum launch", B, L, E, win, 0, nwin, ids64, w, (const float*)nullptr, gate, dgate, (const float*)nullptr, pad_idx, (float*)nullptr, row_of_token, c, (long)G.cap * kGateWP)) return e_;
+    if (int e_ = rbr::launch<gp_csum_kernel, 256>(dim3((unsigned)std::min((G.cap * kGateWP + 255) / 256, 2048)), dim3(256), 0, st, "datt gate tap-sum fold launch", G.cap, counter, c)) return e_;
     const int n_out = win * E + 1;
-    hipLaunchKernelGGL(gp_dw_partial_kernel, dim3(G.n_chunks), dim3(256), 0, st, E, win, G.cap, counter, tok_of_row, table, c, part);
-    RBR_CHECK_LAUNCH("datt gate dw partial launch");
-    hipLaunchKernelGGL(gp_dw_final_kernel, dim3((n_out + 3) / 4), dim3(256), 0, st, G.cap, n_out, counter, part, dw, db0);
-    RBR_CHECK_LAUNCH("datt gate dw final launch");
+    if (int e_ = rbr::launch<gp_dw_partial_kernel, 256>(dim3(G.n_chunks), dim3(256), 0, st, "datt gate dw partial launch", E, win, G.cap, counter, tok_of_row, table, c, part)) return e_;
+    if (int e_ = rbr::launch<gp_dw_final_kernel, 256>(dim3((n_out + 3) / 4), dim3(256), 0, st, "datt gate dw final launch", G.cap, n_out, counter, part, dw, db0)) return e_;
     if (dtable != nullptr) {
         const long n = (long)V * E;
-        if (accumulate)
-            hipLaunchKernelGGL(gp_dtable_rows_kernel, dim3((unsigned)std::min<long>(((long)G.cap * E + 255) / 256, 8192)), dim3(256), 0, st, E,
-                               win, G.cap, pad_idx, counter, tok_of_row, c, w, dtable);
-        else
-            hipLaunchKernelGGL(gp_dtable_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, V, E, win, pad_idx,
-                               row_of_token, c, w, dtable, 0);
-        RBR_CHECK_LAUNCH("datt gate dtable launch");
+        if (accumulate) {
+            if (int e_ = rbr::launch<gp_dtable_rows_kernel, 256>(dim3((unsigned)std::min<long>(((long)G.cap * E + 255) / 256, 8192)), dim3(256), 0, st, "gp_dtable_rows_kernel launch", E, win, G.cap, pad_idx, counter, tok_of_row, c, w, dtable)) return e_;
+        } else {
+            if (int e_ = rbr::launch<gp_dtable_kernel, 256>(dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, st, "datt gate dtable launch", V, E, win, pad_idx, row_of_token, c, w, dtable, 0)) return e_;
+        }
     }
     return 0;
 }
@@ -1004,12 +976,8 @@ extern "C" int rbr_datt_token_rows(int32_t B, int32_t L, int32_t V, const int64_
     int* used = reinterpret_cast<int*>(base + T.used);
     if (int e = zero_words(counter, T.row_of_token - T.counter, st)) return e;
     const long n_pos = (long)B * L;
-    hipLaunchKernelGGL(gp_mark_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, n_pos,
-                       reinterpret_cast<const long long*>(ids), used);
-    RBR_CHECK_LAUNCH("token rows mark launch");
-    hipLaunchKernelGGL(gp_compact_kernel, dim3((V + 255) / 256), dim3(256), 0, st, V, T.cap, used,
-                       reinterpret_cast<int*>(base + T.row_of_token), reinterpret_cast<int*>(base + T.tok_of_row), counter);
-    RBR_CHECK_LAUNCH("token rows compact launch");
+    if (int e_ = rbr::launch<gp_mark_kernel, 256>(dim3((unsigned)std::min<long>((n_pos + 255) / 256, 2048)), dim3(256), 0, st, "token rows mark launch", n_pos, reinterpret_cast<const long long*>(ids), used)) return e_;
+    if (int e_ = rbr::launch<gp_compact_kernel, 256>(dim3((V + 255) / 256), dim3(256), 0, st, "token rows compact launch", V, T.cap, used, reinterpret_cast<int*>(base + T.row_of_token), reinterpret_cast<int*>(base + T.tok_of_row), counter)) return e_;
     return 0;
 }
 
@@ -1031,32 +999,20 @@ extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, in
     const char* base = static_cast<const char*>(rows);
     const int* counter = reinterpret_cast<const int*>(base + T.counter);
     const int* row_of_token = reinterpret_cast<const int*>(base + T.row_of_token);
-    hipLaunchKernelGGL(global_gate_bwd_dpre_kernel, dim3(B), dim3(256), 0, st, B, L, gate, dgate, ws);
-    RBR_CHECK_LAUNCH("datt global gate bwd dpre launch");
-    hipLaunchKernelGGL(global_gate_bwd_dw_kernel, dim3(L + 1), dim3(256), 0, st, B, L, E, ids64, table, ws, dw, db0);
-    RBR_CHECK_LAUNCH("datt global gate bwd dw launch");
+    if (int e_ = rbr::launch<global_gate_bwd_dpre_kernel, 256>(dim3(B), dim3(256), 0, st, "datt global gate bwd dpre launch", B, L, gate, dgate, ws)) return e_;
+    if (int e_ = rbr::launch<global_gate_bwd_dw_kernel, 256>(dim3(L + 1), dim3(256), 0, st, "datt global gate bwd dw launch", B, L, E, ids64, table, ws, dw, db0)) return e_;
     if (dtable != nullptr) {
         float* wT = ws + B;
         float* A = wT + (((size_t)E * L + 3) & ~(size_t)3);             // 16-byte aligned behind wT when ws is
         if ((reinterpret_cast<uintptr_t>(A) & 15) != 0) A += 4 - ((reinterpret_cast<uintptr_t>(A) & 15) >> 2);
-        hipLaunchKernelGGL(transpose_w_kernel, dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0,
-                           st, E, L, w, wT);
-        RBR_CHECK_LAUNCH("datt global gate transpose launch");
+        if (int e_ = rbr::launch<transpose_w_kernel, 256>(dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0, st, "datt global gate transpose launch", E, L, w, wT)) return e_;
         int* dense_count = reinterpret_cast<int*>(A + (size_t)T.cap * L);
         int* dense_list = dense_count + 4;
-        hipLaunchKernelGGL(gg_zero_kernel, dim3((unsigned)std::min<long>(((long)T.cap * L / 4 + 255) / 256, 8192)), dim3(256), 0, st,
-                           T.cap, L, counter, reinterpret_cast<f32x4g*>(A), dense_count);
-        RBR_CHECK_LAUNCH("datt global gate occurrence zero launch");
+        if (int e_ = rbr::launch<gg_zero_kernel, 256>(dim3((unsigned)std::min<long>(((long)T.cap * L / 4 + 255) / 256, 8192)), dim3(256), 0, st, "datt global gate occurrence zero launch", T.cap, L, counter, reinterpret_cast<f32x4g*>(A), dense_count)) return e_;
         const long n_pos = (long)B * L;
-        hipLaunchKernelGGL(gg_scatter_kernel, dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, B, L,
-                           pad_idx, ids64, row_of_token, (const float*)ws, A);
-        RBR_CHECK_LAUNCH("datt global gate occurrence scatter launch");
-        hipLaunchKernelGGL(gg_rows_kernel, dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, V, L, E, pad_idx, row_of_token,
-                           (const float*)A, (const float*)wT, dtable, dense_count, dense_list, accumulate);
-        RBR_CHECK_LAUNCH("datt global gate rows launch");
-        hipLaunchKernelGGL(gg_dense_rows_kernel, dim3((unsigned)std::min(V, 512)), dim3(1024), 0, st, L, E, row_of_token,
-                           (const float*)A, (const float*)wT, dtable, (const int*)dense_count, (const int*)dense_list, accumulate);
-        RBR_CHECK_LAUNCH("datt global gate dense rows launch");
+        if (int e_ = rbr::launch<gg_scatter_kernel, 256>(dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, "datt global gate occurrence scatter launch", B, L, pad_idx, ids64, row_of_token, (const float*)ws, A)) return e_;
+        if (int e_ = rbr::launch<gg_rows_kernel, 256>(dim3((unsigned)((V + 3) / 4)), dim3(256), 0, st, "datt global gate rows launch", V, L, E, pad_idx, row_of_token, (const float*)A, (const float*)wT, dtable, dense_count, dense_list, accumulate)) return e_;
+        if (int e_ = rbr::launch<gg_dense_rows_kernel, 1024>(dim3((unsigned)std::min(V, 512)), dim3(1024), 0, st, "datt global gate dense rows launch", L, E, row_of_token, (const float*)A, (const float*)wT, dtable, (const int*)dense_count, (const int*)dense_list, accumulate)) return e_;
     }
     return 0;
 }

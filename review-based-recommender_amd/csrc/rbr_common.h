@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/rbr_hip.h"
+#include "rbr_launch.h"
 
 namespace rbr {
 
@@ -259,8 +260,14 @@ __device__ __forceinline__ bool dropout_keep(unsigned word, float p) {      // u
 
 }  // namespace rbr
 
+// after a DIRECT launch (hipLaunchKernelGGL): inside a pair region (rbr_launch.h) such a launch would have run ahead of the
+// recorded ones, so the entry point is refused there
 #define RBR_CHECK_LAUNCH(what)                                   \
     do {                                                         \
         int _e = rbr::check_hip(hipGetLastError(), what);        \
         if (_e) return _e;                                       \
+        if (rbr::pair_region_open()) {                           \
+            rbr::set_error("%s: this entry point launches directly and cannot be used inside rbr_pair_begin / rbr_pair_end", what); \
+            return RBR_ERR_UNSUPPORTED;                          \
+        }                                                        \
     } while (0)

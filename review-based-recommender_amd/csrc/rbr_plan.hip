@@ -136,5 +136,61 @@ int build_plans(const rbr_textcnn_desc* d, ConvPlan* plans, int tiles_per_group)
 
 }  // namespace rbr
 
+namespace rbr {
+PairState& pair_state() {
+    static thread_local PairState S;
+    return S;
+}
+}  // namespace rbr
+
+// ---- pair regions (rbr_launch.h): the launches of two independent problems of equal shapes, zipped into shared launches
+extern "C" int rbr_pair_begin(void) {
+    rbr::PairState& S = rbr::pair_state();
+    if (S.mode != 0) { rbr::set_error("rbr_pair_begin: a pair region is already open on this thread"); return RBR_ERR_BAD_ARG; }
+    S.rec[0].clear(); S.rec[1].clear();
+    S.mode = 1;
+    return 0;
+}
+extern "C" int rbr_pair_next(void) {
+    rbr::PairState& S = rbr::pair_state();
+    if (S.mode != 1) { rbr::set_error("rbr_pair_next: expected after rbr_pair_begin, once"); return RBR_ERR_BAD_ARG; }
+    S.mode = 2;
+    return 0;
+}
+extern "C" void rbr_pair_abort(void) {
+    rbr::PairState& S = rbr::pair_state();
+    S.rec[0].clear(); S.rec[1].clear();
+    S.mode = 0;
+}
+extern "C" int rbr_pair_end(int32_t* n_paired, int32_t* n_single) {
+    rbr::PairState& S = rbr::pair_state();
+    if (S.mode == 0) { rbr::set_error("rbr_pair_end: no pair region is open"); return RBR_ERR_BAD_ARG; }
+    S.mode = 0;                              // from here on launches run
+    S.paired = S.singles = 0;
+    int rc = 0;
+    const size_t n0 = S.rec[0].size(), n1 = S.rec[1].size(), nz = std::min(n0, n1);
+    size_t i = 0;
+    // zip while the two lists name the same kernels; a pair that does not form (grids, shared arguments) goes out as two
+    // launches and the zip carries on -- the lists still line up.  Each problem's launches keep their order either way.
+    for (; i < nz && rc == 0; ++i) {
+        const rbr::PairRec &a = S.rec[0][i], &b = S.rec[1][i];
+        if (a.pair != b.pair) break;
+        rc = a.pair(a, b);
+        if (rc == rbr::kPairNoMatch) {
+            rc = a.single(a);
+            if (rc == 0) rc = b.single(b);
+            S.singles += 2;
+        } else if (rc == 0) {
+            S.paired += 1;
+        }
+    }
+    for (size_t k = i; k < n0 && rc == 0; ++k, ++S.singles) rc = S.rec[0][k].single(S.rec[0][k]);
+    for (size_t k = i; k < n1 && rc == 0; ++k, ++S.singles) rc = S.rec[1][k].single(S.rec[1][k]);
+    S.rec[0].clear(); S.rec[1].clear();
+    if (n_paired) *n_paired = S.paired;
+    if (n_single) *n_single = S.singles;
+    return rc;
+}
+
 extern "C" int rbr_version(void) { return 1; }
 extern "C" const char* rbr_last_error(void) { return rbr::g_err; }

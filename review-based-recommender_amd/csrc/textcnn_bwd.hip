@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(const BwdArgs A, const 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // kDwMaxM = taps per thread (compile-time bound: the register arrays below are sized by it)
 template <int kDwMaxM>
-__global__ __launch_bounds__(256) void dw_partial4_kernel(const BwdArgs A, const long long* __restrict__ ids,
+__device__ __forceinline__ void dw_partial4_kernel(const BwdArgs& A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask,
                                                           const float* __restrict__ gate, const float* __restrict__ table,
                                                           const float* __restrict__ feat, const int* __restrict__ argmax,
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(256) void dw_doc_kernel(const BwdArgs A, const long
 // the NCH loads of an element independent of each other), transposes through LDS and writes the [d][tap] block of the
 // torch layout as one contiguous run.
 constexpr int kRedCols = 128;
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const BwdArgs A, const float* __restrict__ ws_w,
-                                                        const float* __restrict__ ws_b, const MutPtrArray dW,
-                                                        const MutPtrArray dbias) {
+__device__ __forceinline__ void dw_reduce_kernel(const BwdArgs& A, const float* __restrict__ ws_w,
+                                                        const float* __restrict__ ws_b, const MutPtrArray& dW,
+                                                        const MutPtrArray& dbias) {
     __shared__ float s_out[kMaxKF * kRedCols];
     const int c = blockIdx.x, d0 = blockIdx.y * kRedCols;
     const int nd = min(kRedCols, A.D - d0);
@@ -712,22 +712,18 @@ extern "C" int rbr_textcnn_bwd_dw(const rbr_textcnn_desc* d, const int64_t* ids,
                 taps_per_thread = std::max(taps_per_thread, (d->kz[w] + js - 1) / js);
             }
         if (vec4 && taps_per_thread <= 1) {
-            hipLaunchKernelGGL(dw_partial4_kernel<1>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                               argmax, d_feat, ws_w, ws_b);
+            if (int e_ = rbr::launch<dw_partial4_kernel<1>, 256>(dim3(A.C, A.NCH), dim3(256), 0, st, "textcnn dw_partial4 launch", A, ids64, mask, gate, table, feat, argmax, d_feat, ws_w, ws_b)) return e_;
         } else if (vec4 && taps_per_thread <= 3) {
-            hipLaunchKernelGGL(dw_partial4_kernel<3>, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat,
-                               argmax, d_feat, ws_w, ws_b);
+            if (int e_ = rbr::launch<dw_partial4_kernel<3>, 256>(dim3(A.C, A.NCH), dim3(256), 0, st, "textcnn dw_partial4 launch", A, ids64, mask, gate, table, feat, argmax, d_feat, ws_w, ws_b)) return e_;
         } else {      // odd widths, or rows so long that one slot would own > 3 taps: the scalar-column kernel
             hipLaunchKernelGGL(dw_partial_kernel, dim3(A.C, A.NCH), dim3(256), 0, st, A, ids64, mask, gate, table, feat, argmax,
                                d_feat, ws_w, ws_b);
+            RBR_CHECK_LAUNCH("textcnn dw_partial launch");
         }
-        RBR_CHECK_LAUNCH("textcnn dw_partial launch");
     }
     MutPtrArray dWp{}, dbp{};
     for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)A.C, (unsigned)((A.D + kRedCols - 1) / kRedCols)), dim3(256), 0, st, A,
-                       ws_w, ws_b, dWp, dbp);
-    RBR_CHECK_LAUNCH("textcnn dw_reduce launch");
+    if (int e_ = rbr::launch<dw_reduce_kernel, 256>(dim3((unsigned)A.C, (unsigned)((A.D + kRedCols - 1) / kRedCols)), dim3(256), 0, st, "textcnn dw_reduce launch", A, ws_w, ws_b, dWp, dbp)) return e_;
     return 0;
 }
 

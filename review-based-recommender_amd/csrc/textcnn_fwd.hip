@@ -649,8 +649,8 @@ void conv_store_kernel(const ConvPlan P, const long long* __restrict__ ids, cons
 
 // ------------------------------------------------------------------------------------ finalize
 // one thread per (doc, slot): reduce the wpd slabs in position order, bias + activation.
-__global__ __launch_bounds__(256) void pool_finalize_kernel(const ConvPlan P, const float* __restrict__ pval,
-                                                            const int* __restrict__ pidx, const PtrArray bias,
+__device__ __forceinline__ void pool_finalize_kernel(const ConvPlan& P, const float* __restrict__ pval,
+                                                            const int* __restrict__ pidx, const PtrArray& bias,
                                                             float* __restrict__ feat, int* __restrict__ argmax) {
     const int* flags = pidx + (long)P.total_wt * P.nslots_total;   // sched region written by tile_scan_kernel
     const int nslots = P.ntiles * kTile;
@@ -834,7 +834,7 @@ extern "C" int rbr_textcnn_conv_fwd(const rbr_textcnn_desc* d, const int64_t* id
 
 namespace rbr {
 
-__global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions R) {
+__device__ __forceinline__ void zero_regions_kernel(const ZeroRegions& R) {
     const long total = R.n[0] + R.n[1] + R.n[2];
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long)gridDim.x * 256) {
         if (k < R.n[0]) R.p[0][k] = 0;
@@ -845,8 +845,7 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(const ZeroRegions R) 
 
 int zero_regions(const ZeroRegions& r, hipStream_t st) {
     const long n = r.n[0] + r.n[1] + r.n[2];
-    hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st, r);
-    RBR_CHECK_LAUNCH("zero_regions launch");
+    if (int e_ = rbr::launch<zero_regions_kernel, 256>(dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st, "zero_regions launch", r)) return e_;
     return 0;
 }
 
@@ -892,9 +891,7 @@ extern "C" int rbr_textcnn_pool_finalize(const rbr_textcnn_desc* d, const float*
     for (int g = 0; g < ng; ++g) {
         const long total = (long)plans[g].n_docs * plans[g].ntiles * kTile;
         const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(pool_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, plans[g], pval, pidx,
-                           bp, feat, argmax);
-        RBR_CHECK_LAUNCH("textcnn pool_finalize launch");
+        if (int e_ = rbr::launch<pool_finalize_kernel, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, "textcnn pool_finalize launch", plans[g], pval, pidx, bp, feat, argmax)) return e_;
     }
     return 0;
 }

@@ -42,7 +42,7 @@ struct ProdArgs {
 // ---------------------------------------------------------------------------------- distinct tokens
 // Launch 2 of the forward chain: blocks [0, nb_scan) build the work list of the REAL documents (which 32-token slabs
 // hold an unmasked token), the remaining blocks mark the tokens that occur.  Independent jobs, one launch.
-__global__ __launch_bounds__(256) void mark_scan_kernel(const ConvPlan P, int nb_scan, long n_tok, const long long* __restrict__ ids,
+__device__ __forceinline__ void mark_scan_kernel(const ConvPlan& P, int nb_scan, long n_tok, const long long* __restrict__ ids,
                                                         const unsigned char* __restrict__ mask, int* __restrict__ sched,
                                                         unsigned char* __restrict__ used) {
     if ((int)blockIdx.x < nb_scan) {
@@ -89,12 +89,12 @@ __device__ __forceinline__ float prod_weight(const PackJob& J, const PtrArray& W
 // Launch 3: blocks [0, nb_compact) turn the marks into the token list (row_of_token[v] = dense row or -1,
 // tok_of_row / row_mask describe the pseudo-document, *counter = rows); the remaining blocks write the product weight
 // image of the forward GEMM and the row-major Wprod^T the backward's sparse product reads.
-__global__ __launch_bounds__(256) void compact_pack_kernel(const PackJob J, int nb_compact, int V, int cap,
+__device__ __forceinline__ void compact_pack_kernel(const PackJob& J, int nb_compact, int V, int cap,
                                                            const unsigned char* __restrict__ used, int* __restrict__ row_of_token,
                                                            long long* __restrict__ tok_of_row, unsigned char* __restrict__ row_mask,
                                                            int* __restrict__ counter, float* __restrict__ zero_row, int pitch,
-                                                           const PtrArray W, float* __restrict__ packed, float* __restrict__ WT,
-                                                           const B16Pack JB, unsigned char* __restrict__ bimg) {
+                                                           const PtrArray& W, float* __restrict__ packed, float* __restrict__ WT,
+                                                           const B16Pack& JB, unsigned char* __restrict__ bimg) {
     if ((int)blockIdx.x < nb_compact) {
         if (blockIdx.x == 0)      // the all-zero row of T that masked / out-of-document taps read
             for (int k = threadIdx.x; k < pitch; k += 256) zero_row[k] = 0.f;
@@ -180,7 +180,7 @@ typedef unsigned u32x2u __attribute__((ext_vector_type(2), aligned(2)));  // fou
 // 62: 53 us against 44 at cfg2, 218 against 152 for D-ATT.  Eight waves per SIMD with two loads each already keep the L2 at its
 // rate; fewer waves with more loads each do not.)
 template <bool TB16>
-__global__ __launch_bounds__(256) void gather_pool_kernel(const ConvPlan P, const ProdArgs A, const long long* __restrict__ ids,
+__device__ __forceinline__ void gather_pool_kernel(const ConvPlan& P, const ProdArgs& A, const long long* __restrict__ ids,
                                                           const unsigned char* __restrict__ mask, const float* __restrict__ gate,
                                                           const int* __restrict__ row_of_token, const void* __restrict__ Tv,
                                                           const int* __restrict__ sched, float* __restrict__ pval,
@@ -301,7 +301,7 @@ struct ProdBwdArgs {
 };
 
 // ... and the gate gradient build_g accumulates into (n_dgate floats, 0 for un-gated convs): one launch for both
-__global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
+__device__ __forceinline__ void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
                                                           float* __restrict__ dgate, long n_dgate) {
     const long n = (G != nullptr) ? (long)min(*counter, cap) * KG4 : 0;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void zero_g_rows_kernel(const int* __restrict_
 
 // one thread per (doc, channel, tap).  Gated convs (D-ATT: x = gate[doc,p] * table[id]): the token's share is g * gate, and
 // d(gate[doc,p]) += g * <W[c,:,j], table[id]> = g * T[token][(w,j,c)], read from the forward's product table.
-__global__ __launch_bounds__(256) void build_g_kernel(const ProdBwdArgs A, const long long* __restrict__ ids,
+__device__ __forceinline__ void build_g_kernel(const ProdBwdArgs& A, const long long* __restrict__ ids,
                                                       const unsigned char* __restrict__ mask, const float* __restrict__ gate,
                                                       const int* __restrict__ row_of_token, const float* __restrict__ T,
                                                       const float* __restrict__ feat, const int* __restrict__ argmax,
@@ -358,7 +358,7 @@ constexpr int kSpQ4 = 2;      // float4 columns per lane and pass: 512 floats of
 enum { kGtwDense = 0, kGtwAccumulate = 1, kGtwRows = 2 };
 constexpr int kGtwMaxBlocks = 8192;      // workgroups of g_times_w = entries of its sq_part
 template <int MODE>
-__global__ __launch_bounds__(256) void g_times_w_kernel(const ProdBwdArgs A, const int KGW, const int* __restrict__ counter,
+__device__ __forceinline__ void g_times_w_kernel(const ProdBwdArgs& A, const int KGW, const int* __restrict__ counter,
                                                         const float* __restrict__ G, const float* __restrict__ WT,
                                                         const long long* __restrict__ tok_of_row,
                                                         const int* __restrict__ row_of_token, int V, float* __restrict__ dtable,
@@ -1241,32 +1241,22 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     const bool want_g = dtable != nullptr || !(phases & kGProduct);
     if (phases & kGBuild) {
         if ((want_g && !(phases & kGZeroed)) || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
-            hipLaunchKernelGGL(zero_g_rows_kernel, dim3(2048), dim3(256), 0, st, counter, Lo.cap, B.KG / 4,
-                               (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate,
-                               dgate != nullptr ? (long)d->n_docs * d->L * (RBR_CONV_GATE_SPLIT_OF(d->flags) ? 2 : 1) : 0L);
-            RBR_CHECK_LAUNCH("textcnn zero_g_rows launch");
+            if (int e_ = rbr::launch<zero_g_rows_kernel, 256>(dim3(2048), dim3(256), 0, st, "textcnn zero_g_rows launch", counter, Lo.cap, B.KG / 4, (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate, dgate != nullptr ? (long)d->n_docs * d->L * (RBR_CONV_GATE_SPLIT_OF(d->flags) ? 2 : 1) : 0L)) return e_;
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;
-        hipLaunchKernelGGL(build_g_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, A,
-                           reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat,
-                           want_g ? G : nullptr, dgate, prod_t_bf16(d) ? 1 : 0);
-        RBR_CHECK_LAUNCH("textcnn build_g launch");
+        if (int e_ = rbr::launch<build_g_kernel, 256>(dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, "textcnn build_g launch", A, reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat, want_g ? G : nullptr, dgate, prod_t_bf16(d) ? 1 : 0)) return e_;
     }
     if (dtable == nullptr || !(phases & kGProduct)) return 0;
     const size_t lds = (size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * sizeof(float);
     const dim3 grid((unsigned)std::min(Lo.cap, kGtwMaxBlocks));
     if (phases & kGRows) {
         if (sq_part == nullptr) { set_error("compact row gradient needs sq_part"); return RBR_ERR_BAD_ARG; }
-        hipLaunchKernelGGL(g_times_w_kernel<kGtwRows>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V,
-                           dtable, sq_part);
+        if (int e_ = rbr::launch<g_times_w_kernel<kGtwRows>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, sq_part)) return e_;
     } else if (phases & kGAccumulate) {
-        hipLaunchKernelGGL(g_times_w_kernel<kGtwAccumulate>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
-                           d->V, dtable, (float*)nullptr);
+        if (int e_ = rbr::launch<g_times_w_kernel<kGtwAccumulate>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, (float*)nullptr)) return e_;
     } else {
-        hipLaunchKernelGGL(g_times_w_kernel<kGtwDense>, grid, dim3(256), lds, st, A, B.KGW, counter, G, WT, tok_of_row, row_of_token,
-                           d->V, dtable, (float*)nullptr);
+        if (int e_ = rbr::launch<g_times_w_kernel<kGtwDense>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, (float*)nullptr)) return e_;
     }
-    RBR_CHECK_LAUNCH("textcnn g_times_w launch");
     return 0;
 }
 
@@ -1346,9 +1336,7 @@ static int prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uin
     const long n_tok = (long)d->n_docs * d->L;
     const int nb_scan = (plans[0].total_wt + 255) / 256;
     const int nb_mark = (int)std::min<long>((n_tok + 255) / 256, 2048);
-    hipLaunchKernelGGL(mark_scan_kernel, dim3(nb_scan + nb_mark), dim3(256), 0, st, plans[0], nb_scan, n_tok,
-                       reinterpret_cast<const long long*>(ids), mask, sched, S.used);
-    RBR_CHECK_LAUNCH("textcnn mark_scan launch");
+    if (int e_ = rbr::launch<mark_scan_kernel, 256>(dim3(nb_scan + nb_mark), dim3(256), 0, st, "textcnn mark_scan launch", plans[0], nb_scan, n_tok, reinterpret_cast<const long long*>(ids), mask, sched, S.used)) return e_;
     PackJob J{};
     J.P = S.pp[0]; J.n_widths = d->n_widths; J.D = d->D; J.cp_real = S.A.cp_real;
     for (int w = 0; w < d->n_widths; ++w) { J.kz[w] = d->kz[w]; J.ch[w] = d->ch[w]; J.poff[w] = S.A.poff[w]; }
@@ -1362,13 +1350,8 @@ static int prod_prepare(const rbr_textcnn_desc* d, const int64_t* ids, const uin
                         (long)S.A.cp_real * d->D;
     const int nb_pack = (int)std::min<long>((n_pack + 255) / 256, 2048);
     // (bf16-plane GEMM: the weight planes in MFMA-fragment order instead of the f32 tile image)
-    hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, S.Lo.cap, S.used,
-                       S.row_of_token, S.tok_of_row, S.row_mask, S.counter,
-                       prod_t_bf16(d) ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(S.T) + (size_t)S.Lo.cap * S.A.pitch)
-                                      : S.T + (size_t)S.Lo.cap * S.A.pitch,
-                       prod_t_bf16(d) ? S.A.pitch / 2 : S.A.pitch, wp,
-                       b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr);
-    RBR_CHECK_LAUNCH("textcnn compact_pack launch");
+    if (int e_ = rbr::launch<compact_pack_kernel, 256>(dim3(nb_compact + nb_pack), dim3(256), 0, st, "textcnn compact_pack launch", J, nb_compact, d->V, S.Lo.cap, S.used, S.row_of_token, S.tok_of_row, S.row_mask, S.counter, prod_t_bf16(d) ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(S.T) + (size_t)S.Lo.cap * S.A.pitch)
+                                      : S.T + (size_t)S.Lo.cap * S.A.pitch, prod_t_bf16(d) ? S.A.pitch / 2 : S.A.pitch, wp, b16 ? nullptr : S.packed_p, S.WT, JB, b16 ? reinterpret_cast<unsigned char*>(S.base + S.Lo.bimg) : nullptr)) return e_;
     return 0;
 }
 
@@ -1434,9 +1417,7 @@ extern "C" int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int6
                    {(long)((Lo.row_of_token - Lo.used) / sizeof(int)), kSchedCounters, 0}};
     if (int e = zero_regions(zr, st)) return e;
     const long n_tok = (long)d->n_docs * d->L;
-    hipLaunchKernelGGL(mark_scan_kernel, dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, plans[0], 0, n_tok,
-                       reinterpret_cast<const long long*>(ids), mask, (int*)nullptr, reinterpret_cast<unsigned char*>(base + Lo.used));
-    RBR_CHECK_LAUNCH("textcnn mark launch");
+    if (int e_ = rbr::launch<mark_scan_kernel, 256>(dim3((unsigned)std::min<long>((n_tok + 255) / 256, 2048)), dim3(256), 0, st, "textcnn mark launch", plans[0], 0, n_tok, reinterpret_cast<const long long*>(ids), mask, (int*)nullptr, reinterpret_cast<unsigned char*>(base + Lo.used))) return e_;
     PackJob J{};
     J.P = pp[0]; J.n_widths = d->n_widths; J.D = d->D;
     int o = 0;
@@ -1446,12 +1427,7 @@ extern "C" int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int6
     for (int w = 0; w < d->n_widths; ++w) wp.p[w] = W[w];
     const int nb_compact = (d->V + 255) / 256;
     const int nb_pack = (int)std::min<long>(((long)J.cp_real * d->D + 255) / 256, 2048);
-    hipLaunchKernelGGL(compact_pack_kernel, dim3(nb_compact + nb_pack), dim3(256), 0, st, J, nb_compact, d->V, Lo.cap,
-                       reinterpret_cast<unsigned char*>(base + Lo.used), reinterpret_cast<int*>(base + Lo.row_of_token),
-                       reinterpret_cast<long long*>(base + Lo.tok_of_row), reinterpret_cast<unsigned char*>(base + Lo.row_mask),
-                       reinterpret_cast<int*>(base + Lo.counter), reinterpret_cast<float*>(base + Lo.table_T), pp[0].nslots_total, wp,
-                       (float*)nullptr, reinterpret_cast<float*>(base + Lo.wt), B16Pack{}, (unsigned char*)nullptr);
-    RBR_CHECK_LAUNCH("textcnn compact launch");
+    if (int e_ = rbr::launch<compact_pack_kernel, 256>(dim3(nb_compact + nb_pack), dim3(256), 0, st, "textcnn compact launch", J, nb_compact, d->V, Lo.cap, reinterpret_cast<unsigned char*>(base + Lo.used), reinterpret_cast<int*>(base + Lo.row_of_token), reinterpret_cast<long long*>(base + Lo.tok_of_row), reinterpret_cast<unsigned char*>(base + Lo.row_mask), reinterpret_cast<int*>(base + Lo.counter), reinterpret_cast<float*>(base + Lo.table_T), pp[0].nslots_total, wp, (float*)nullptr, reinterpret_cast<float*>(base + Lo.wt), B16Pack{}, (unsigned char*)nullptr)) return e_;
     return dtable_through_list(d, plans, ids, mask, nullptr, feat, argmax, d_feat, base, base + align256(list_bytes), dtable, nullptr, st);
 }
 
@@ -1480,12 +1456,9 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     const int* sched = pidx + (size_t)plans[0].total_wt * plans[0].nslots_total;      // filled by rbr_textcnn_prod_prepare
     const int max_items = (plans[0].total_wt + kWavesPerWG - 1) / kWavesPerWG;
     if (prod_t_bf16(d))
-        hipLaunchKernelGGL(gather_pool_kernel<true>, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
-                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx);
+        { if (int e_ = rbr::launch<gather_pool_kernel<true>, 256>(dim3(max_items), dim3(256), 0, st, "textcnn gather_pool launch", plans[0], S.A, reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx)) return e_; }
     else
-        hipLaunchKernelGGL(gather_pool_kernel<false>, dim3(max_items), dim3(256), 0, st, plans[0], S.A,
-                           reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx);
-    RBR_CHECK_LAUNCH("textcnn gather_pool launch");
+        if (int e_ = rbr::launch<gather_pool_kernel<false>, 256>(dim3(max_items), dim3(256), 0, st, "textcnn gather_pool launch", plans[0], S.A, reinterpret_cast<const long long*>(ids), mask, gate, S.row_of_token, static_cast<const void*>(S.T), sched, pval, pidx)) return e_;
     return 0;
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ void b16_dma16(const void* gsrc, void* lds_base) {
 
 // NPROD plane products per f32 product: 6 (bf16x3), 3 (bf16x2), 1 (bf16)
 template <int NPROD>
-__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16_kernel(const B16Gemm g) {
+__device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int NPLANES = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
     const int n = min(*g.counter, g.cap);
@@ -216,7 +216,7 @@ template <int NT> struct B16d {
 };
 
 template <int NPROD, int NT>
-__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16d_kernel(const B16Gemm g) {
+__device__ __forceinline__ void prod_gemm_b16d_kernel(const B16Gemm& g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     using Cfg = B16d<NT>;
     constexpr int S = Cfg::kStages, NG = NT / 4;
@@ -370,7 +370,7 @@ struct B16sGemm {
     int cap, Dp, pitch, ngroups, nchunks16;
 };
 
-__global__ __launch_bounds__(256) void rows_to_b16_kernel(const int* __restrict__ counter, int cap, int D, int Dp,
+__device__ __forceinline__ void rows_to_b16_kernel(const int* __restrict__ counter, int cap, int D, int Dp,
                                                           const long long* __restrict__ tok_of_row, const float* __restrict__ table,
                                                           unsigned short* __restrict__ a16) {
     const int n = min(*counter, cap);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void rows_to_b16_kernel(const int* __restrict_
     }
 }
 
-__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16s_kernel(const B16sGemm g) {
+__device__ __forceinline__ void prod_gemm_b16s_kernel(const B16sGemm& g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int n = min(*g.counter, g.cap);
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -541,7 +541,7 @@ constexpr int kB16sdStages = 3;
 constexpr int kB16sdStageBytes = 2 * kB16sBBytes;                // 16 KiB: [group][k-half][tile]
 constexpr int kB16sdLds = kB16sdStages * kB16sdStageBytes;       // 48 KiB
 
-__global__ __launch_bounds__(kB16Threads, 2) void prod_gemm_b16sd_kernel(const B16Gemm g, unsigned short* __restrict__ T16, int nchunks16) {
+__device__ __forceinline__ void prod_gemm_b16sd_kernel(const B16Gemm& g, unsigned short* __restrict__ T16, int nchunks16) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     constexpr int S = kB16sdStages, NG = 2, NT = 8;
     const int n = min(*g.counter, g.cap);
@@ -653,12 +653,6 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
         g.T = static_cast<unsigned short*>(Tv); g.cap = cap; g.Dp = b16s_dp(d->D); g.pitch = pitch; g.ngroups = prod_b16_groups(cp_real);
         g.nchunks16 = (d->D + kB16KC - 1) / kB16KC;
         if (pitch < g.ngroups * kB16BN || (pitch & 1)) { set_error("product table pitch %d unusable", pitch); return RBR_ERR_BAD_ARG; }
-        static bool attr_s = false;
-        if (!attr_s) {
-            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16s_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kB16sLds), "prod_gemm_b16s LDS")) return e;
-            attr_s = true;
-        }
         // six or more column groups (cfg2): the rows straight from the f32 table into registers, no compact copy, two groups per
         // workgroup -- 25.4 us against 8.4 (rows_to_b16) + 24.1, the step of the class 0.329 -> 0.313 ms.  RBR_B16_ROWS_COPY=1: the
         // two-launch form below (which smaller shapes keep: they do not fill the chip with half the workgroups).
@@ -668,18 +662,13 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
             gd.counter = counter; gd.tok_of_row = tok_of_row; gd.table = table; gd.bimg = g.bimg; gd.T = nullptr;
             gd.cap = cap; gd.D = d->D; gd.pitch = pitch; gd.ngroups = g.ngroups; gd.nchunks = g.nchunks16;
             const int mb = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
-            hipLaunchKernelGGL(prod_gemm_b16sd_kernel, dim3((unsigned)(mb * ((g.ngroups + 1) / 2))), dim3(kB16Threads), kB16sdLds, st, gd,
-                               g.T, g.nchunks16);
-            RBR_CHECK_LAUNCH("textcnn prod_gemm_b16sd launch");
+            if (int e_ = rbr::launch<prod_gemm_b16sd_kernel, kB16Threads, 2>(dim3((unsigned)(mb * ((g.ngroups + 1) / 2))), dim3(kB16Threads), kB16sdLds, st, "textcnn prod_gemm_b16sd launch", gd, g.T, g.nchunks16)) return e_;
             return 0;
         }
         const long segs = (long)cap * (g.Dp / 8);
-        hipLaunchKernelGGL(rows_to_b16_kernel, dim3((unsigned)std::min<long>((segs + 255) / 256, 4096)), dim3(256), 0, st, counter, cap, d->D,
-                           g.Dp, tok_of_row, table, static_cast<unsigned short*>(a16));
-        RBR_CHECK_LAUNCH("textcnn rows_to_b16 launch");
+        if (int e_ = rbr::launch<rows_to_b16_kernel, 256>(dim3((unsigned)std::min<long>((segs + 255) / 256, 4096)), dim3(256), 0, st, "textcnn rows_to_b16 launch", counter, cap, d->D, g.Dp, tok_of_row, table, static_cast<unsigned short*>(a16))) return e_;
         const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
-        hipLaunchKernelGGL(prod_gemm_b16s_kernel, dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16sLds, st, g);
-        RBR_CHECK_LAUNCH("textcnn prod_gemm_b16s launch");
+        if (int e_ = rbr::launch<prod_gemm_b16s_kernel, kB16Threads, 2>(dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16sLds, st, "textcnn prod_gemm_b16s launch", g)) return e_;
         return 0;
     }
     float* T = static_cast<float*>(Tv);
@@ -687,17 +676,7 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     g.counter = counter; g.tok_of_row = tok_of_row; g.table = table; g.bimg = static_cast<const unsigned char*>(bimg); g.T = T;
     g.cap = cap; g.D = d->D; g.pitch = pitch; g.ngroups = prod_b16_groups(cp_real); g.nchunks = (d->D + kB16KC - 1) / kB16KC;
     if (pitch < g.ngroups * kB16BN) { set_error("product table pitch %d < %d", pitch, g.ngroups * kB16BN); return RBR_ERR_BAD_ARG; }
-    static bool attr_set = false;
-    if (!attr_set) {
-        // dynamic LDS is declared to the runtime (needed above 64 KiB; harmless below)
-        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<6>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<6> LDS")) return e;
-        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<3>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<3> LDS")) return e;
-        if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16_kernel<1>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kB16Lds), "prod_gemm_b16<1> LDS")) return e;
-        attr_set = true;
-    }
+    // (dynamic LDS above 64 KiB: rbr::launch raises the wrapper kernels' limit at their first launch)
     const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;           // whole XCD rounds
     const dim3 grid((unsigned)(mblocks * g.ngroups)), block(kB16Threads);
     // The form with the token rows in registers and two 128-column groups per workgroup (prod_gemm_b16d_kernel) where it was
@@ -706,34 +685,20 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     // groups but K = 100: 7 steps) 61 against 58 -- those keep the kernel above.
     static const bool direct_ok = getenv("RBR_GEMM_ROWS_IN_LDS") == nullptr || atoi(getenv("RBR_GEMM_ROWS_IN_LDS")) == 0;
     if (direct_ok && g.ngroups >= 6 && g.nchunks >= 12) {
-        static bool attr_d = false;
-        if (!attr_d) {
-            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<6, 8>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<6> LDS")) return e;
-            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<3, 8>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<3> LDS")) return e;
-            if (int e = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(prod_gemm_b16d_kernel<1, 8>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, B16d<8>::kLds), "prod_gemm_b16d<1> LDS")) return e;
-            attr_d = true;
-        }
         const dim3 grid_d((unsigned)(mblocks * ((g.ngroups + 1) / 2)));
         switch (prod_precision()) {
-            case RBR_PROD_BF16X3: hipLaunchKernelGGL((prod_gemm_b16d_kernel<6, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
-            case RBR_PROD_BF16X2: hipLaunchKernelGGL((prod_gemm_b16d_kernel<3, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
-            case RBR_PROD_BF16: hipLaunchKernelGGL((prod_gemm_b16d_kernel<1, 8>), grid_d, block, B16d<8>::kLds, st, g); break;
+            case RBR_PROD_BF16X3: return rbr::launch<prod_gemm_b16d_kernel<6, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
+            case RBR_PROD_BF16X2: return rbr::launch<prod_gemm_b16d_kernel<3, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
+            case RBR_PROD_BF16: return rbr::launch<prod_gemm_b16d_kernel<1, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
             default: set_error("prod_b16_gemm called in f32 mode"); return RBR_ERR_BAD_ARG;
         }
-        RBR_CHECK_LAUNCH("textcnn prod_gemm_b16d launch");
-        return 0;
     }
     switch (prod_precision()) {
-        case RBR_PROD_BF16X3: hipLaunchKernelGGL(prod_gemm_b16_kernel<6>, grid, block, kB16Lds, st, g); break;
-        case RBR_PROD_BF16X2: hipLaunchKernelGGL(prod_gemm_b16_kernel<3>, grid, block, kB16Lds, st, g); break;
-        case RBR_PROD_BF16: hipLaunchKernelGGL(prod_gemm_b16_kernel<1>, grid, block, kB16Lds, st, g); break;
+        case RBR_PROD_BF16X3: return rbr::launch<prod_gemm_b16_kernel<6>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
+        case RBR_PROD_BF16X2: return rbr::launch<prod_gemm_b16_kernel<3>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
+        case RBR_PROD_BF16: return rbr::launch<prod_gemm_b16_kernel<1>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
         default: set_error("prod_b16_gemm called in f32 mode"); return RBR_ERR_BAD_ARG;
     }
-    RBR_CHECK_LAUNCH("textcnn prod_gemm_b16 launch");
-    return 0;
 }
 
 }  // namespace rbr

@@ -1611,6 +1611,239 @@ def datt_gate(table, w, b0, ids, *, is_global, padding_idx=0, rows=None):
     return _DattGate.apply(table, w, b0, ids, is_global, padding_idx, rows)
 
 
+# --------------------------------------------------------------------------- D-ATT: both towers through every kernel in one pass
+@contextlib.contextmanager
+def _pair_region():
+    """with _pair_region() as region: problem 0's calls; region.next(); problem 1's calls -- the C-ABI calls inside are recorded,
+    and leave at the end as shared launches (rbr_pair_begin / _next / _end of rbr_hip.h).  Nothing but library calls and
+    allocations may happen inside (a torch op would run ahead of the recorded launches)."""
+    L_ = _lib.lib()
+    check(L_.rbr_pair_begin(), "rbr_pair_begin")
+
+    class _Region:
+        paired = singles = 0
+
+        @staticmethod
+        def next():
+            check(L_.rbr_pair_next(), "rbr_pair_next")
+
+    region = _Region()
+    try:
+        yield region
+    except BaseException:
+        L_.rbr_pair_abort()
+        raise
+    n_p, n_s = C.c_int32(0), C.c_int32(0)
+    check(L_.rbr_pair_end(C.byref(n_p), C.byref(n_s)), "rbr_pair_end")
+    region.paired, region.singles = n_p.value, n_s.value
+
+
+PAIR_STATS = {"paired": 0, "singles": 0}      # launches of the last paired D-ATT forward + backward that left as pairs / singly
+
+
+def datt_pair_applies(table, docs2, local_w, conv_ws) -> bool:
+    """True when both D-ATT towers can go through datt_towers(): equal shapes by construction (one [2B, L] id block), the
+    token-product forms of the local gate and of the merged four-bank conv apply, the distinct-token rows pay, and the GEMM is
+    one of the bf16-plane kernels (the f32 MFMA kernel still launches directly)."""
+    if not (table.is_cuda and table.dtype == F32 and docs2.dim() == 2 and docs2.shape[0] % 2 == 0):
+        return False
+    if os.environ.get("RBR_DATT_PAIRED", "1") == "0" or get_prod_precision() == "f32":
+        return False
+    B, L = docs2.shape[0] // 2, docs2.shape[1]
+    V, E = table.shape
+    win = int(local_w.shape[2])
+    L_ = _lib.lib()
+    if V * 5 > B * L * 2 or B * L < 4096 or os.environ.get("RBR_DATT_ROWS", "1") == "0":
+        return False
+    if not L_.rbr_datt_local_gate_prod_ws_bytes(B, L, E, win, V) or not L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V):
+        return False
+    desc = _lib.make_desc(B, L, E, V, [int(w.shape[2]) for w in conv_ws], [int(w.shape[0]) for w in conv_ws], PAD_VALID, ACT_TANH, 0,
+                          _lib.conv_gate_split(1))
+    return bool(L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc)) > 0 and L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc)) > 0
+                and conv_ws[0].shape[2] == 1)
+
+
+class _DattTowers(torch.autograd.Function):
+    """feats [2B, l_out + 3 g_out] = both D-ATT towers' encoders (reference models/dual_att/dual_att.py:45-57, layers.py:43-53,
+    81-89): per tower the distinct-token rows, the local gate, the global gate and the merged four-bank gated conv (local 1-wide
+    bank under the local gate, global 2/3/4-wide banks under the global gate) -- the SAME C-ABI calls the single-tower functions
+    make (_DattGate, _TextCNN), issued for tower 0 and tower 1 inside a pair region, so every kernel runs once for both towers
+    (gridDim.z = 2).  The towers have separate parameters and share the word table; each tower adds its table-gradient rows
+    into a buffer of its own (two towers' workgroups of one launch may meet in a row) and the buffers are summed at the end."""
+
+    N_TOWER_PARAMS = 12        # local attn w, b | global attn w, b | conv weights x4 | conv biases x4
+
+    @staticmethod
+    def forward(ctx, table, docs2, padding_idx, pad_runs, *params):
+        NP = _DattTowers.N_TOWER_PARAMS
+        if len(params) != 2 * NP:
+            raise RuntimeError("datt_towers: expected 2 x 12 tower parameters")
+        L_ = _lib.lib()
+        dev = table.device
+        table_c = table.contiguous()
+        dev_ptr(table_c, F32, "word table")
+        docs2 = docs2.contiguous()
+        dev_ptr(docs2, I64, "docs")
+        B, L = docs2.shape[0] // 2, docs2.shape[1]
+        V, E = table.shape
+        pad = -1 if padding_idx is None else int(padding_idx)
+        st = current_stream()
+        towers = []
+        for t in range(2):
+            q = [x.contiguous() for x in params[t * NP:(t + 1) * NP]]
+            tw = _ConvSaved(ids=docs2[t * B:(t + 1) * B], lw=q[0], lb=q[1], gw=q[2], gb=q[3], ws=q[4:8], bs=q[8:12])
+            if tw.gw.shape[2] != L:
+                raise RuntimeError(f"GlobalAttention weight spans {tw.gw.shape[2]} positions but documents have {L}")
+            towers.append(tw)
+        win = int(towers[0].lw.shape[2])
+        kz = [int(w.shape[2]) for w in towers[0].ws]
+        ch = [int(w.shape[0]) for w in towers[0].ws]
+        for tw in towers:
+            if [int(w.shape[2]) for w in tw.ws] != kz or [int(w.shape[0]) for w in tw.ws] != ch or int(tw.lw.shape[2]) != win:
+                raise RuntimeError("datt_towers: the towers' layers must have equal shapes")
+        flags = _lib.conv_gate_split(1) | (_lib.CONV_PAD_RUNS if (pad_runs and padding_idx is not None
+                                                                   and os.environ.get("RBR_PAD_RUNS", "1") != "0") else 0)
+        desc = _lib.make_desc(B, L, E, V, kz, ch, PAD_VALID, ACT_TANH, padding_idx, flags)
+        Ctot = sum(ch)
+        n_part = L_.rbr_textcnn_partial_elems(C.byref(desc))
+        ws_bytes = L_.rbr_textcnn_fwd_ws_bytes(C.byref(desc))
+        rows_bytes = L_.rbr_datt_token_rows_ws_bytes(B, L, V)
+        gws_bytes = L_.rbr_datt_local_gate_prod_ws_bytes(B, L, E, win, V)
+        if not (n_part and ws_bytes and rows_bytes and gws_bytes):
+            check(-1, "datt_towers plan (datt_pair_applies() was not consulted)")
+        feats = torch.empty(2 * B, Ctot, dtype=F32, device=dev)
+        argmax = torch.empty(2 * B, Ctot, dtype=I32, device=dev)
+        for t, tw in enumerate(towers):          # allocations only: nothing here launches
+            tw.rows = torch.empty(rows_bytes, dtype=torch.uint8, device=dev)
+            tw.gate2 = torch.empty(2, B, L, dtype=F32, device=dev)          # plane 0: local gate, plane 1: global gate
+            tw.gate_ws = torch.empty(gws_bytes, dtype=torch.uint8, device=dev)
+            tw.pval = torch.empty(n_part, dtype=F32, device=dev)
+            tw.pidx = torch.empty(n_part, dtype=I32, device=dev)
+            tw.prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            tw.feat, tw.argmax = feats[t * B:(t + 1) * B], argmax[t * B:(t + 1) * B]
+        ev = TIMER.record("datt_towers_fwd")
+        with _pair_region() as region:
+            for t, tw in enumerate(towers):
+                if t == 1:
+                    region.next()
+                ids_p = dev_ptr(tw.ids, I64, "ids")
+                check(L_.rbr_datt_token_rows(B, L, V, ids_p, tw.rows.data_ptr(), st), "rbr_datt_token_rows")
+                check(L_.rbr_datt_local_gate_fwd_prod(B, L, E, win, V, ids_p, dev_ptr(table_c, F32, "table"), dev_ptr(tw.lw, F32, "w"),
+                                                      dev_ptr(tw.lb, F32, "b0"), dev_ptr(tw.gate2[0], F32, "gate"), tw.gate_ws.data_ptr(),
+                                                      tw.rows.data_ptr(), st), "rbr_datt_local_gate_fwd_prod")
+                check(L_.rbr_datt_global_gate_fwd(B, L, E, ids_p, dev_ptr(table_c, F32, "table"), dev_ptr(tw.gw, F32, "w"),
+                                                  dev_ptr(tw.gb, F32, "b0"), dev_ptr(tw.gate2[1], F32, "gate"), st),
+                      "rbr_datt_global_gate_fwd")
+                wsp = tw.prod_ws.data_ptr()
+                check(L_.rbr_textcnn_prod_prepare(C.byref(desc), ids_p, None, ptr_array(tw.ws, F32, "conv weight"),
+                                                  dev_ptr(tw.pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_prepare")
+                check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
+                check(L_.rbr_textcnn_prod_pool(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), dev_ptr(tw.pval, F32, "pval"),
+                                               dev_ptr(tw.pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
+                check(L_.rbr_textcnn_pool_finalize(C.byref(desc), dev_ptr(tw.pval, F32, "pval"), dev_ptr(tw.pidx, I32, "pidx"),
+                                                   ptr_array(tw.bs, F32, "conv bias"), dev_ptr(tw.feat, F32, "feat"),
+                                                   dev_ptr(tw.argmax, I32, "argmax"), st), "rbr_textcnn_pool_finalize")
+        if ev is not None:
+            ev.record()
+        PAIR_STATS["paired"], PAIR_STATS["singles"] = region.paired, region.singles
+        for tw in towers:
+            tw.pval = tw.pidx = None           # only the backward's inputs stay
+        ctx.towers, ctx.desc, ctx.table = towers, desc, table_c
+        ctx.dims = (B, L, V, E, win, pad)
+        ctx.keep = (feats, argmax, docs2)
+        ctx.set_materialize_grads(False)
+        return feats
+
+    @staticmethod
+    def backward(ctx, d_feats):
+        NP = _DattTowers.N_TOWER_PARAMS
+        towers, desc, table = ctx.towers, ctx.desc, ctx.table
+        B, L, V, E, win, pad = ctx.dims
+        L_ = _lib.lib()
+        dev = table.device
+        if d_feats is None:
+            d_feats = torch.zeros_like(ctx.keep[0])
+        d_feats = d_feats.contiguous()
+        need_table = ctx.needs_input_grad[0]
+        # one zeroed gradient buffer per tower (see the class comment); allocated and cleared BEFORE the region
+        dtab = torch.zeros(2, V, E, dtype=F32, device=dev) if need_table else None
+        bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc))
+        gg_floats = L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V)
+        wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
+        for tw in towers:
+            tw.bws = torch.empty(bws_bytes, dtype=torch.uint8, device=dev)
+            tw.dgate2 = torch.empty(2, B, L, dtype=F32, device=dev)          # zeroed by the launch that zeroes G's rows
+            tw.gg_ws = torch.empty(gg_floats, dtype=F32, device=dev)
+            tw.wsb = torch.empty(max(wsn, 1), dtype=F32, device=dev)
+            tw.grads = ([torch.empty_like(tw.lw), torch.empty(1, dtype=F32, device=dev), torch.empty_like(tw.gw),
+                         torch.empty(1, dtype=F32, device=dev)] + [torch.empty_like(w) for w in tw.ws]
+                        + [torch.empty(w.shape[0], dtype=F32, device=dev) for w in tw.ws])
+        st = current_stream()
+        # the conv weight gradient (dw_partial4, dw_reduce) starts from d_feats alone: second stream, beside the table-gradient
+        # chain, as in _textcnn_backward.  The fork is recorded before the region's launches leave, the join after them.
+        side = _side_stream(dev)
+        fork = join = None
+        if side is not None:
+            fork = torch.cuda.Event()
+            fork.record()
+            side.wait_event(fork)
+        st_dw = side.cuda_stream if side is not None else st
+        ev = TIMER.record("datt_towers_bwd")
+        with _pair_region() as region:
+            for t, tw in enumerate(towers):
+                if t == 1:
+                    region.next()
+                ids_p = dev_ptr(tw.ids, I64, "ids")
+                d_feat = d_feats[t * B:(t + 1) * B]
+                dt = dev_ptr(dtab[t], F32, "dtable") if need_table else None
+                tab = dev_ptr(table, F32, "table")
+                # G, d(gate) and -- when wanted -- this tower's conv share of the table gradient
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
+                                                        dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                                        dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt,
+                                                        dev_ptr(tw.dgate2, F32, "dgate"), None,
+                                                        _lib.G_BUILD | ((_lib.G_PRODUCT | _lib.G_ACCUMULATE) if need_table else 0), st),
+                      "rbr_textcnn_bwd_dtable_prod")
+                check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, V, ids_p, tab, dev_ptr(tw.lw, F32, "w"),
+                                                      dev_ptr(tw.gate2[0], F32, "gate"), dev_ptr(tw.dgate2[0], F32, "dgate"), pad,
+                                                      dev_ptr(tw.grads[0], F32, "dw"), dev_ptr(tw.grads[1], F32, "db0"), dt,
+                                                      tw.gate_ws.data_ptr(), tw.rows.data_ptr(), 1, st), "rbr_datt_local_gate_bwd_prod")
+                check(L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, ids_p, tab, dev_ptr(tw.gw, F32, "w"),
+                                                       dev_ptr(tw.gate2[1], F32, "gate"), dev_ptr(tw.dgate2[1], F32, "dgate"), pad,
+                                                       dev_ptr(tw.grads[2], F32, "dw"), dev_ptr(tw.grads[3], F32, "db0"), dt,
+                                                       dev_ptr(tw.gg_ws, F32, "ws"), tw.rows.data_ptr(), 1, st),
+                      "rbr_datt_global_gate_bwd_rows")
+                check(L_.rbr_textcnn_bwd_dw(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), tab,
+                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                            dev_ptr(d_feat, F32, "d_feat"), ptr_array(tw.grads[4:8], F32, "dW"),
+                                            ptr_array(tw.grads[8:12], F32, "dbias"), dev_ptr(tw.wsb, F32, "ws"), st_dw), "rbr_textcnn_bwd_dw")
+        if side is not None:
+            with torch.cuda.stream(side):
+                join = torch.cuda.Event()
+                join.record()
+            _join(join)
+        if ev is not None:
+            ev.record()
+        PAIR_STATS["paired"] += region.paired
+        PAIR_STATS["singles"] += region.singles
+        dtable = (dtab[0].add_(dtab[1])) if need_table else None
+        grads = towers[0].grads + towers[1].grads
+        for tw in towers:
+            tw.bws = tw.dgate2 = tw.gg_ws = tw.wsb = tw.grads = None
+        return (dtable, None, None, None, *grads)
+
+
+def datt_towers(table, docs2, u_params, i_params, *, padding_idx=0, pad_runs=True):
+    """Both D-ATT towers' encoders in one pass (see _DattTowers): docs2 [2B, L] int64 (user documents, then item documents);
+    u_params / i_params = (local attn weight [1,E,win], bias [1], global attn weight [1,E,L], bias [1], [4 conv weights],
+    [4 conv biases]).  Returns feats [2B, l_out + 3 g_out], user rows first: cat((local, global), 1) per tower."""
+    flat = []
+    for q in (u_params, i_params):
+        lw, lb, gw, gb, ws, bs = q
+        flat += [lw, lb, gw, gb, *ws, *bs]
+    return _DattTowers.apply(table, docs2, padding_idx, pad_runs, *flat)
+
+
 def datt_token_rows(ids, vocab_size):
     """Distinct-token row maps of one tower's documents (rbr_datt_token_rows), or None where they do not pay (few positions
     per vocabulary entry: the same rule as the token-product conv)."""

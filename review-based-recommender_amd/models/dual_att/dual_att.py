@@ -56,12 +56,27 @@ class DualAtt(nn.Module):
         hid = RF.linear(feat, self.fc[0].weight, self.fc[0].bias, relu=True, drop=drop)
         return RF.linear(hid, self.fc[3].weight, self.fc[3].bias)
 
+    def _tower_params(self, local, glob):
+        convs = [local.conv[0], glob.conv1[0], glob.conv2[0], glob.conv3[0]]
+        return (local.attn[0].weight, local.attn[0].bias, glob.attn[0].weight, glob.attn[0].bias,
+                [c.weight for c in convs], [c.bias for c in convs])
+
     def forward(self, u_docs, i_docs):
         """u_docs / i_docs [bz, doc_len] int64 -> ratings [bz]."""
         bz = u_docs.shape[0]
+        pad = self.word_embeddings.padding_idx
         if self.validate_ids:
-            pad = self.word_embeddings.padding_idx
             u_docs, i_docs = RF.sanitize_ids([(u_docs, self.vocab_size, pad), (i_docs, self.vocab_size, pad)])
+        # Both towers through every kernel in ONE pass (RF.datt_towers): the towers run the same ops on separate parameters and
+        # documents of equal shapes (dual_att.py:45-57), so each kernel of the chain -- token rows, both gates, the merged
+        # four-bank conv, and their backwards -- is launched once with gridDim.z = 2 instead of once per tower.
+        u_par, i_par = self._tower_params(self.u_local_atten, self.u_global_atten), self._tower_params(self.i_local_atten, self.i_global_atten)
+        if u_docs.shape == i_docs.shape and self.u_local_atten.window_size == self.i_local_atten.window_size:
+            docs2 = RF.stack_rows(u_docs, i_docs)
+            if RF.datt_pair_applies(self.word_embeddings.weight, docs2, u_par[0], u_par[4]):
+                feats = RF.datt_towers(self.word_embeddings.weight, docs2, u_par, i_par, padding_idx=pad,
+                                       pad_runs=self.u_local_atten.window_size <= 17)
+                return RF.pair_dot(self._fc(feats)).view(-1)                # sum(u_feat * i_feat, 1)  (dual_att.py:58)
         # eight ops of the step produce gradient for the word table (a gate and a conv, local and global, per tower): each gets
         # its own alias, and their backwards add their rows into one buffer instead of eight dense gradients summed by autograd
         # (Tried in round 3 and dropped: the item tower on a stream of its own, so that one tower's ~40 latency-bound launches run

@@ -1,0 +1,138 @@
+"""D-ATT: both towers through every kernel in one pass (functional.datt_towers, csrc/rbr_launch.h pair regions) against the two
+single-tower passes it replaces and against the CPU oracle (oracle/ref_cpu.py: reference models/dual_att/dual_att.py:37-61,
+layers.py:25-89).
+
+The paired pass issues the SAME C-ABI calls with the same arguments as the single-tower functions; only the launches are
+shared (gridDim.z = 2).  So: features and argmax come out bit for bit, gradients to summation order (f32 atomics in build_g and
+in the gates' scatter), and the launch count of a step falls."""
+import os
+
+import pytest
+import torch
+
+import synth
+from helpers import quiet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+# large enough for the token-product forms (V * 5 <= B * L * 2, B * L >= 4096), small enough for the CPU oracle
+MID = dict(B=12, L=512, E=40, win=5, l_out=24, g_out=12, h1=32, h2=8, V=1500)
+
+
+def _model(cfg, scale=0.5):
+    from review_based_recommender_amd.models.dual_att.dual_att import DualAtt
+    c = cfg
+    m = quiet(DualAtt, c["V"], c["L"], c["win"], c["l_out"], c["g_out"], c["E"], c["h1"], c["h2"], 0.0, None)
+    m.load_state_dict(synth.datt_params(cfg, 0, table_scale=scale))
+    return m.to(DEV)
+
+
+class _paired:
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("RBR_DATT_PAIRED")
+        os.environ["RBR_DATT_PAIRED"] = "1" if self.on else "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("RBR_DATT_PAIRED", None)
+        else:
+            os.environ["RBR_DATT_PAIRED"] = self.old
+
+
+def _step(model, args, ratings):
+    model.zero_grad(set_to_none=True)
+    pred = model(*args)
+    torch.nn.functional.mse_loss(pred, ratings).backward()
+    torch.cuda.synchronize()
+    return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("cfgname", ["mid", "cfg4"])
+def test_paired_towers_equal_the_two_single_tower_passes(cfgname):
+    from review_based_recommender_amd import functional as RF
+    cfg = MID if cfgname == "mid" else synth.DATT_CFGS["cfg4"]
+    model = _model(cfg, scale=0.5 if cfgname == "mid" else 0.3)
+    model.train()
+    b = synth.datt_batch(cfg, 3)
+    args, ratings = (b["u_docs"].to(DEV), b["i_docs"].to(DEV)), b["ratings"].to(DEV)
+    with _paired(False):
+        pred_s, grads_s = _step(model, args, ratings)
+    RF.PAIR_STATS["paired"] = RF.PAIR_STATS["singles"] = 0
+    with _paired(True):
+        pred_p, grads_p = _step(model, args, ratings)
+    assert RF.PAIR_STATS["paired"] >= 30, f"the towers' launches did not pair up: {RF.PAIR_STATS}"
+    assert RF.PAIR_STATS["singles"] == 0, f"some launches of the towers left singly: {RF.PAIR_STATS}"
+    # forward: the same kernels on the same inputs -> the same bits
+    assert torch.equal(pred_p, pred_s)
+    for k in grads_s:
+        ref = grads_s[k]
+        scale = float(ref.norm()) + 1e-30
+        err = float((grads_p[k] - ref).abs().max())
+        assert err <= 1e-7 + 2e-5 * scale, (k, err, scale)
+
+
+def test_paired_features_and_argmax_are_the_single_tower_bits():
+    """functional.datt_towers against datt_gate x2 + textcnn(gate_split) per tower: features bit for bit."""
+    from review_based_recommender_amd import functional as RF
+    cfg = MID
+    model = _model(cfg)
+    b = synth.datt_batch(cfg, 4, edge_cases=True)
+    u, i = b["u_docs"].to(DEV), b["i_docs"].to(DEV)
+    docs2 = torch.cat([u, i])
+    table = model.word_embeddings.weight
+    up = model._tower_params(model.u_local_atten, model.u_global_atten)
+    ip = model._tower_params(model.i_local_atten, model.i_global_atten)
+    assert RF.datt_pair_applies(table, docs2, up[0], up[4])
+    with torch.no_grad():
+        feats = RF.datt_towers(table, docs2, up, ip, padding_idx=0, pad_runs=True)
+        with _paired(False):
+            tabs = (table,) * 4
+            fu, _ = model._encode(u, model.u_local_atten, model.u_global_atten, tabs)
+            fi, _ = model._encode(i, model.i_local_atten, model.i_global_atten, tabs)
+    torch.cuda.synchronize()
+    assert torch.equal(feats[:cfg["B"]], fu) and torch.equal(feats[cfg["B"]:], fi)
+
+
+def test_paired_towers_match_the_oracle():
+    """Predictions and every gradient of the paired pass against autograd over the CPU restatement of the reference."""
+    from oracle import ref_cpu as O
+    cfg = MID
+    model = _model(cfg)
+    model.train()
+    b = synth.datt_batch(cfg, 5, edge_cases=True)
+    args, ratings = (b["u_docs"].to(DEV), b["i_docs"].to(DEV)), b["ratings"].to(DEV)
+    with _paired(True):
+        pred, grads = _step(model, args, ratings)
+    p = {k: v.clone().requires_grad_(True) for k, v in synth.datt_params(cfg, 0, table_scale=0.5).items()}
+    ref = O.datt_forward(p, b["u_docs"], b["i_docs"])
+    torch.nn.functional.mse_loss(ref, b["ratings"]).backward()
+    assert float((pred.cpu() - ref.detach()).abs().max()) <= 1e-4
+    for k, g in grads.items():
+        r = p[k].grad
+        scale = float(r.norm()) + 1e-12
+        err = float((g.cpu() - r).abs().max())
+        assert err <= 2e-6 + 2e-4 * scale, (k, err, scale)
+
+
+def test_pair_region_refuses_entry_points_that_launch_directly():
+    """Inside rbr_pair_begin / rbr_pair_end an entry point that still launches with hipLaunchKernelGGL would run ahead of the
+    recorded launches: it must answer RBR_ERR_UNSUPPORTED (a Python RuntimeError), and the region can be dropped."""
+    from review_based_recommender_amd import _lib
+    L_ = _lib.lib()
+    x = torch.zeros(64, 8, device=DEV)
+    ids = torch.zeros(4, dtype=torch.int64, device=DEV)
+    out = torch.empty(4, 8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L_.rbr_pair_begin() == 0
+    try:
+        assert L_.rbr_pair_begin() != 0                      # not re-entrant
+        rc = L_.rbr_embedding_fwd(4, 8, ids.data_ptr(), x.data_ptr(), out.data_ptr(), st)
+        assert rc != 0 and b"pair" in L_.rbr_last_error()
+    finally:
+        L_.rbr_pair_abort()
+    assert L_.rbr_pair_end(None, None) != 0                  # nothing open any more
+    assert L_.rbr_embedding_fwd(4, 8, ids.data_ptr(), x.data_ptr(), out.data_ptr(), st) == 0
+    torch.cuda.synchronize()

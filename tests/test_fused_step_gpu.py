@@ -139,8 +139,9 @@ def test_hipclipadam_then_torch_adam_on_one_model_updates_the_table():
             assert float((ta.grad - tb.grad).abs().max()) <= 2e-6 + 2e-3 * float(tb.grad.abs().max()), k
             moved_a, moved_b = (ta.detach() - before).abs().sum(1) > 0, tb.grad.abs().sum(1) > 0
             # the rows of THIS batch moved (a fresh Adam moves an element by ~lr wherever its gradient is not vanishingly small)
-            assert not bool((moved_a & ~moved_b).any()) and int(moved_a.sum()) >= 0.98 * int(moved_b.sum()) > 0, \
-                (k, int(moved_a.sum()), int(moved_b.sum()))
+            assert int((moved_a & moved_b).sum()) >= 0.98 * int(moved_b.sum()) > 0, (k, int(moved_a.sum()), int(moved_b.sum()))
+            if k == 2:          # a fresh Adam: nothing but this batch's rows can move (later steps also carry momentum of earlier rows)
+                assert not bool((moved_a & ~moved_b).any()), (int(moved_a.sum()), int(moved_b.sum()))
         del stepper
     finally:
         HipClipAdam.ROW_GRAD_MIN_ROWS = keep_rows
