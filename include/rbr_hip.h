@@ -472,6 +472,18 @@ int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const flo
 size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT);
 int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
                    int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, void* stream);
+/* The same layer with its products SPLIT ALONG K over several workgroups per output tile (D-ATT's shared fc, dual_att.py:31-35:
+ * 1024 x 500 x 500 is 128 output tiles on 256 CUs, its weight gradients 64 and 8): every slice writes a partial tile to `ws`, a
+ * second launch adds the partial tiles in slice order and applies bias / activation / dropout.  Same results as the calls above
+ * up to the summation order over K; run to run the same bits.
+ *   ws: rbr_linear_fwd_ws_floats(N, IN, OUT) floats (0 = the shape is not split: ws may be NULL) /
+ *       rbr_linear_bwd_ex_ws_floats(N, IN, OUT) floats (covers rbr_linear_bwd_ws_floats). */
+size_t rbr_linear_fwd_ws_floats(int32_t N, int32_t IN, int32_t OUT);
+size_t rbr_linear_bwd_ex_ws_floats(int32_t N, int32_t IN, int32_t OUT);
+int rbr_linear_fwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b, int32_t relu,
+                      const float* drop, float* y, float* ws, void* stream);
+int rbr_linear_bwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
+                      int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, void* stream);
 
 /* ---- standalone word-embedding row gather / scatter-add (WordEmbedding.forward, deepconn/layers.py:22-24).
  *      The models never call these (the gather is fused into the conv kernel); they serve callers that

@@ -1008,6 +1008,7 @@ extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, in
         if (int e_ = rbr::launch<transpose_w_kernel, 256>(dim3((unsigned)std::min<long>(((long)E * L + 255) / 256, 2048)), dim3(256), 0, st, "datt global gate transpose launch", E, L, w, wT)) return e_;
         int* dense_count = reinterpret_cast<int*>(A + (size_t)T.cap * L);
         int* dense_list = dense_count + 4;
+        PairSolo solo;        // zero A -> scatter into A -> rows from A: a chain over the 160 MB occurrence matrix (rbr_launch.h)
         if (int e_ = rbr::launch<gg_zero_kernel, 256>(dim3((unsigned)std::min<long>(((long)T.cap * L / 4 + 255) / 256, 8192)), dim3(256), 0, st, "datt global gate occurrence zero launch", T.cap, L, counter, reinterpret_cast<f32x4g*>(A), dense_count)) return e_;
         const long n_pos = (long)B * L;
         if (int e_ = rbr::launch<gg_scatter_kernel, 256>(dim3((unsigned)std::min<long>((n_pos + 255) / 256, 8192)), dim3(256), 0, st, "datt global gate occurrence scatter launch", B, L, pad_idx, ids64, row_of_token, (const float*)ws, A)) return e_;

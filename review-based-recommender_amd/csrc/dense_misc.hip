@@ -31,11 +31,20 @@ struct Epi {
     int relu;            // activation: 0 none, 1 ReLU, 2 Tanh
 };
 
-__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const float* __restrict__ A, long sam, long sak,
+// Split K (gridDim.z = slices > 1): D-ATT's shared fc is 128 output tiles, its weight gradients 64 and 8 -- a fraction of the
+// chip's 256 CUs, each tile a chain of K / 32 barrier-separated chunks on ONE wave per SIMD.  Slice z multiplies K range
+// [z * kper, (z + 1) * kper) into a partial tile in `part` ([slice][tile][4 waves][16][64] floats); gemm_reduce_kernel adds the
+// partial tiles in slice order and applies the epilogue.  (Measured and dropped: ONE launch in which the last slice of a tile
+// to arrive -- a ticket per tile -- does the reduction: the release / acquire fences that make the partial tiles visible across
+// the 8 XCDs write back and invalidate whole L2s, and the 1024 x 500 x 500 fc took 84 us instead of 24.)
+__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K_all, const float* __restrict__ A, long sam, long sak,
                                                    const float* __restrict__ B, long sbn, long sbk, float* __restrict__ C,
-                                                   long ldc, const Epi ep, long bytes_a, long bytes_b) {
+                                                   long ldc, const Epi ep, long bytes_a, long bytes_b, int kper,
+                                                   float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float As[64 * GS];
     __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
+    const int kb = (gridDim.z > 1) ? (int)blockIdx.z * kper : 0;
+    const int K = (gridDim.z > 1) ? min(K_all - kb, kper) : K_all;          // this slice's K extent (kper is a multiple of GK)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -64,8 +73,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int m = m0 + arow[q], n = n0 + brow[q];
-        offa[q] = (m < M) ? (int)((m * sam + akk[q] * sak) * 4) : kOutside;
-        offb[q] = (n < N) ? (int)((n * sbn + bkk[q] * sbk) * 4) : kOutside;
+        offa[q] = (m < M) ? (int)((m * sam + (kb + akk[q]) * sak) * 4) : kOutside;
+        offb[q] = (n < N) ? (int)((n * sbn + (kb + bkk[q]) * sbk) * 4) : kOutside;
     }
     auto fetch = [&](int k0, float (&fa)[8], float (&fb)[8]) {       // one straight-line path: 16 loads
         const int sa = (int)(k0 * sak * 4), sb = (int)(k0 * sbk * 4);
@@ -119,6 +128,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
         chunk(k0, std::true_type{}, ra[0], rb[0]);
         if (k0 + GK < K) chunk(k0 + GK, std::true_type{}, ra[1], rb[1]);
     }
+    if (gridDim.z > 1) {                              // a K slice: the partial tile goes to `part`, gemm_reduce_kernel finishes
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+        float* mine = part + (((long)blockIdx.z * ntiles + tile) * 4 + wave) * 1024 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+        return;
+    }
     const int n = n0 + wn * 32 + i;
     if (n >= N) return;
     const float bv = ep.bias ? ep.bias[n] : 0.f;
@@ -135,16 +151,83 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K, const fl
     }
 }
 
+// C tile = epilogue(sum over the slices, in slice order); same (wave, register, lane) -> (m, n) map as gemm_kernel's epilogue
+// One WAVE per 32 x 32 quadrant (grid z = quadrant): four times the workgroups of the product's grid, every load of a lane in flight
+// at once -- the kernel is two memory round trips long.
+__global__ __launch_bounds__(64) void gemm_reduce_kernel(int M, int N, int slices, const float* __restrict__ part, float* __restrict__ C,
+                                                         long ldc, const Epi ep) {
+    const int wave = blockIdx.z, lane = threadIdx.x;
+    const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int n = n0 + wn * 32 + i;
+    const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.f;
+    float mulv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        mulv[r] = (ep.mul && m < M && n < N) ? ep.mul[(long)m * N + n] : 1.f;
+    }
+    for (int z = 0; z < slices; z += 2) {            // two slices (32 loads) per round, added in slice order
+        const float* p0 = part + (((long)z * ntiles + tile) * 4 + wave) * 1024 + lane;
+        const float* p1 = part + (((long)min(z + 1, slices - 1) * ntiles + tile) * 4 + wave) * 1024 + lane;
+        float v0[16], v1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v0[r] = p0[r * 64]; v1[r] = p1[r * 64]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] += v0[r];
+            if (z + 1 < slices) acc[r] += v1[r];
+        }
+    }
+    if (n >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M) {
+            float v = acc[r] + bv;
+            if (ep.relu == 1) v = fmaxf(v, 0.f);
+            else if (ep.relu == 2) v = tanhf(v);
+            C[(long)m * ldc + n] = v * mulv[r];
+        }
+    }
+}
+
+// slices and K per slice for an M x N x K product: enough workgroups for two per CU, at least two chunks of K per slice
+static void gemm_split(int M, int N, int K, int& slices, int& kper) {
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    int s = (int)std::min<long>(8, std::max<long>(1, 512 / std::max<long>(tiles, 1)));
+    s = std::min(s, std::max(1, K / (2 * GK)));
+    kper = ((K + s - 1) / s + GK - 1) / GK * GK;
+    slices = (K + kper - 1) / kper;
+    if (slices <= 1) { slices = 1; kper = K; }
+}
+static size_t gemm_split_floats(int M, int N, int K) {
+    int s, kper;
+    gemm_split(M, N, K, s, kper);
+    return s > 1 ? (size_t)s * ((M + 63) / 64) * ((N + 63) / 64) * 4096 : 0;
+}
+
+// part: split-K scratch (gemm_split_floats floats) or NULL = one slice
 static int launch_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
-                       long ldc, Epi ep, hipStream_t st) {
+                       long ldc, Epi ep, hipStream_t st, float* part = nullptr) {
     const long bytes_a = ((long)(M - 1) * sam + (long)(K - 1) * sak + 1) * 4, bytes_b = ((long)(N - 1) * sbn + (long)(K - 1) * sbk + 1) * 4;
     if (bytes_a >= (1L << 30) || bytes_b >= (1L << 30)) {
         set_error("gemm operand of %ld / %ld bytes exceeds the 1 GiB the buffer addressing of this kernel covers", bytes_a, bytes_b);
         return RBR_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, C,
-                       ldc, ep, bytes_a, bytes_b);
+    int slices = 1, kper = K;
+    if (part != nullptr) gemm_split(M, N, K, slices, kper);
+    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, slices), dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, C,
+                       ldc, ep, bytes_a, bytes_b, kper, part);
     RBR_CHECK_LAUNCH("gemm launch");
+    if (slices > 1) {
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((N + 63) / 64, (M + 63) / 64, 4), dim3(64), 0, st, M, N, slices, part, C, ldc, ep);
+        RBR_CHECK_LAUNCH("gemm reduce launch");
+    }
     return 0;
 }
 
@@ -265,21 +348,50 @@ __global__ __launch_bounds__(256) void hier_bwd_kernel(int n_docs, int L, int D,
 
 using namespace rbr;
 
-extern "C" int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b,
-                              int32_t relu, const float* drop, float* y, void* stream) {
+static int linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b, int32_t relu,
+                      const float* drop, float* y, float* ws, void* stream) {
     if (N <= 0 || IN <= 0 || OUT <= 0) { set_error("bad linear shape"); return RBR_ERR_BAD_ARG; }
     if (!x || !W || !y) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     Epi ep{b, drop, relu};
-    return launch_gemm(N, OUT, IN, x, IN, 1, W, IN, 1, y, OUT, ep, (hipStream_t)stream);
+    return launch_gemm(N, OUT, IN, x, IN, 1, W, IN, 1, y, OUT, ep, (hipStream_t)stream, ws);
+}
+extern "C" int rbr_linear_fwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b,
+                              int32_t relu, const float* drop, float* y, void* stream) {
+    return linear_fwd(N, IN, OUT, x, W, b, relu, drop, y, nullptr, stream);
+}
+extern "C" size_t rbr_linear_fwd_ws_floats(int32_t N, int32_t IN, int32_t OUT) {
+    return (N > 0 && IN > 0 && OUT > 0) ? gemm_split_floats(N, OUT, IN) : 0;
+}
+extern "C" int rbr_linear_fwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* b,
+                                 int32_t relu, const float* drop, float* y, float* ws, void* stream) {
+    return linear_fwd(N, IN, OUT, x, W, b, relu, drop, y, ws, stream);
 }
 
 extern "C" size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT) { return (N > 0 && OUT > 0) ? (size_t)N * OUT : 0; }
+extern "C" size_t rbr_linear_bwd_ex_ws_floats(int32_t N, int32_t IN, int32_t OUT) {
+    if (N <= 0 || IN <= 0 || OUT <= 0) return 0;
+    return (size_t)N * OUT + std::max(gemm_split_floats(OUT, IN, N), gemm_split_floats(N, IN, OUT));
+}
 
+static int linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
+                      int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, bool split, void* stream);
 extern "C" int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y,
                               const float* d_y, int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws,
                               void* stream) {
+    return linear_bwd(N, IN, OUT, x, W, y, d_y, relu, drop, d_x, dW, db, ws, false, stream);
+}
+extern "C" int rbr_linear_bwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y,
+                                 const float* d_y, int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws,
+                                 void* stream) {
+    return linear_bwd(N, IN, OUT, x, W, y, d_y, relu, drop, d_x, dW, db, ws, true, stream);
+}
+
+// split: ws holds rbr_linear_bwd_ex_ws_floats (g, then the split-K partial tiles); else rbr_linear_bwd_ws_floats
+static int linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
+                      int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, bool split, void* stream) {
     if (N <= 0 || IN <= 0 || OUT <= 0) { set_error("bad linear shape"); return RBR_ERR_BAD_ARG; }
     if (!x || !W || !y || !d_y || !dW || !ws) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    float* part = split ? ws + (size_t)N * OUT : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const float* g = d_y;
     if (relu || drop) {
@@ -291,13 +403,13 @@ extern "C" int rbr_linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x
     }
     Epi none{nullptr, nullptr, 0};
     // dW[OUT, IN] = g^T[OUT, N] . x[N, IN]:  A(m=o, k=n) = g[n*OUT + o], B(n=i, k=n) = x[n*IN + i]
-    if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st)) return e;
+    if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st, part)) return e;
     if (db) {
         hipLaunchKernelGGL(colsum_kernel, dim3((OUT + 63) / 64), dim3(256), 0, st, N, OUT, g, db);
         RBR_CHECK_LAUNCH("linear colsum launch");
     }
     // d_x[N, IN] = g[N, OUT] . W[OUT, IN]:  A(m=n, k=o) = g[n*OUT + o], B(n=i, k=o) = W[o*IN + i]
-    if (d_x) return launch_gemm(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, st);
+    if (d_x) return launch_gemm(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, st, part);
     return 0;
 }
 

@@ -43,7 +43,15 @@ template <class H, class... T> struct Pack<H, T...> {
 inline Pack<> make_pack() { return {}; }
 template <class H, class... T> inline Pack<H, T...> make_pack(H h, T... t) { return Pack<H, T...>{h, make_pack(t...)}; }
 
-template <class T> constexpr bool kSharedArg = sizeof(T) > 256;      // passed once per pair (must be equal in both records)
+// Arguments passed ONCE per pair (they must be bytewise equal in both records, else the pair does not form): the shape-only
+// structs -- plans and dimension blocks, which hold no pointers and are the same for towers of equal shapes.  A struct that is
+// indexed dynamically by the body cannot be selected between two kernarg copies without being copied to scratch memory first,
+// so every such struct either is shape-only (marked here: RBR_SHARED_KERNEL_ARG) or holds nothing but pointers the body
+// indexes with constants.  Anything above 256 bytes counts as shared as well (kernarg space: 4 KB per launch).
+template <class T> struct SharedKernelArg : std::bool_constant<(sizeof(T) > 256)> {};
+template <class T> constexpr bool kSharedArg = SharedKernelArg<T>::value;
+#define RBR_SHARED_KERNEL_ARG(T) \
+    template <> struct SharedKernelArg<T> : std::true_type {}
 struct NoArg {};
 // problem 1's arguments: the shared ones left out
 template <class... A> struct Pack1;
@@ -72,6 +80,30 @@ template <auto Fn, class H, class... T, class... Done>
 __device__ __forceinline__ void call_pack(const Pack<H, T...>& p, const Done&... d) {
     call_pack<Fn>(p.t, d..., p.h);
 }
+// problem 1 / problem 0 by a (uniform) flag: ONE copy of the body, every non-shared argument selected between the two
+// kernarg packs (scalars and pointers, by value).  One body keeps the register allocation of the single launch: with a body
+// per argument set the allocator needed 2-4 more VGPRs, enough to cost gather_pool (64 -> 66) a wave per SIMD.
+template <auto Fn, class... Done> __device__ __forceinline__ void call_sel(bool, const Pack<>&, const Pack1<>&, const Done&... d) { Fn(d...); }
+template <auto Fn, class H, class... T, class... Done>
+__device__ __forceinline__ void call_sel(bool second, const Pack<H, T...>& p0, const Pack1<H, T...>& p1, const Done&... d) {
+    if constexpr (kSharedArg<H>) {
+        call_sel<Fn>(second, p0.t, p1.t, d..., p0.h);
+    } else {
+        static_assert(!std::is_class_v<H>, "struct arguments that differ between the problems take the branch form");
+        const H h = second ? p1.h : p0.h;
+        call_sel<Fn>(second, p0.t, p1.t, d..., h);
+    }
+}
+
+// The two __global__ wrappers.  The function pointer is a typed template argument (F, Fn) rather than `auto`: profilers then
+// demangle the kernel names (rbr::pair_k<void (*)(...), &rbr::gather_pool_kernel<false>, 256, 1, ...>).
+template <class F, F Fn, int BOUNDS, int MINB, class... A> __global__ __launch_bounds__(BOUNDS, MINB) void single_k(const Pack<A...> p) {
+    call_pack<Fn>(p);
+}
+// A struct argument that differs between the problems (PtrArray: per-tower weight pointers, indexed dynamically) cannot be
+// selected by address -- the compiler would copy the kernarg packs to scratch memory -- so kernels that take one get a copy of
+// the body per argument set behind a branch on the (uniform) blockIdx.z instead; they are short, un-pressured kernels
+// (pool_finalize, dw_reduce, compact_pack, the GEMM whose occupancy LDS decides).
 template <auto Fn, class... Done> __device__ __forceinline__ void call_pack1(const Pack<>&, const Pack1<>&, const Done&... d) { Fn(d...); }
 template <auto Fn, class H, class... T, class... Done>
 __device__ __forceinline__ void call_pack1(const Pack<H, T...>& p0, const Pack1<H, T...>& p1, const Done&... d) {
@@ -80,19 +112,17 @@ __device__ __forceinline__ void call_pack1(const Pack<H, T...>& p0, const Pack1<
     else
         call_pack1<Fn>(p0.t, p1.t, d..., p1.h);
 }
-
-// The two __global__ wrappers.  Two copies of the body in pair_k (one per argument set) rather than one body behind a pointer
-// select: selecting &p0 / &p1 makes the compiler copy the chosen argument struct to scratch memory; a branch on the (uniform)
-// blockIdx.z keeps every argument a scalar load from the kernarg segment, as in the single launch.
-template <auto Fn, int BOUNDS, int MINB, class... A> __global__ __launch_bounds__(BOUNDS, MINB) void single_k(const Pack<A...> p) {
-    call_pack<Fn>(p);
-}
-template <auto Fn, int BOUNDS, int MINB, class... A>
+template <class... A> constexpr bool kPairByBranch = ((!kSharedArg<A> && std::is_class_v<A>) || ...);
+template <class F, F Fn, int BOUNDS, int MINB, class... A>
 __global__ __launch_bounds__(BOUNDS, MINB) void pair_k(const Pack<A...> p0, const Pack1<A...> p1) {
-    if (blockIdx.z == 0)
-        call_pack<Fn>(p0);
-    else
-        call_pack1<Fn>(p0, p1);
+    if constexpr (kPairByBranch<A...>) {
+        if (blockIdx.z == 0)
+            call_pack<Fn>(p0);
+        else
+            call_pack1<Fn>(p0, p1);
+    } else {
+        call_sel<Fn>(blockIdx.z != 0, p0, p1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- the pair region (per thread)
@@ -105,16 +135,29 @@ struct PairRec {
     size_t lds;
     hipStream_t st;
     const char* what;
+    int solo;                        // recorded inside a PairSolo scope: never shares a launch (see PairSolo)
     alignas(16) unsigned char args[kPairArgBytes];
 };
 constexpr int kPairNoMatch = -1000;
 struct PairState {
     int mode = 0;                    // 0: launches run at once; 1 / 2: recording problem 0 / 1
+    int solo = 0;                    // depth of PairSolo scopes
     std::vector<PairRec> rec[2];
     int paired = 0, singles = 0;     // what the last rbr_pair_end launched
 };
 PairState& pair_state();             // thread-local (rbr_plan.hip)
 inline bool pair_region_open() { return pair_state().mode != 0; }
+// Launches recorded while a PairSolo lives do not pair: a run of consecutive solo records leaves problem by problem (all of
+// problem 0's, then all of problem 1's).  For producer -> consumer chains over a working set of Infinity-Cache size: the
+// distinct-token GEMM writes the product table T (176 MB per D-ATT tower at cfg4) that the gather reads next, build_g writes the
+// G that the sparse product reads -- run tower by tower the consumer finds its input in the 256 MB cache, paired it finds the
+// OTHER tower's (measured, cfg4: gather 2 x 153 us tower by tower, 366 us as a pair; g_times_w 2 x 87 against 206).
+struct PairSolo {
+    PairSolo() { ++pair_state().solo; }
+    ~PairSolo() { --pair_state().solo; }
+    PairSolo(const PairSolo&) = delete;
+    PairSolo& operator=(const PairSolo&) = delete;
+};
 
 template <class K> inline int raise_lds_limit(K kernel, size_t lds) {
     // above the default 64 KB of dynamic LDS a kernel needs its limit raised once (per process; the attribute is the
@@ -133,11 +176,11 @@ template <auto Fn, int BOUNDS, int MINB, class... A> struct KernelOf {
         if (lds > 64 * 1024) {
             static bool raised = false;
             if (!raised) {
-                if (int e = raise_lds_limit(single_k<Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
+                if (int e = raise_lds_limit(single_k<decltype(Fn), Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
                 raised = true;
             }
         }
-        hipLaunchKernelGGL((single_k<Fn, BOUNDS, MINB, A...>), g, b, lds, st, p);
+        hipLaunchKernelGGL((single_k<decltype(Fn), Fn, BOUNDS, MINB, A...>), g, b, lds, st, p);
         return check_hip(hipGetLastError(), what);
     }
     static int single_fn(const PairRec& r) {
@@ -159,13 +202,13 @@ template <auto Fn, int BOUNDS, int MINB, class... A> struct KernelOf {
         if (a.lds > 64 * 1024) {
             static bool raised = false;
             if (!raised) {
-                if (int e = raise_lds_limit(pair_k<Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
+                if (int e = raise_lds_limit(pair_k<decltype(Fn), Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
                 raised = true;
             }
         }
         dim3 g = a.grid;
         g.z = 2;
-        hipLaunchKernelGGL((pair_k<Fn, BOUNDS, MINB, A...>), g, a.block, a.lds, a.st, p0, p1);
+        hipLaunchKernelGGL((pair_k<decltype(Fn), Fn, BOUNDS, MINB, A...>), g, a.block, a.lds, a.st, p0, p1);
         return check_hip(hipGetLastError(), a.what);
     }
     static int go(dim3 g, dim3 b, size_t lds, hipStream_t st, const char* what, A... a) {
@@ -175,7 +218,7 @@ template <auto Fn, int BOUNDS, int MINB, class... A> struct KernelOf {
         PairRec r;
         r.pair = &pair_fn;
         r.single = &single_fn;
-        r.grid = g; r.block = b; r.lds = lds; r.st = st; r.what = what;
+        r.grid = g; r.block = b; r.lds = lds; r.st = st; r.what = what; r.solo = S.solo > 0;
         memcpy(r.args, &p, sizeof(P0));
         S.rec[S.mode - 1].push_back(r);
         return 0;

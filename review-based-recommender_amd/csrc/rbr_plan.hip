@@ -172,9 +172,18 @@ extern "C" int rbr_pair_end(int32_t* n_paired, int32_t* n_single) {
     size_t i = 0;
     // zip while the two lists name the same kernels; a pair that does not form (grids, shared arguments) goes out as two
     // launches and the zip carries on -- the lists still line up.  Each problem's launches keep their order either way.
-    for (; i < nz && rc == 0; ++i) {
+    while (i < nz && rc == 0) {
         const rbr::PairRec &a = S.rec[0][i], &b = S.rec[1][i];
-        if (a.pair != b.pair) break;
+        if (a.pair != b.pair || a.solo != b.solo) break;
+        if (a.solo) {
+            // a run of solo records: problem 0's launches of the run, then problem 1's (PairSolo)
+            size_t j = i;
+            while (j < nz && S.rec[0][j].solo && S.rec[1][j].solo && S.rec[0][j].pair == S.rec[1][j].pair) ++j;
+            for (int t = 0; t < 2 && rc == 0; ++t)
+                for (size_t k = i; k < j && rc == 0; ++k, ++S.singles) rc = S.rec[t][k].single(S.rec[t][k]);
+            i = j;
+            continue;
+        }
         rc = a.pair(a, b);
         if (rc == rbr::kPairNoMatch) {
             rc = a.single(a);
@@ -183,6 +192,7 @@ extern "C" int rbr_pair_end(int32_t* n_paired, int32_t* n_single) {
         } else if (rc == 0) {
             S.paired += 1;
         }
+        ++i;
     }
     for (size_t k = i; k < n0 && rc == 0; ++k, ++S.singles) rc = S.rec[0][k].single(S.rec[0][k]);
     for (size_t k = i; k < n1 && rc == 0; ++k, ++S.singles) rc = S.rec[1][k].single(S.rec[1][k]);

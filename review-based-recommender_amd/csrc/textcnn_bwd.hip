@@ -41,6 +41,7 @@ struct BwdArgs {
     int doc_centric;                // 1: dw_doc_kernel (short documents), 0: dw_partial_kernel
     int dev_flags;                  // tuning aid (RBR_DEV_DX_ABLATE): 1 = no atomics, 2 = no accumulation phase
 };
+RBR_SHARED_KERNEL_ARG(BwdArgs);
 
 __device__ __forceinline__ int bank_of(const BwdArgs& A, int c) {
     int w = 0;

@@ -38,6 +38,7 @@ struct ProdArgs {
     int rank_off[RBR_MAX_WIDTHS];   // first slot of bank w in the pooling workspace (banks ordered by kernel width, stable)
     int cp_real;                    // product channels before padding to whole launch groups
 };
+RBR_SHARED_KERNEL_ARG(ProdArgs);
 
 // ---------------------------------------------------------------------------------- distinct tokens
 // Launch 2 of the forward chain: blocks [0, nb_scan) build the work list of the REAL documents (which 32-token slabs
@@ -299,6 +300,7 @@ struct ProdBwdArgs {
     int n_widths;
     int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
 };
+RBR_SHARED_KERNEL_ARG(ProdBwdArgs);
 
 // ... and the gate gradient build_g accumulates into (n_dgate floats, 0 for un-gated convs): one launch for both
 __device__ __forceinline__ void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
@@ -1212,6 +1214,7 @@ extern "C" int rbr_textcnn_token_list(const rbr_textcnn_desc* d, void* fwd_ws, c
 static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans, const int64_t* ids, const uint8_t* mask, const float* gate,
                                const float* feat, const int32_t* argmax, const float* d_feat, void* fwd_ws, void* bwd_ws,
                                float* dtable, float* dgate, hipStream_t st, int phases, float* sq_part) {
+    PairSolo solo;        // zero G -> build G -> G @ Wprod^T: a producer / consumer chain over G (rbr_launch.h)
     ProdLayout Lo;
     ProdBwdLayout B;
     if (!prod_layout(d, Lo) || !prod_bwd_layout(d, Lo, B)) return RBR_ERR_BAD_ARG;
@@ -1434,6 +1437,7 @@ extern "C" int rbr_textcnn_bwd_dtable_list(const rbr_textcnn_desc* d, const int6
 // Stage 2 (one kernel): T = table[tok_of_row] @ Wprod on the f32 MFMA pipe.
 extern "C" int rbr_textcnn_prod_table(const rbr_textcnn_desc* d, const float* table, void* ws, void* stream) {
     if (!table) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    PairSolo solo;        // the GEMM writes the product table the gather (rbr_textcnn_prod_pool) reads next: tower by tower
     ProdState S;
     if (int e = prod_state(d, ws, S)) return e;
     if (prod_b16_applicable(d))
@@ -1450,6 +1454,7 @@ extern "C" int rbr_textcnn_prod_pool(const rbr_textcnn_desc* d, const int64_t* i
     const int ngroups = build_plans(d, plans);
     if (!ngroups) return RBR_ERR_BAD_ARG;
     if (!ids || !pval || !pidx) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    PairSolo solo;        // see rbr_textcnn_prod_table
     ProdState S;
     if (int e = prod_state(d, ws, S)) return e;
     hipStream_t st = (hipStream_t)stream;

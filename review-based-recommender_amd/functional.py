@@ -788,6 +788,15 @@ def _ticket(dev) -> torch.Tensor:
     return t
 
 
+def prepare_stream_state(dev) -> None:
+    """Creates the per-(device, stream) state of the CURRENT stream -- the arrival counter of the fused head's MSE reduction --
+    so that its first use does not allocate and zero-fill it.  train_step.GraphedTrainStep /
+    GraphedForward call it on their capture stream before recording: a counter buffer created during a capture would live in
+    that graph's private memory pool and cost every replay a fill node."""
+    dev = torch.device(dev)
+    _ticket(dev)
+
+
 def encode_head_applicable(table, n_docs, L, kernel_sizes, channels, padding_idx) -> bool:
     """True when the fused encoder + head function serves this conv: the token-product formulation applies and one
     pool-epilogue launch covers every channel slot."""
@@ -1286,8 +1295,11 @@ class _Linear(torch.autograd.Function):
         b = b.contiguous() if b is not None else None
         drop = drop.contiguous() if drop is not None else None
         y = torch.empty(N, OUT, dtype=F32, device=x.device)
-        check(L_.rbr_linear_fwd(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(b, F32, "b"), int(relu),
-                                dev_ptr(drop, F32, "drop"), dev_ptr(y, F32, "y"), current_stream()), "rbr_linear_fwd")
+        wsn = L_.rbr_linear_fwd_ws_floats(N, IN, OUT)          # > 0: the product is split along K (few output tiles)
+        ws = torch.empty(wsn, dtype=F32, device=x.device) if wsn else None
+        check(L_.rbr_linear_fwd_ex(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(b, F32, "b"), int(relu),
+                                   dev_ptr(drop, F32, "drop"), dev_ptr(y, F32, "y"), dev_ptr(ws, F32, "ws"),
+                                   current_stream()), "rbr_linear_fwd_ex")
         ctx.relu = int(relu)
         ctx.has_b = b is not None
         ctx.has_drop = drop is not None
@@ -1306,11 +1318,11 @@ class _Linear(torch.autograd.Function):
         d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W)
         db = torch.empty(OUT, dtype=F32, device=dev) if ctx.has_b else None
-        ws = torch.empty(L_.rbr_linear_bwd_ws_floats(N, OUT), dtype=F32, device=dev)
-        check(L_.rbr_linear_bwd(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(y, F32, "y"),
-                                dev_ptr(d_y, F32, "d_y"), ctx.relu, dev_ptr(drop, F32, "drop"), dev_ptr(d_x, F32, "d_x"),
-                                dev_ptr(dW, F32, "dW"), dev_ptr(db, F32, "db"), dev_ptr(ws, F32, "ws"), current_stream()),
-              "rbr_linear_bwd")
+        ws = torch.empty(L_.rbr_linear_bwd_ex_ws_floats(N, IN, OUT), dtype=F32, device=dev)
+        check(L_.rbr_linear_bwd_ex(N, IN, OUT, dev_ptr(x, F32, "x"), dev_ptr(W, F32, "W"), dev_ptr(y, F32, "y"),
+                                   dev_ptr(d_y, F32, "d_y"), ctx.relu, dev_ptr(drop, F32, "drop"), dev_ptr(d_x, F32, "d_x"),
+                                   dev_ptr(dW, F32, "dW"), dev_ptr(db, F32, "db"), dev_ptr(ws, F32, "ws"),
+                                   current_stream()), "rbr_linear_bwd_ex")
         return d_x, dW, db, None, None
 
 
@@ -1641,6 +1653,35 @@ def _pair_region():
 PAIR_STATS = {"paired": 0, "singles": 0}      # launches of the last paired D-ATT forward + backward that left as pairs / singly
 
 
+class _NoRegion:
+    """Stands in for a pair region in bench.py's kernel-timing pass (TIMER.enabled): the same calls, launched where they are made,
+    so that HIP events can bracket them -- the long kernels of the step (GEMM, gather, the G chain) leave singly in a region too
+    (PairSolo), so what the events see is what a region launches."""
+    paired = singles = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    @staticmethod
+    def next():
+        pass
+
+
+def _region_or_timed():
+    return _NoRegion() if TIMER.enabled else _pair_region()
+
+
+def _timed_call(name, rc_fn):
+    """check(rc_fn()) bracketed by TIMER events when the timing pass is on."""
+    ev = TIMER.record(name)
+    check(rc_fn(), name)
+    if ev is not None:
+        ev.record()
+
+
 def datt_pair_applies(table, docs2, local_w, conv_ws) -> bool:
     """True when both D-ATT towers can go through datt_towers(): equal shapes by construction (one [2B, L] id block), the
     token-product forms of the local gate and of the merged four-bank conv apply, the distinct-token rows pay, and the GEMM is
@@ -1722,7 +1763,7 @@ class _DattTowers(torch.autograd.Function):
             tw.prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             tw.feat, tw.argmax = feats[t * B:(t + 1) * B], argmax[t * B:(t + 1) * B]
         ev = TIMER.record("datt_towers_fwd")
-        with _pair_region() as region:
+        with _region_or_timed() as region:
             for t, tw in enumerate(towers):
                 if t == 1:
                     region.next()
@@ -1737,9 +1778,10 @@ class _DattTowers(torch.autograd.Function):
                 wsp = tw.prod_ws.data_ptr()
                 check(L_.rbr_textcnn_prod_prepare(C.byref(desc), ids_p, None, ptr_array(tw.ws, F32, "conv weight"),
                                                   dev_ptr(tw.pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_prepare")
-                check(L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st), "rbr_textcnn_prod_table")
-                check(L_.rbr_textcnn_prod_pool(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), dev_ptr(tw.pval, F32, "pval"),
-                                               dev_ptr(tw.pidx, I32, "pidx"), wsp, st), "rbr_textcnn_prod_pool")
+                _timed_call("textcnn_prod_table", lambda: L_.rbr_textcnn_prod_table(C.byref(desc), dev_ptr(table_c, F32, "word table"), wsp, st))
+                _timed_call("textcnn_prod_pool", lambda: L_.rbr_textcnn_prod_pool(
+                    C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), dev_ptr(tw.pval, F32, "pval"),
+                    dev_ptr(tw.pidx, I32, "pidx"), wsp, st))
                 check(L_.rbr_textcnn_pool_finalize(C.byref(desc), dev_ptr(tw.pval, F32, "pval"), dev_ptr(tw.pidx, I32, "pidx"),
                                                    ptr_array(tw.bs, F32, "conv bias"), dev_ptr(tw.feat, F32, "feat"),
                                                    dev_ptr(tw.argmax, I32, "argmax"), st), "rbr_textcnn_pool_finalize")
@@ -1789,7 +1831,7 @@ class _DattTowers(torch.autograd.Function):
             side.wait_event(fork)
         st_dw = side.cuda_stream if side is not None else st
         ev = TIMER.record("datt_towers_bwd")
-        with _pair_region() as region:
+        with _region_or_timed() as region:
             for t, tw in enumerate(towers):
                 if t == 1:
                     region.next()
@@ -1797,13 +1839,28 @@ class _DattTowers(torch.autograd.Function):
                 d_feat = d_feats[t * B:(t + 1) * B]
                 dt = dev_ptr(dtab[t], F32, "dtable") if need_table else None
                 tab = dev_ptr(table, F32, "table")
+                # first in the list: the weight-gradient pair goes to the second stream before the long chain below is
+                # enqueued (recorded last it started ~400 us late in the replayed graph, under the global gate's kernels)
+                check(L_.rbr_textcnn_bwd_dw(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), tab,
+                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                            dev_ptr(d_feat, F32, "d_feat"), ptr_array(tw.grads[4:8], F32, "dW"),
+                                            ptr_array(tw.grads[8:12], F32, "dbias"), dev_ptr(tw.wsb, F32, "ws"), st_dw), "rbr_textcnn_bwd_dw")
                 # G, d(gate) and -- when wanted -- this tower's conv share of the table gradient
-                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
-                                                        dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
-                                                        dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt,
-                                                        dev_ptr(tw.dgate2, F32, "dgate"), None,
-                                                        _lib.G_BUILD | ((_lib.G_PRODUCT | _lib.G_ACCUMULATE) if need_table else 0), st),
-                      "rbr_textcnn_bwd_dtable_prod")
+                if TIMER.enabled and need_table:      # the two phases as two calls: the sparse product (one launch) gets events of its own
+                    check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
+                                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                                            dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), None,
+                                                            dev_ptr(tw.dgate2, F32, "dgate"), None, _lib.G_BUILD, st), "rbr_textcnn_bwd_g_build")
+                    _timed_call("textcnn_bwd_g_product", lambda: L_.rbr_textcnn_bwd_dtable_prod_ex(
+                        C.byref(desc), None, None, None, None, None, None, tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt, None, None,
+                        _lib.G_PRODUCT | _lib.G_ACCUMULATE, st))
+                else:
+                    check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
+                                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                                            dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt,
+                                                            dev_ptr(tw.dgate2, F32, "dgate"), None,
+                                                            _lib.G_BUILD | ((_lib.G_PRODUCT | _lib.G_ACCUMULATE) if need_table else 0), st),
+                          "rbr_textcnn_bwd_dtable_prod")
                 check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, V, ids_p, tab, dev_ptr(tw.lw, F32, "w"),
                                                       dev_ptr(tw.gate2[0], F32, "gate"), dev_ptr(tw.dgate2[0], F32, "dgate"), pad,
                                                       dev_ptr(tw.grads[0], F32, "dw"), dev_ptr(tw.grads[1], F32, "db0"), dt,
@@ -1813,10 +1870,6 @@ class _DattTowers(torch.autograd.Function):
                                                        dev_ptr(tw.grads[2], F32, "dw"), dev_ptr(tw.grads[3], F32, "db0"), dt,
                                                        dev_ptr(tw.gg_ws, F32, "ws"), tw.rows.data_ptr(), 1, st),
                       "rbr_datt_global_gate_bwd_rows")
-                check(L_.rbr_textcnn_bwd_dw(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), tab,
-                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
-                                            dev_ptr(d_feat, F32, "d_feat"), ptr_array(tw.grads[4:8], F32, "dW"),
-                                            ptr_array(tw.grads[8:12], F32, "dbias"), dev_ptr(tw.wsb, F32, "ws"), st_dw), "rbr_textcnn_bwd_dw")
         if side is not None:
             with torch.cuda.stream(side):
                 join = torch.cuda.Event()

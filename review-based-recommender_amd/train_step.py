@@ -314,6 +314,15 @@ def _flat_views(flat: torch.Tensor, layout, like):
     return [flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(layout, like)]
 
 
+def _capture_stream(dev) -> torch.cuda.Stream:
+    """A stream to record a graph on, with the library's per-stream state (functional.prepare_stream_state) already in place."""
+    cs = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(cs):
+        RF.prepare_stream_state(dev)
+    torch.cuda.synchronize(dev)
+    return cs
+
+
 class GraphedForward:
     """model(*batch) under torch.no_grad(), recorded once into a hipGraph and replayed: the eval / serving forward of a
     fixed batch shape (the trainers' validation loops, trainer/train_deepconn_pp.py:171-196: ~25 short kernels whose eager
@@ -340,7 +349,8 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+        self._capture_stream = _capture_stream(batch[0].device)
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode=capture_error_mode):
             out = model(*self.batch)
         self.pred = out[0] if isinstance(out, tuple) else out
 
@@ -449,15 +459,17 @@ class GraphedTrainStep:
         # with a process group alive, RCCL's watchdog thread polls events while we record: only this thread's calls
         # may be policed by the capture ("thread_local"), as torch recommends for captures next to NCCL work
         mode = capture_error_mode or ("thread_local" if grad_sync is not None else "global")
+        self._capture_stream = _capture_stream(ratings.device)
+        cs = self._capture_stream
         for sl in self._slots:
             optimizer.zero_grad(set_to_none=True)
             sl.g_fwd_bwd = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
             if grad_sync is None:
-                with torch.cuda.graph(sl.g_fwd_bwd, capture_error_mode=mode):
+                with torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
                     sl.loss, sl.gnorm, sl.pred = train_step(model, optimizer, sl.batch, sl.ratings, max_grad_norm)
                 sl.static_grads = [(p, p.grad) for p in model.parameters()]
             else:
-                with torch.cuda.graph(sl.g_fwd_bwd, capture_error_mode=mode):
+                with torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
                     optimizer.zero_grad()
                     pred, loss = _forward_loss_backward(model, sl.batch, sl.ratings)
                     sl.loss, sl.pred = loss.detach(), pred.detach()
@@ -466,7 +478,7 @@ class GraphedTrainStep:
                 grad_sync(model)
                 sl.static_grads = [(p, p.grad) for p in model.parameters()]
                 sl.g_update = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
-                with torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), capture_error_mode=mode):
+                with torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), stream=cs, capture_error_mode=mode):
                     sl.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
             for p, v in zip(model.parameters(), saved_params):

@@ -63,8 +63,10 @@ def test_paired_towers_equal_the_two_single_tower_passes(cfgname):
     RF.PAIR_STATS["paired"] = RF.PAIR_STATS["singles"] = 0
     with _paired(True):
         pred_p, grads_p = _step(model, args, ratings)
-    assert RF.PAIR_STATS["paired"] >= 30, f"the towers' launches did not pair up: {RF.PAIR_STATS}"
-    assert RF.PAIR_STATS["singles"] == 0, f"some launches of the towers left singly: {RF.PAIR_STATS}"
+    # 9 launches per tower stay single on purpose (PairSolo: GEMM + gather, the G chain, the occurrence-matrix chain -- chains
+    # over working sets of Infinity-Cache size run tower by tower); everything else must leave as pairs
+    assert RF.PAIR_STATS["paired"] >= 20, f"the towers' launches did not pair up: {RF.PAIR_STATS}"
+    assert RF.PAIR_STATS["singles"] <= 18, f"more launches than the solo chains left singly: {RF.PAIR_STATS}"
     # forward: the same kernels on the same inputs -> the same bits
     assert torch.equal(pred_p, pred_s)
     for k in grads_s:

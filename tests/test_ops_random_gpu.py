@@ -169,6 +169,38 @@ def test_linear_and_head_random(case):
     _cmp_grads(gl, cl)
 
 
+@pytest.mark.parametrize("N,IN,OUT,act", [(1024, 500, 500, "relu"), (1024, 500, 50, "none"), (300, 1000, 70, "tanh"), (64, 129, 33, "relu"), (64, 50, 33, "relu")])
+def test_linear_split_along_k_matches_torch_and_is_reproducible(N, IN, OUT, act):
+    """rbr_linear_fwd_ex / _bwd_ex (D-ATT's shared fc, dual_att.py:31-35, at its cfg4 shapes and two odd ones): products with few
+    output tiles are split along K, the last slice of a tile adds the partial tiles in slice order.  Against torch in float64;
+    two runs give the same bits (the partial tiles are added in slice order)."""
+    from review_based_recommender_amd import _lib, functional as RF
+    g = torch.Generator().manual_seed(N + OUT)
+    x, W, b = torch.randn(N, IN, generator=g), torch.randn(OUT, IN, generator=g) / np.sqrt(IN), torch.randn(OUT, generator=g) * 0.1
+    drop = (torch.rand(N, OUT, generator=g) > 0.5).float() * 2
+    d = torch.randn(N, OUT, generator=g)
+    cl = [_leaf(t.double()) for t in (x, W, b)]
+    z = F.linear(*cl)
+    z = F.relu(z) if act == "relu" else torch.tanh(z) if act == "tanh" else z
+    ((z * drop.double()) * d.double()).sum().backward()
+    L_ = _lib.lib()
+    split = L_.rbr_linear_fwd_ws_floats(N, IN, OUT) > 0
+    assert split == (IN >= 128), "K of at least four 32-deep chunks is split (every shape here has few output tiles), a shorter K not"
+    outs = []
+    for _ in range(2):
+        gl = [_leaf(t.to(DEV)) for t in (x, W, b)]
+        out = RF.linear(gl[0], gl[1], gl[2], relu=(act == "relu"), tanh=(act == "tanh"), drop=drop.to(DEV))
+        (out * d.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append([out.detach().clone()] + [t.grad.clone() for t in gl])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    ref = [(z * drop.double()).detach()] + [t.grad for t in cl]
+    for got, r in zip(outs[0], ref):
+        scale = float(r.abs().max()) + 1e-30
+        assert float((got.double().cpu() - r).abs().max()) <= 2e-5 * max(1.0, scale), (tuple(r.shape), scale)
+
+
 @pytest.mark.parametrize("n", [1, 7, 256, 1000, 70001])
 def test_mse_loss_matches_torch(n):
     """rbr_mse_loss_fwd/_bwd vs nn.MSELoss (train_deepconn_pp.py:137,164): loss, d_pred, and a non-unit upstream gradient."""
