@@ -95,6 +95,15 @@ struct B16Pack;
 B16Pack prod_b16_pack_job(const rbr_textcnn_desc* d);     // textcnn_b16.h
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
                   const float* table, const void* bimg, void* T, void* a16, hipStream_t st);
+// The backward's table-gradient rows as a GEMM on the same kernel (textcnn_prod_b16.hip): rows [cap, D] = G [cap, KG] @ Wprod^T, with
+// the per-workgroup sums of squares the row-form optimizer wants; applicable: whether the shape takes it (many short documents: G
+// is dense enough that the sparse product loses), image bytes / work items of its weight planes, partial count, launch
+bool prod_b16_rows_applicable(const rbr_textcnn_desc* d);
+size_t prod_b16_rows_image_bytes(int KG, int D);
+long prod_b16_rows_image_items(int KG, int D);
+int prod_b16_rows_partials(int cap, int D);
+int prod_b16_rows_gemm(int KG, int D, int cap, const int* counter, const float* G, const void* bimg_t, float* rows, float* sq_part,
+                       hipStream_t st);
 // bf16 STORAGE of the plain-bf16 class (textcnn_prod_b16.hip): T holds bf16, and `a16` (prod_b16_rows_bytes) the compact bf16 rows
 bool prod_t_bf16(const rbr_textcnn_desc* d);
 size_t prod_b16_rows_bytes(const rbr_textcnn_desc* d, int cap);

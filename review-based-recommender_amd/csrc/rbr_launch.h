@@ -75,53 +75,59 @@ template <class H, class... T> inline bool shared_equal(const Pack<H, T...>& a, 
 // The members are handed to the body BY REFERENCE into the kernarg segment: a body that takes its struct arguments as
 // `const T&` indexes them where they lie (scalar loads), exactly as a __global__ kernel indexes its by-value parameters; a
 // by-value struct parameter would be copied to scratch memory first whenever the body indexes it dynamically.
-template <auto Fn, class... Done> __device__ __forceinline__ void call_pack(const Pack<>&, const Done&... d) { Fn(d...); }
-template <auto Fn, class H, class... T, class... Done>
+template <class Tag, class... Done> __device__ __forceinline__ void call_pack(const Pack<>&, const Done&... d) { Tag::call(d...); }
+template <class Tag, class H, class... T, class... Done>
 __device__ __forceinline__ void call_pack(const Pack<H, T...>& p, const Done&... d) {
-    call_pack<Fn>(p.t, d..., p.h);
+    call_pack<Tag>(p.t, d..., p.h);
 }
 // problem 1 / problem 0 by a (uniform) flag: ONE copy of the body, every non-shared argument selected between the two
 // kernarg packs (scalars and pointers, by value).  One body keeps the register allocation of the single launch: with a body
 // per argument set the allocator needed 2-4 more VGPRs, enough to cost gather_pool (64 -> 66) a wave per SIMD.
-template <auto Fn, class... Done> __device__ __forceinline__ void call_sel(bool, const Pack<>&, const Pack1<>&, const Done&... d) { Fn(d...); }
-template <auto Fn, class H, class... T, class... Done>
+template <class Tag, class... Done> __device__ __forceinline__ void call_sel(bool, const Pack<>&, const Pack1<>&, const Done&... d) { Tag::call(d...); }
+template <class Tag, class H, class... T, class... Done>
 __device__ __forceinline__ void call_sel(bool second, const Pack<H, T...>& p0, const Pack1<H, T...>& p1, const Done&... d) {
     if constexpr (kSharedArg<H>) {
-        call_sel<Fn>(second, p0.t, p1.t, d..., p0.h);
+        call_sel<Tag>(second, p0.t, p1.t, d..., p0.h);
     } else {
         static_assert(!std::is_class_v<H>, "struct arguments that differ between the problems take the branch form");
         const H h = second ? p1.h : p0.h;
-        call_sel<Fn>(second, p0.t, p1.t, d..., h);
+        call_sel<Tag>(second, p0.t, p1.t, d..., h);
     }
 }
 
-// The two __global__ wrappers.  The function pointer is a typed template argument (F, Fn) rather than `auto`: profilers then
-// demangle the kernel names (rbr::pair_k<void (*)(...), &rbr::gather_pool_kernel<false>, 256, 1, ...>).
-template <class F, F Fn, int BOUNDS, int MINB, class... A> __global__ __launch_bounds__(BOUNDS, MINB) void single_k(const Pack<A...> p) {
-    call_pack<Fn>(p);
+// The kernel body travels into the __global__ wrappers as a TYPE (KTag<decltype(&body), &body>), not as a non-type template
+// argument of the wrapper itself: a function template with a dependent-typed non-type parameter is mangled with the newer
+// "Tn" production, which the demanglers of rocprofv3 and binutils do not know -- the profiles showed raw _ZN3rbr6pair_kI... names.
+// As a class template argument the same pointer mangles the classic way:
+//     rbr::pair_k<rbr::KTag<void (*)(rbr::ConvPlan const&, ...), &rbr::gather_pool_kernel<false>>, 256, 1, ...>
+template <class F, F Fn> struct KTag {
+    template <class... A> static __device__ __forceinline__ void call(const A&... a) { Fn(a...); }
+};
+template <class Tag, int BOUNDS, int MINB, class... A> __global__ __launch_bounds__(BOUNDS, MINB) void single_k(const Pack<A...> p) {
+    call_pack<Tag>(p);
 }
 // A struct argument that differs between the problems (PtrArray: per-tower weight pointers, indexed dynamically) cannot be
 // selected by address -- the compiler would copy the kernarg packs to scratch memory -- so kernels that take one get a copy of
 // the body per argument set behind a branch on the (uniform) blockIdx.z instead; they are short, un-pressured kernels
 // (pool_finalize, dw_reduce, compact_pack, the GEMM whose occupancy LDS decides).
-template <auto Fn, class... Done> __device__ __forceinline__ void call_pack1(const Pack<>&, const Pack1<>&, const Done&... d) { Fn(d...); }
-template <auto Fn, class H, class... T, class... Done>
+template <class Tag, class... Done> __device__ __forceinline__ void call_pack1(const Pack<>&, const Pack1<>&, const Done&... d) { Tag::call(d...); }
+template <class Tag, class H, class... T, class... Done>
 __device__ __forceinline__ void call_pack1(const Pack<H, T...>& p0, const Pack1<H, T...>& p1, const Done&... d) {
     if constexpr (kSharedArg<H>)
-        call_pack1<Fn>(p0.t, p1.t, d..., p0.h);
+        call_pack1<Tag>(p0.t, p1.t, d..., p0.h);
     else
-        call_pack1<Fn>(p0.t, p1.t, d..., p1.h);
+        call_pack1<Tag>(p0.t, p1.t, d..., p1.h);
 }
 template <class... A> constexpr bool kPairByBranch = ((!kSharedArg<A> && std::is_class_v<A>) || ...);
-template <class F, F Fn, int BOUNDS, int MINB, class... A>
+template <class Tag, int BOUNDS, int MINB, class... A>
 __global__ __launch_bounds__(BOUNDS, MINB) void pair_k(const Pack<A...> p0, const Pack1<A...> p1) {
     if constexpr (kPairByBranch<A...>) {
         if (blockIdx.z == 0)
-            call_pack<Fn>(p0);
+            call_pack<Tag>(p0);
         else
-            call_pack1<Fn>(p0, p1);
+            call_pack1<Tag>(p0, p1);
     } else {
-        call_sel<Fn>(blockIdx.z != 0, p0, p1);
+        call_sel<Tag>(blockIdx.z != 0, p0, p1);
     }
 }
 
@@ -176,11 +182,11 @@ template <auto Fn, int BOUNDS, int MINB, class... A> struct KernelOf {
         if (lds > 64 * 1024) {
             static bool raised = false;
             if (!raised) {
-                if (int e = raise_lds_limit(single_k<decltype(Fn), Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
+                if (int e = raise_lds_limit(single_k<KTag<decltype(Fn), Fn>, BOUNDS, MINB, A...>, 160 * 1024)) return e;
                 raised = true;
             }
         }
-        hipLaunchKernelGGL((single_k<decltype(Fn), Fn, BOUNDS, MINB, A...>), g, b, lds, st, p);
+        hipLaunchKernelGGL((single_k<KTag<decltype(Fn), Fn>, BOUNDS, MINB, A...>), g, b, lds, st, p);
         return check_hip(hipGetLastError(), what);
     }
     static int single_fn(const PairRec& r) {
@@ -202,13 +208,13 @@ template <auto Fn, int BOUNDS, int MINB, class... A> struct KernelOf {
         if (a.lds > 64 * 1024) {
             static bool raised = false;
             if (!raised) {
-                if (int e = raise_lds_limit(pair_k<decltype(Fn), Fn, BOUNDS, MINB, A...>, 160 * 1024)) return e;
+                if (int e = raise_lds_limit(pair_k<KTag<decltype(Fn), Fn>, BOUNDS, MINB, A...>, 160 * 1024)) return e;
                 raised = true;
             }
         }
         dim3 g = a.grid;
         g.z = 2;
-        hipLaunchKernelGGL((pair_k<decltype(Fn), Fn, BOUNDS, MINB, A...>), g, a.block, a.lds, a.st, p0, p1);
+        hipLaunchKernelGGL((pair_k<KTag<decltype(Fn), Fn>, BOUNDS, MINB, A...>), g, a.block, a.lds, a.st, p0, p1);
         return check_hip(hipGetLastError(), a.what);
     }
     static int go(dim3 g, dim3 b, size_t lds, hipStream_t st, const char* what, A... a) {

@@ -96,5 +96,36 @@ __device__ __forceinline__ void b16_pack_item(const B16Pack& J, const PtrArray& 
     }
 }
 
+// The backward's row GEMM (textcnn_prod_b16.hip: prod_b16_rows_gemm) multiplies G [rows, KG] by Wprod^T [KG, D]: its weight image
+// holds the planes of WT (the row-major Wprod^T the forward's pack launch left in the workspace) in the same fragment order --
+// element (lane l, j) of fragment (group, step, tile, plane) is plane(WT[k = step*16 + 8*(l >> 5) + j][column = group*128 + tile*32
+// + (l & 31)]), zero outside [cp_real) x [D).  One work item = one lane's 16 bytes of the three planes.
+__device__ __forceinline__ void b16_pack_wt_item(const float* __restrict__ WT, int cp_real, int D, int nchunks,
+                                                 unsigned char* __restrict__ bimg, long idx) {
+    long r = idx;
+    const int l = (int)(r & 63); r >>= 6;
+    const int t = (int)(r & 3); r >>= 2;
+    const int c = (int)(r % nchunks);
+    const int ng = (int)(r / nchunks);
+    const int col = ng * kB16BN + t * 32 + (l & 31);
+    const int k0 = c * kB16KC + 8 * (l >> 5);
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + 2 * q + e;
+            x[e] = (k < cp_real && col < D) ? WT[(long)k * D + col] : 0.f;
+        }
+        unsigned a, b, cc;
+        split_pair<3>(x[0], x[1], a, b, cc);
+        ph[q] = a; pm[q] = b; pl[q] = cc;
+    }
+    unsigned char* dst = bimg + (((size_t)ng * nchunks + c) * 4 + t) * 3 * kB16BFrag + l * 16;
+    *reinterpret_cast<u32x4*>(dst) = ph;
+    *reinterpret_cast<u32x4*>(dst + kB16BFrag) = pm;
+    *reinterpret_cast<u32x4*>(dst + 2 * kB16BFrag) = pl;
+}
 
 }  // namespace rbr

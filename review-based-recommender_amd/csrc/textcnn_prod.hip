@@ -303,11 +303,19 @@ struct ProdBwdArgs {
 RBR_SHARED_KERNEL_ARG(ProdBwdArgs);
 
 // ... and the gate gradient build_g accumulates into (n_dgate floats, 0 for un-gated convs): one launch for both
+// ... and (row-GEMM shapes) the bf16 planes of Wprod^T that GEMM reads: blocks past nb_zero, from the WT the forward's pack left
 __device__ __forceinline__ void zero_g_rows_kernel(const int* __restrict__ counter, int cap, int KG4, f32x4* __restrict__ G,
-                                                          float* __restrict__ dgate, long n_dgate) {
+                                                          float* __restrict__ dgate, long n_dgate, int nb_zero, const float* __restrict__ WT,
+                                                          int cp_real, int D, long n_img, unsigned char* __restrict__ bimg_t) {
+    if ((int)blockIdx.x >= nb_zero) {
+        const int nchunks = (4 * KG4 + kB16KC - 1) / kB16KC;
+        for (long k = (long)(blockIdx.x - nb_zero) * 256 + threadIdx.x; k < n_img; k += (long)(gridDim.x - nb_zero) * 256)
+            b16_pack_wt_item(WT, cp_real, D, nchunks, bimg_t, k);
+        return;
+    }
     const long n = (G != nullptr) ? (long)min(*counter, cap) * KG4 : 0;
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)gridDim.x * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_dgate; k += (long)gridDim.x * 256) dgate[k] = 0.f;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long)nb_zero * 256) G[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < n_dgate; k += (long)nb_zero * 256) dgate[k] = 0.f;
 }
 
 // one thread per (doc, channel, tap).  Gated convs (D-ATT: x = gate[doc,p] * table[id]): the token's share is g * gate, and
@@ -934,15 +942,158 @@ __global__ __launch_bounds__(256) void dw_from_g_kernel(int KG, int D, int cap, 
 
 // dbias partials: chunk b of documents -> part_b[b][c] = sum of g over the chunk (fixed order)
 constexpr int kDbChunks = 256;
-__global__ __launch_bounds__(256) void dbias_partial_kernel(int n_docs, int C, int act, const float* __restrict__ feat,
-                                                            const float* __restrict__ d_feat, float* __restrict__ part_b) {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+__device__ __forceinline__ void dbias_partial_block(int n_docs, int C, int act, const float* __restrict__ feat,
+                                                    const float* __restrict__ d_feat, float* __restrict__ part_b, int cb, int b) {
+    const int c = cb * 256 + threadIdx.x;
     if (c >= C) return;
     const int per = (n_docs + kDbChunks - 1) / kDbChunks;
     const int d_begin = b * per, d_end = min(n_docs, d_begin + per);
     float s = 0.f;
     for (int doc = d_begin; doc < d_end; ++doc) s += act_grad(act, feat[(long)doc * C + c], d_feat[(long)doc * C + c]);
     part_b[(long)b * C + c] = s;
+}
+
+// The same contraction on the bf16 pipe with exact three-plane operand splits (textcnn_b16.h: the forward GEMM's arithmetic, f32-class
+// accuracy): 6 v_mfma_f32_32x32x16_bf16 per 16 k (192 cycles) where the kernel above issues 8 v_mfma_f32_32x32x2_f32 (512).  Both
+// operands are K-major in memory (G [row][column], table [row][d]); a thread stages column c of a 32-row tile -- 8 consecutive rows,
+// 8 coalesced loads -- splits its 8 values into planes ONCE and writes each plane's 16 bytes to LDS as [plane][m][32 k] (16-byte
+// chunks XOR-swizzled by m: the fragment reads of 8 lanes cover all banks), so an MFMA operand is one ds_read_b128.  Same grid,
+// same partials as dw_from_g_kernel (RBR_DW_FROM_G_F32=1 selects that one).
+__global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int cap, const int* __restrict__ counter,
+                                                            const float* __restrict__ G, const long long* __restrict__ tok_of_row,
+                                                            const float* __restrict__ table, float* __restrict__ part,
+                                                            int n_docs, int C, int act, const float* __restrict__ feat,
+                                                            const float* __restrict__ d_feat, float* __restrict__ part_b) {
+    if (blockIdx.z >= kDwgSplit) {
+        // the bias gradient's partial sums ride in this launch (one launch less on the chain): the blocks of the z slices past the K
+        // splits take one (channel block, document chunk) pair of dbias_partial_kernel each
+        const int nb = gridDim.x * gridDim.y * (gridDim.z - kDwgSplit);
+        const int b0 = ((blockIdx.z - kDwgSplit) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int ncb = (C + 255) / 256;
+        for (int w = b0; w < ncb * kDbChunks; w += nb) dbias_partial_block(n_docs, C, act, feat, d_feat, part_b, w % ncb, w / ncb);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char As[3][64][64];      // [plane][column][32 k as bf16]
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][64][64];      // [plane][d][32 k as bf16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int col0 = blockIdx.x * 64, d0 = blockIdx.y * 64, z = blockIdx.z;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n = min(*counter, cap);
+    const int rps = (((n + kDwgSplit - 1) / kDwgSplit) + 63) & ~63;      // token rows per split, multiple of 64 (two tiles per round)
+    const int r_begin = z * rps, r_end = min(n, r_begin + rps);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int c = tid & 63, kq = __builtin_amdgcn_readfirstlane(tid >> 6);      // this thread stages rows kq*8 .. kq*8+7 of column c
+    const bool col_ok = col0 + c < KG, d_ok = d0 + c < D;
+    const int cg = min(col0 + c, KG - 1), cd = min(d0 + c, D - 1);         // clamped: every load below is unconditional
+    if (r_begin >= r_end) {                                               // an empty split (fewer rows than splits x 32): zeros
+        const int dcol0 = d0 + wn * 32 + i;
+        if (dcol0 < D) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = col0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (col < KG) part[((long)z * KG + col) * D + dcol0] = 0.f;
+            }
+        }
+        return;
+    }
+    // Two register sets in a ring: set s holds a 32-row tile; it is refilled right after it has been staged, so a tile's loads have
+    // the staging + MFMA phases of TWO tiles to arrive (one phase is ~0.4 us, a gathered table row under load well over 1 us; with
+    // one set the kernel ran 63 us for 29 GFLOP of plane products).  The table-row offsets of a tile are fetched one refill earlier.
+    long off[2][8];
+    float ga[2][8], gb[2][8];
+    // No load is predicated: rows past the split's end are clamped to its last row and their values multiplied by zero AFTER the
+    // load.  A predicated load compiles to a branch around it, and behind a branch the compiler no longer counts the
+    // loads in flight -- it drained them one by one (s_waitcnt vmcnt(0) after each of 16 offset loads per tile).
+    auto load_offs = [&](int s_, int r0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = min(r0 + kq * 8 + q, r_end - 1);              // wave-uniform: a scalar load
+            off[s_][q] = tok_of_row[row] * (long)D;
+        }
+    };
+    auto load_tile = [&](int s_, int r0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = r0 + kq * 8 + q, rc = min(row, r_end - 1);
+            const float va = G[(long)rc * KG + cg], vb = table[off[s_][q] + cd];
+            // x * 1 is exact and x * 0 = 0 for the finite values here: a product, not a select -- a select on the (wave-uniform) row
+            // test is turned back into a branch around the two loads
+            ga[s_][q] = va * ((row < r_end && col_ok) ? 1.f : 0.f);
+            gb[s_][q] = vb * ((row < r_end && d_ok) ? 1.f : 0.f);
+        }
+    };
+    const int wchunk = (kq ^ ((c >> 1) & 3)) * 16;                        // where this thread's 8 k land in its column's row
+    auto stage = [&](const float (&x)[8], unsigned char (&dst)[3][64][64]) {
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a, b, cc;
+            split_pair<3>(x[2 * q], x[2 * q + 1], a, b, cc);
+            ph[q] = a; pm[q] = b; pl[q] = cc;
+        }
+        *reinterpret_cast<u32x4*>(&dst[0][c][wchunk]) = ph;
+        *reinterpret_cast<u32x4*>(&dst[1][c][wchunk]) = pm;
+        *reinterpret_cast<u32x4*>(&dst[2][c][wchunk]) = pl;
+    };
+    const int am = wm * 32 + i, bn = wn * 32 + i;
+    const int aswz = (am >> 1) & 3, bswz = (bn >> 1) & 3;
+    auto mma_tile = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {    // two 16-deep MFMA steps per 32-row tile; lane half h holds k = 8h .. 8h+7 of the step
+            const int ca = ((2 * s2 + h) ^ aswz) * 16, cb = ((2 * s2 + h) ^ bswz) * 16;
+            const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&As[0][am][ca]);
+            const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(&As[1][am][ca]);
+            const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&As[2][am][ca]);
+            const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(&Bs[0][bn][cb]);
+            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(&Bs[1][bn][cb]);
+            const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(&Bs[2][bn][cb]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);      // small terms first, as the forward
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+        }
+    };
+    // (a set may be refilled past the end: clamped rows, zeroed values)
+    load_offs(0, r_begin);
+    load_offs(1, r_begin + 32);
+    load_tile(0, r_begin);
+    load_tile(1, r_begin + 32);
+    for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+        __syncthreads();                    // the previous tile's MFMAs have read LDS
+        stage(ga[0], As);
+        stage(gb[0], Bs);
+        __syncthreads();
+        load_offs(0, r0 + 64);
+        mma_tile();
+        load_tile(0, r0 + 64);              // behind the MFMAs: its offsets were requested before them
+        // the second tile of the round unconditionally (past the end it is all zeros): loads behind a branch are not counted, and
+        // the wait for set 0 at the loop head would drain set 1 as well
+        __syncthreads();
+        stage(ga[1], As);
+        stage(gb[1], Bs);
+        __syncthreads();
+        load_offs(1, r0 + 96);
+        mma_tile();
+        load_tile(1, r0 + 96);
+    }
+    const int dcol = d0 + wn * 32 + i;
+    if (dcol < D) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = col0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (col < KG) part[((long)z * KG + col) * D + dcol] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dbias_partial_kernel(int n_docs, int C, int act, const float* __restrict__ feat,
+                                                            const float* __restrict__ d_feat, float* __restrict__ part_b) {
+    dbias_partial_block(n_docs, C, act, feat, d_feat, part_b, blockIdx.x, blockIdx.y);
 }
 
 // dW_w[cl, d, j] = sum_z part[z][(w,j,cl)][d];  dbias[c] = sum_b part_b[b][c]   (torch layouts, fixed order)
@@ -953,9 +1104,12 @@ __global__ __launch_bounds__(256) void dw_from_g_reduce_kernel(const ProdBwdArgs
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_w + A.C; idx += (long)gridDim.x * 256) {
         if (idx < n_w) {
             const int pc = (int)(idx / A.D), d = (int)(idx - (long)pc * A.D);
+            float v[kDwgSplit];
+#pragma unroll
+            for (int z = 0; z < kDwgSplit; ++z) v[z] = part[((long)z * A.KG + pc) * A.D + d];      // all in flight, added in slice order
             float t = 0.f;
-#pragma unroll 4
-            for (int z = 0; z < kDwgSplit; ++z) t += part[((long)z * A.KG + pc) * A.D + d];
+#pragma unroll
+            for (int z = 0; z < kDwgSplit; ++z) t += v[z];
             int w = 0;
 #pragma unroll
             for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
@@ -1077,8 +1231,9 @@ extern "C" size_t rbr_textcnn_fwd_ws_bytes(const rbr_textcnn_desc* d) {
 namespace {
 
 struct ProdBwdLayout {
-    size_t G, total;
+    size_t G, bimg_t, total;         // bimg_t: weight planes of the row GEMM (prod_b16_rows_applicable shapes), else unused
     int KG, KGW, cp_real;
+    bool rows_gemm;
 };
 
 bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLayout& B) {
@@ -1091,6 +1246,8 @@ bool prod_bwd_layout(const rbr_textcnn_desc* d, const ProdLayout& Lo, ProdBwdLay
     if ((size_t)B.KGW * 8 * kWavesPerWG + (size_t)kWavesPerWG * d->D * 4 > 64 * 1024) return false;   // lists + partial rows in LDS
     size_t o = 0;
     B.G = o;  o += align256((size_t)Lo.cap * B.KG * sizeof(float));
+    B.rows_gemm = prod_b16_rows_applicable(d);
+    B.bimg_t = o;  o += B.rows_gemm ? align256(prod_b16_rows_image_bytes(B.KG, d->D)) : 0;
     B.total = o;
     return true;
 }
@@ -1192,6 +1349,7 @@ extern "C" int rbr_textcnn_bwd_dtable_prod_ex(const rbr_textcnn_desc* d, const i
 extern "C" size_t rbr_textcnn_row_grad_partials(const rbr_textcnn_desc* d) {
     ProdLayout Lo;
     if (!prod_applicable(d) || !prod_layout(d, Lo)) return 0;
+    if (prod_b16_rows_applicable(d)) return (size_t)prod_b16_rows_partials(Lo.cap, d->D);
     return (size_t)std::min(Lo.cap, kGtwMaxBlocks);
 }
 
@@ -1243,8 +1401,11 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     // kGBuild alone (rbr_textcnn_bwd_g_build) always builds G: its caller multiplies it out later (rbr_textcnn_bwd_g_product)
     const bool want_g = dtable != nullptr || !(phases & kGProduct);
     if (phases & kGBuild) {
-        if ((want_g && !(phases & kGZeroed)) || dgate != nullptr) {      // dgate is zeroed here: the caller hands it over uninitialised
-            if (int e_ = rbr::launch<zero_g_rows_kernel, 256>(dim3(2048), dim3(256), 0, st, "textcnn zero_g_rows launch", counter, Lo.cap, B.KG / 4, (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate, dgate != nullptr ? (long)d->n_docs * d->L * (RBR_CONV_GATE_SPLIT_OF(d->flags) ? 2 : 1) : 0L)) return e_;
+        if ((want_g && !(phases & kGZeroed)) || dgate != nullptr || B.rows_gemm) {      // dgate is zeroed here: the caller hands it over uninitialised
+            // row-GEMM shapes: the same launch writes the bf16 planes of Wprod^T the product phase multiplies G by
+            const long n_img = B.rows_gemm ? prod_b16_rows_image_items(B.KG, d->D) : 0;
+            const int nb_zero = 2048, nb_img = (int)std::min<long>((n_img + 255) / 256, 1024);
+            if (int e_ = rbr::launch<zero_g_rows_kernel, 256>(dim3(nb_zero + nb_img), dim3(256), 0, st, "textcnn zero_g_rows launch", counter, Lo.cap, B.KG / 4, (want_g && !(phases & kGZeroed)) ? reinterpret_cast<f32x4*>(G) : nullptr, dgate, dgate != nullptr ? (long)d->n_docs * d->L * (RBR_CONV_GATE_SPLIT_OF(d->flags) ? 2 : 1) : 0L, nb_zero, WT, cp_real, d->D, n_img, reinterpret_cast<unsigned char*>(static_cast<char*>(bwd_ws) + B.bimg_t))) return e_;
         }
         const long n_items = (long)d->n_docs * A.C * A.KF;
         if (int e_ = rbr::launch<build_g_kernel, 256>(dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, "textcnn build_g launch", A, reinterpret_cast<const long long*>(ids), mask, gate, row_of_token, T, feat, argmax, d_feat, want_g ? G : nullptr, dgate, prod_t_bf16(d) ? 1 : 0)) return e_;
@@ -1254,6 +1415,8 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     const dim3 grid((unsigned)std::min(Lo.cap, kGtwMaxBlocks));
     if (phases & kGRows) {
         if (sq_part == nullptr) { set_error("compact row gradient needs sq_part"); return RBR_ERR_BAD_ARG; }
+        if (B.rows_gemm)          // many short documents: G is dense enough for the bf16-plane GEMM (textcnn_prod_b16.hip)
+            return prod_b16_rows_gemm(B.KG, d->D, Lo.cap, counter, G, static_cast<char*>(bwd_ws) + B.bimg_t, dtable, sq_part, st);
         if (int e_ = rbr::launch<g_times_w_kernel<kGtwRows>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, sq_part)) return e_;
     } else if (phases & kGAccumulate) {
         if (int e_ = rbr::launch<g_times_w_kernel<kGtwAccumulate>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, (float*)nullptr)) return e_;
@@ -1506,12 +1669,22 @@ extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float*
     }
     float* part = ws;
     float* part_b = ws + (size_t)kDwgSplit * B.KG * d->D;
-    hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
-                       counter, G, tok_of_row, table, part);
+    static const bool f32_form = getenv("RBR_DW_FROM_G_F32") != nullptr && atoi(getenv("RBR_DW_FROM_G_F32")) != 0;
+    // z slices beyond the K splits: one workgroup per (channel block, document chunk) of the bias gradient's partial sums
+    const int tile_wgs = ((B.KG + 63) / 64) * ((d->D + 63) / 64);
+    const int db_slices = (((A.C + 255) / 256) * kDbChunks + tile_wgs - 1) / tile_wgs;
+    if (f32_form)
+        hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                           counter, G, tok_of_row, table, part);
+    else      // (the bias gradient's partials in the same launch: one z slice more)
+        hipLaunchKernelGGL(dw_from_g_b16_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit + db_slices), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                           counter, G, tok_of_row, table, part, d->n_docs, A.C, d->act, feat, d_feat, part_b);
     RBR_CHECK_LAUNCH("textcnn dw_from_g launch");
-    hipLaunchKernelGGL(dbias_partial_kernel, dim3((A.C + 255) / 256, kDbChunks), dim3(256), 0, st, d->n_docs, A.C, d->act, feat, d_feat,
-                       part_b);
-    RBR_CHECK_LAUNCH("textcnn dbias partial launch");
+    if (f32_form) {
+        hipLaunchKernelGGL(dbias_partial_kernel, dim3((A.C + 255) / 256, kDbChunks), dim3(256), 0, st, d->n_docs, A.C, d->act, feat, d_feat,
+                           part_b);
+        RBR_CHECK_LAUNCH("textcnn dbias partial launch");
+    }
     MutPtrArray dWp{}, dbp{};
     for (int w = 0; w < d->n_widths; ++w) { dWp.p[w] = dW[w]; dbp.p[w] = dbias[w]; }
     const long total = (long)cp_real * d->D + A.C;

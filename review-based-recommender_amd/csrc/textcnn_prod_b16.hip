@@ -48,6 +48,8 @@ struct B16Gemm {
     const unsigned char* bimg;       // [group][chunk][tile][step][plane][lane][8 bf16]
     float* T;
     int cap, D, pitch, ngroups, nchunks;
+    int ncols;                       // columns of T that exist (stores beyond are dropped); 0 = every column of a group (pitch-wide T)
+    float* sq_part;                  // != NULL: sq_part[workgroup] = sum of squares of what this workgroup stored (fixed order)
 };
 
 __device__ __forceinline__ void b16_dma16(const void* gsrc, void* lds_base) {
@@ -66,7 +68,10 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int mblock = (jj / g.ngroups) * 8 + xcd, ng = jj - (jj / g.ngroups) * g.ngroups;
     const int m0 = mblock * kB16BM;
-    if (m0 >= n) return;
+    if (m0 >= n) {
+        if (g.sq_part != nullptr && threadIdx.x == 0) g.sq_part[blockIdx.x] = 0.f;
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = g.D;
@@ -80,7 +85,7 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     for (int q = 0; q < 2; ++q) {
         const int rl = wave * 32 + q * 16 + (lane >> 2);
         const int row = m0 + rl;
-        aoff[q] = (row < n) ? g.tok_of_row[row] * (long)D : -1;
+        aoff[q] = (row < n) ? (g.tok_of_row != nullptr ? g.tok_of_row[row] : (long long)row) * (long)D : -1;      // NULL: rows in place
         aseg[q] = ((lane & 3) ^ ((rl >> 2) & 3)) * 4;          // position p of the row holds segment p ^ swz(row)
     }
     // weight fragments of a stage: 12 x 1 KiB, three per wave.  Every wave issues 5 LDS-DMA instructions per stage, also
@@ -181,13 +186,28 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     // instruction writes two whole 128-byte lines
     float* out = g.T + (size_t)(m0 + wave * 32 + 4 * h) * g.pitch + ng * kB16BN + r32;
     const int rows_left = n - (m0 + wave * 32 + 4 * h);
+    const int cols_left = (g.ncols > 0 ? g.ncols : g.ngroups * kB16BN) - (ng * kB16BN + r32);      // this lane's column t*32 exists iff < cols_left
+    float sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int dr = (r & 3) + 8 * (r >> 2);
         if (dr < rows_left) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) out[(size_t)dr * g.pitch + t * 32] = acc[t][r];
+            for (int t = 0; t < 4; ++t)
+                if (t * 32 < cols_left) {
+                    out[(size_t)dr * g.pitch + t * 32] = acc[t][r];
+                    sq = fmaf(acc[t][r], acc[t][r], sq);
+                }
         }
+    }
+    if (g.sq_part != nullptr) {          // the rows' share of the gradient norm: lanes by shuffle, waves in wave order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        float* s_sq = reinterpret_cast<float*>(smem);
+        __builtin_amdgcn_s_barrier();      // every wave is out of the K loop: the ring is free
+        if (lane == 0) s_sq[wave] = sq;
+        __syncthreads();
+        if (tid == 0) g.sq_part[blockIdx.x] = (s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3]);
     }
 }
 
@@ -641,6 +661,35 @@ __device__ __forceinline__ void prod_gemm_b16sd_kernel(const B16Gemm& g, unsigne
                 *reinterpret_cast<unsigned*>(out + (size_t)dr * g.pitch + t * 32) = pack_bf16(mine, other);
         }
     }
+}
+
+// ---- the backward's row GEMM: rows [cap, D] = G [cap, KG] @ Wprod^T  (rbr_common.h)
+bool prod_b16_rows_applicable(const rbr_textcnn_desc* d) {
+    // Many short documents (NARRE: 5120 reviews of 50 tokens -> 2.3 M taps into 14.8 k x 450 cells: G is a third full) make the
+    // sparse row product fetch a 1200-byte row of Wprod^T per non-zero (131 us at cfg3) where the dense product on the bf16 pipe,
+    // exact three-plane split as in the forward, is 4 GFLOP.  The rule is the weight gradient's (dw_from_g): the same shapes.
+    long cp = 0;
+    for (int w = 0; w < d->n_widths; ++w) cp += (long)d->kz[w] * d->ch[w];
+    static const bool off = getenv("RBR_ROWS_GEMM") != nullptr && atoi(getenv("RBR_ROWS_GEMM")) == 0;
+    return !off && d->D % 4 == 0 && d->L <= 128 && d->n_docs >= 512 && cp <= 2048;
+}
+size_t prod_b16_rows_image_bytes(int KG, int D) {
+    return (size_t)((D + kB16BN - 1) / kB16BN) * ((KG + kB16KC - 1) / kB16KC) * kB16BBytes;
+}
+long prod_b16_rows_image_items(int KG, int D) { return (long)((D + kB16BN - 1) / kB16BN) * ((KG + kB16KC - 1) / kB16KC) * 4 * 64; }
+int prod_b16_rows_partials(int cap, int D) {
+    return (((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8) * ((D + kB16BN - 1) / kB16BN);
+}
+int prod_b16_rows_gemm(int KG, int D, int cap, const int* counter, const float* G, const void* bimg_t, float* rows, float* sq_part,
+                       hipStream_t st) {
+    if ((((uintptr_t)G) & 15) != 0 || (KG & 3) != 0 || (D & 3) != 0) { set_error("row GEMM operands must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
+    B16Gemm g{};
+    g.counter = counter; g.tok_of_row = nullptr; g.table = G; g.bimg = static_cast<const unsigned char*>(bimg_t); g.T = rows;
+    g.cap = cap; g.D = KG; g.pitch = D; g.ngroups = (D + kB16BN - 1) / kB16BN; g.nchunks = (KG + kB16KC - 1) / kB16KC;
+    g.ncols = D; g.sq_part = sq_part;
+    const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
+    return rbr::launch<prod_gemm_b16_kernel<6>, kB16Threads, 2>(dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16Lds, st,
+                                                               "textcnn rows GEMM launch", g);
 }
 
 int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, const int* counter, const long long* tok_of_row,
