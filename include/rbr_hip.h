@@ -69,6 +69,16 @@ typedef struct rbr_textcnn_desc {
  * return RBR_ERR_UNSUPPORTED for a split gate. */
 #define RBR_CONV_GATE_SPLIT(k) (((k) & 0xf) << 8)
 #define RBR_CONV_GATE_SPLIT_OF(flags) (((flags) >> 8) & 0xf)
+/* Arithmetic class STAMPED into a descriptor (rbr_textcnn_desc_stamp): bits 16-17 the RBR_PROD_* precision, bit 18 bf16 storage of
+ * the product table, bit 19 "stamped".  A stamped descriptor carries the class it was planned with from the forward to the
+ * backward: the workspace layout (weight image, bf16 row copy, element type of T) depends on it, and reading the process-wide
+ * settings again in every stage let a change between a forward and its backward -- or between a graph capture and a later
+ * eager call on the same workspace -- silently reinterpret T.  An unstamped descriptor (flags bit 19 clear) reads the
+ * process-wide settings at every call, as before.  Reference counterpart: none (the reference has one arithmetic: fp32). */
+#define RBR_CONV_CLASS_STAMPED (1 << 19)
+#define RBR_CONV_CLASS_PRECISION_OF(flags) (((flags) >> 16) & 0x3)
+#define RBR_CONV_CLASS_T_BF16 (1 << 18)
+void rbr_textcnn_desc_stamp(rbr_textcnn_desc* d);
 
 int rbr_version(void);
 const char* rbr_last_error(void);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "rbr_set_conv_mode": (None, [i32]),
     "rbr_set_prod_precision": (None, [i32]),
     "rbr_get_prod_precision": (i32, []),
+    "rbr_textcnn_desc_stamp": (None, [_DESC]),
     "rbr_set_b16_storage": (None, [i32]),
     "rbr_textcnn_conv_fwd": (C.c_int, [_DESC, c_i64p, c_u8p, c_f32p, c_f32p, _PP, c_f32p, c_f32p, c_i32p, C.c_void_p,
                                        c_stream]),
@@ -266,8 +267,42 @@ def ptr_array(tensors: Sequence[torch.Tensor], dtype: torch.dtype, name: str):
     return arr
 
 
+# ---- capture guard.  While train_step.GraphedTrainStep / GraphedForward record a hipGraph, every op of this package must be
+# enqueued on the capturing stream or on a stream this package forked from it with events (functional._side_stream: the weight-
+# gradient chain).  An op issued on any OTHER stream during a capture is refused with a Python error -- round 3's "item tower on a
+# stream of its own" experiment ended in a segmentation fault inside the capture of the backward instead (the
+# word table's AccumulateGrad node lived on another stream than the gradient's producer, and autograd's cross-stream hand-over to
+# it is what hipGraph capture died in); a two-stream forward must fork and join INSIDE one autograd function, as _textcnn_backward
+# and _DattTowers.backward do, so that autograd sees one node on one stream.
+_CAPTURE_GUARD = None            # None, or the set of stream handles an op may use while a capture is being recorded
+FORKED_STREAMS: set = set()      # streams functional forks from the current one with events (allowed under the guard)
+
+
+class capture_guard:
+    """with capture_guard(stream): ... -- ops of this package raise if they find another current stream than `stream` (or one of
+    the package's own forked streams)."""
+
+    def __init__(self, stream):
+        self.allowed = {stream.cuda_stream}
+
+    def __enter__(self):
+        global _CAPTURE_GUARD
+        self.prev, _CAPTURE_GUARD = _CAPTURE_GUARD, self.allowed
+        return self
+
+    def __exit__(self, *a):
+        global _CAPTURE_GUARD
+        _CAPTURE_GUARD = self.prev
+        return False
+
+
 def current_stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    s = torch.cuda.current_stream().cuda_stream
+    if _CAPTURE_GUARD is not None and s not in _CAPTURE_GUARD and s not in FORKED_STREAMS:
+        raise RuntimeError("an op of this package was issued on a stream that is neither the capturing stream nor one the package "
+                           "forked from it: a hipGraph capture cannot follow it (fork and join inside ONE autograd function "
+                           "instead; see _lib.capture_guard)")
+    return s
 
 
 CONV_PAD_RUNS = 1      # RBR_CONV_PAD_RUNS
@@ -285,6 +320,8 @@ def make_desc(n_docs, L, D, V, kernel_sizes, channels, pad_mode, act, padding_id
     d.pad_mode, d.act = int(pad_mode), int(act)
     d.padding_idx = -1 if padding_idx is None else int(padding_idx)
     d.flags = int(flags)
+    # the arithmetic class in force NOW travels with the descriptor (forward -> backward -> any later call on the same workspace)
+    lib().rbr_textcnn_desc_stamp(C.byref(d))
     return d
 
 

@@ -88,6 +88,7 @@ int forced_conv_mode();
 // bf16-plane form of the token-product GEMM (textcnn_prod_b16.hip): RBR_PROD_* in force, whether it serves `d`, the
 // bytes of its weight-plane image, the pack launch and the GEMM launch (T pitch must be >= 128 * prod_b16_groups)
 int prod_precision();
+int prod_precision_of(const rbr_textcnn_desc* d);      // the descriptor's stamped class, else the process-wide setting
 bool prod_b16_applicable(const rbr_textcnn_desc* d);
 int prod_b16_groups(int cp_real);
 size_t prod_b16_image_bytes(const rbr_textcnn_desc* d, int cp_real);

@@ -523,15 +523,23 @@ int prod_precision() {
     return RBR_PROD_BF16X3;
 }
 
-bool prod_b16_applicable(const rbr_textcnn_desc* d) { return prod_precision() != RBR_PROD_F32 && d->D % 4 == 0; }
+// the arithmetic class of a conv call: the descriptor's stamp (rbr_textcnn_desc_stamp) when it carries one, else the process-wide
+// setting -- every stage of a call, and its backward, must read the SAME class (the workspace layout depends on it)
+int prod_precision_of(const rbr_textcnn_desc* d) {
+    return (d->flags & RBR_CONV_CLASS_STAMPED) ? RBR_CONV_CLASS_PRECISION_OF(d->flags) : prod_precision();
+}
+bool prod_b16_applicable(const rbr_textcnn_desc* d) { return prod_precision_of(d) != RBR_PROD_F32 && d->D % 4 == 0; }
 
 // bf16 STORAGE (rows copy, product table): the plain-bf16 class only; RBR_B16_STORAGE=0 keeps f32 streams (an A/B switch: same
 // arithmetic class either way, T's extra rounding stays inside the class's stated tolerances)
 static int g_b16_storage = -1;           // -1: RBR_B16_STORAGE env (default on), 0 off, 1 on
-bool prod_t_bf16(const rbr_textcnn_desc* d) {
+static bool b16_storage_setting() {
     static const char* env = getenv("RBR_B16_STORAGE");
-    const bool on = g_b16_storage >= 0 ? g_b16_storage != 0 : !(env && !strcmp(env, "0"));
-    return on && prod_b16_applicable(d) && prod_precision() == RBR_PROD_BF16;
+    return g_b16_storage >= 0 ? g_b16_storage != 0 : !(env && !strcmp(env, "0"));
+}
+bool prod_t_bf16(const rbr_textcnn_desc* d) {
+    const bool on = (d->flags & RBR_CONV_CLASS_STAMPED) ? (d->flags & RBR_CONV_CLASS_T_BF16) != 0 : b16_storage_setting();
+    return on && prod_b16_applicable(d) && prod_precision_of(d) == RBR_PROD_BF16;
 }
 size_t prod_b16_rows_bytes(const rbr_textcnn_desc* d, int cap) {
     return prod_t_bf16(d) ? (size_t)(cap + kB16BM) * b16s_dp(d->D) * 2 : 0;
@@ -735,14 +743,14 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     static const bool direct_ok = getenv("RBR_GEMM_ROWS_IN_LDS") == nullptr || atoi(getenv("RBR_GEMM_ROWS_IN_LDS")) == 0;
     if (direct_ok && g.ngroups >= 6 && g.nchunks >= 12) {
         const dim3 grid_d((unsigned)(mblocks * ((g.ngroups + 1) / 2)));
-        switch (prod_precision()) {
+        switch (prod_precision_of(d)) {
             case RBR_PROD_BF16X3: return rbr::launch<prod_gemm_b16d_kernel<6, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
             case RBR_PROD_BF16X2: return rbr::launch<prod_gemm_b16d_kernel<3, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
             case RBR_PROD_BF16: return rbr::launch<prod_gemm_b16d_kernel<1, 8>, kB16Threads, 2>(grid_d, block, B16d<8>::kLds, st, "textcnn prod_gemm_b16d launch", g);
             default: set_error("prod_b16_gemm called in f32 mode"); return RBR_ERR_BAD_ARG;
         }
     }
-    switch (prod_precision()) {
+    switch (prod_precision_of(d)) {
         case RBR_PROD_BF16X3: return rbr::launch<prod_gemm_b16_kernel<6>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
         case RBR_PROD_BF16X2: return rbr::launch<prod_gemm_b16_kernel<3>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
         case RBR_PROD_BF16: return rbr::launch<prod_gemm_b16_kernel<1>, kB16Threads, 2>(grid, block, kB16Lds, st, "textcnn prod_gemm_b16 launch", g);
@@ -756,4 +764,9 @@ extern "C" void rbr_set_prod_precision(int32_t mode) {
     rbr::g_prod_precision = (mode >= RBR_PROD_F32 && mode <= RBR_PROD_BF16) ? mode : -1;
 }
 extern "C" int32_t rbr_get_prod_precision(void) { return rbr::prod_precision(); }
+extern "C" void rbr_textcnn_desc_stamp(rbr_textcnn_desc* d) {
+    if (!d) return;
+    d->flags &= ~(RBR_CONV_CLASS_STAMPED | RBR_CONV_CLASS_T_BF16 | (0x3 << 16));
+    d->flags |= RBR_CONV_CLASS_STAMPED | ((rbr::prod_precision() & 0x3) << 16) | (rbr::b16_storage_setting() ? RBR_CONV_CLASS_T_BF16 : 0);
+}
 extern "C" void rbr_set_b16_storage(int32_t on) { rbr::g_b16_storage = (on == 0 || on == 1) ? on : -1; }

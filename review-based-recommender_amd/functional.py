@@ -600,6 +600,7 @@ def _side_stream(dev):
     s = _SIDE_STREAMS.get(dev)
     if s is None:
         s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        _lib.FORKED_STREAMS.add(s.cuda_stream)          # forked and joined with events by its users: fine inside a capture
     return s
 
 

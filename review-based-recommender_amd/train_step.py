@@ -314,6 +314,11 @@ def _flat_views(flat: torch.Tensor, layout, like):
     return [flat[o:o + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for o, t in zip(layout, like)]
 
 
+def _lib_mod():
+    from . import _lib
+    return _lib
+
+
 def _capture_stream(dev) -> torch.cuda.Stream:
     """A stream to record a graph on, with the library's per-stream state (functional.prepare_stream_state) already in place."""
     cs = torch.cuda.Stream(device=dev)
@@ -350,7 +355,8 @@ class GraphedForward:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self._capture_stream = _capture_stream(batch[0].device)
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode=capture_error_mode):
+        with torch.no_grad(), _lib_mod().capture_guard(self._capture_stream), \
+                torch.cuda.graph(self.graph, stream=self._capture_stream, capture_error_mode=capture_error_mode):
             out = model(*self.batch)
         self.pred = out[0] if isinstance(out, tuple) else out
 
@@ -465,11 +471,11 @@ class GraphedTrainStep:
             optimizer.zero_grad(set_to_none=True)
             sl.g_fwd_bwd = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
             if grad_sync is None:
-                with torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
+                with _lib_mod().capture_guard(cs), torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
                     sl.loss, sl.gnorm, sl.pred = train_step(model, optimizer, sl.batch, sl.ratings, max_grad_norm)
                 sl.static_grads = [(p, p.grad) for p in model.parameters()]
             else:
-                with torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
+                with _lib_mod().capture_guard(cs), torch.cuda.graph(sl.g_fwd_bwd, stream=cs, capture_error_mode=mode):
                     optimizer.zero_grad()
                     pred, loss = _forward_loss_backward(model, sl.batch, sl.ratings)
                     sl.loss, sl.pred = loss.detach(), pred.detach()
@@ -478,7 +484,7 @@ class GraphedTrainStep:
                 grad_sync(model)
                 sl.static_grads = [(p, p.grad) for p in model.parameters()]
                 sl.g_update = torch.cuda.CUDAGraph(keep_graph=True) if self._keep_graph else torch.cuda.CUDAGraph()
-                with torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), stream=cs, capture_error_mode=mode):
+                with _lib_mod().capture_guard(cs), torch.cuda.graph(sl.g_update, pool=sl.g_fwd_bwd.pool(), stream=cs, capture_error_mode=mode):
                     sl.gnorm = clip_and_step(model, optimizer, max_grad_norm)
         with torch.no_grad():
             for p, v in zip(model.parameters(), saved_params):

@@ -31,8 +31,10 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     _lib.lib().rbr_set_conv_mode(2)
-    cfg = synth.DEEPCONN_CFGS["cfg1"]                   # B=32 per rank, L=300, D=100: the cfg5 arithmetic at a size two
-                                                        # ranks on one card finish in seconds
+    # RBR_TEST_CFG=cfg1: B=32 per rank, L=300, D=100 -- the cfg5 arithmetic at a size two ranks on one card finish in seconds;
+    # RBR_TEST_CFG=cfg2: configs[4]'s OWN shard shape (256 pairs per rank, 2x512 tokens, D=300, widths 3/5/7, V=50 002: the 60 MB
+    # word-table gradient goes through GradAllReduce(comm_dtype=bf16) as on the 8-GPU node)
+    cfg = synth.DEEPCONN_CFGS[os.environ.get("RBR_TEST_CFG", "cfg1")]
 
     def build():
         with contextlib.redirect_stdout(io.StringIO()):

@@ -121,3 +121,26 @@ def test_graphed_forward_replays_the_eval_forward():
     assert not g.matches(ragged)
     with pytest.raises(RuntimeError):
         g(ragged)
+
+
+def test_capture_guard_refuses_an_op_on_a_stream_nobody_forked():
+    """VERDICT r3 #5 / ADVICE: round 3's "item tower on its own stream" died with a segmentation fault inside the hipGraph capture
+    of the backward.  Now an op of this package that finds itself on a stream other than the capturing one (or one of the
+    package's own forked side streams) while a step is being recorded raises a Python error before anything is launched there."""
+    from review_based_recommender_amd import _lib, functional as RF
+    x = torch.randn(64, device="cuda:0")
+    y = torch.randn(64, device="cuda:0")
+    cs, other = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with _lib.capture_guard(cs):
+        with torch.cuda.stream(cs):
+            RF.mse_loss(x, y)                                  # the capturing stream: fine
+        side = RF._side_stream(x.device)
+        if side is not None:
+            with torch.cuda.stream(side):
+                RF.mse_loss(x, y)                              # the package's forked side stream: fine
+        with torch.cuda.stream(other), pytest.raises(RuntimeError, match="neither the capturing stream"):
+            RF.mse_loss(x, y)
+    with torch.cuda.stream(other):
+        RF.mse_loss(x, y)                                      # no guard, no complaint
+    torch.cuda.synchronize()

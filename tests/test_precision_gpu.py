@@ -267,3 +267,40 @@ def test_bf16_storage_stays_inside_the_bf16_class(golden_dir):
     fscale = float(out[0][1].abs().max())
     assert float((out[0][1] - out[1][1]).abs().max()) <= 6e-3 * fscale
     assert not torch.equal(out[0][1], out[1][1]), "bf16 storage was not engaged"
+
+
+def test_the_arithmetic_class_travels_with_the_descriptor():
+    """the class a forward was planned with (precision, bf16 storage -- they decide the workspace layout and the element
+    type of the product table) is stamped into its descriptor (rbr_textcnn_desc_stamp), so changing the process-wide setting between
+    a forward and its backward cannot reinterpret the workspace: the backward of a bf16-storage forward run under "bf16x3" gives the
+    gradients of the same forward + backward run entirely under "bf16"."""
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd import functional as RF
+    L_ = _lib.lib()
+    cfg = synth.DEEPCONN_CFGS["cfg1"]
+    args, ratings = _deepconn_batch(cfg, False)
+    L_.rbr_set_conv_mode(2)
+    grads = {}
+    try:
+        for switch in (False, True):
+            RF.set_prod_precision("bf16")
+            model = _deepconn(cfg)
+            model.train()
+            loss = torch.nn.functional.mse_loss(model(*args), ratings)
+            if switch:
+                RF.set_prod_precision("bf16x3")         # between the forward and its backward
+                L_.rbr_set_b16_storage(0)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads[switch] = {k: p.grad.clone() for k, p in model.named_parameters()}
+            L_.rbr_set_b16_storage(-1)
+    finally:
+        L_.rbr_set_b16_storage(-1)
+        RF.set_prod_precision(None)
+        L_.rbr_set_conv_mode(0)
+    for k in grads[False]:
+        a, b = grads[False][k], grads[True][k]
+        assert torch.isfinite(b).all(), k
+        assert float((a - b).abs().max()) <= 1e-6 + 1e-4 * float(a.abs().max()), k      # (f32 atomics in G: rounding-level noise)
+    d = _lib.make_desc(64, 64, 8, 100, [3], [6], _lib.PAD_SAME, _lib.ACT_RELU, 0)
+    assert d.flags & (1 << 19), "make_desc stamps the class"
