@@ -346,12 +346,14 @@ int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const float* u_feat
  * documents, then B item documents; d->n_docs = 2B): rbr_textcnn_pool_finalize (deepconn/layers.py:107-109: bias, ReLU, the
  * max over all slabs), the head above (drop: a given multiplier, or p_drop > 0: drawn in-kernel as rbr_pair_head_fwd_train
  * does) and -- when target != NULL -- the trainers' nn.MSELoss(mean) (train_deepconn_pp.py:137,164: loss[0], d_pred_unit as
- * rbr_mse_loss_fwd) in ONE launch instead of three.  feat / argmax [2B, C] are written for the backward.  ticket: one int32
+ * rbr_mse_loss_fwd) in ONE launch instead of three.  feat / argmax [2B, C] are written for the backward.
+ * first [2B] or NULL: document r takes its pool partials from document first[r] (rbr_dedup_rows: the repeated documents of the
+ * batch were blanked and not encoded); feat / argmax rows of r are then copies of first[r]'s.  ticket: one int32
  * in device memory, zero before the first call (the launch re-arms it); calls that may be in flight at the same time (different
  * streams) need a ticket each -- the binding keeps one per (device, stream).  RBR_ERR_UNSUPPORTED when the conv has more than
  * 256 channel slots. */
 int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx, const float* const* bias,
-                           float* feat, int32_t* argmax, int32_t K, const int64_t* u_id, const int64_t* i_id,
+                           float* feat, int32_t* argmax, const int64_t* first, int32_t K, const int64_t* u_id, const int64_t* i_id,
                            const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed, uint64_t* rng_state,
                            float* drop_out, float* zero_buf, int64_t zero_n, float* ul, float* il, float* pred,
                            const float* target, float* loss, float* d_pred_unit, int32_t* ticket, void* stream);
@@ -525,6 +527,9 @@ int rbr_sanitize_ids(int32_t n_sets, const rbr_id_set* sets, int64_t* err, void*
 size_t rbr_dedup_ws_bytes(int32_t U, int32_t I);
 int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const int64_t* i_ids, int32_t U, int32_t I,
                    const uint8_t* mask_in, void* ws, int64_t* first, uint8_t* mask_out, void* stream);
+/* Backward counterpart: d_rows [n_rows, H] (the gradient of the per-document features) -- every repeated row r (first[r] != r) is
+ * ADDED onto row first[r] and cleared, so the encoder's backward, which skips the blanked documents, sees the whole gradient. */
+int rbr_dedup_fold_rows(int32_t n_rows, int32_t H, const int64_t* first, float* d_rows, void* stream);
 
 /* ---- NgramFeat arch="HierPooling" (deepconn/layers.py:62-98,110-114): pooled[doc,d] =
  *      max_l mean_{j<k} x[doc,l+j,d] over l in [0, L-k], x = mask * table[ids]; relu != 0 applies the

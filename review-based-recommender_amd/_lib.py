@@ -119,7 +119,8 @@ SIGNATURES = {
     "rbr_textcnn_token_list": (C.c_int, [_DESC, C.c_void_p, _PP, _PP, _PP, C.POINTER(i32)]),
     "rbr_textcnn_prod_prepare_ids": (C.c_int, [_DESC, i32, C.POINTER(IdSet), C.c_void_p, c_i64p, c_u8p, _PP, c_i32p, C.c_void_p,
                                                c_stream]),
-    "rbr_pair_head_fwd_pool": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, i32, c_i64p, c_i64p, C.POINTER(HeadParams),
+    "rbr_dedup_fold_rows": (C.c_int, [i32, i32, c_i64p, c_f32p, c_stream]),
+    "rbr_pair_head_fwd_pool": (C.c_int, [_DESC, c_f32p, c_i32p, _PP, c_f32p, c_i32p, c_i64p, i32, c_i64p, c_i64p, C.POINTER(HeadParams),
                                          c_f32p, C.c_float, C.c_uint64, C.c_void_p, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p,
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_stream]),
     "rbr_clip_adam_step_rows": (C.c_int, [i32, _PP, _PP, _PP, _PP, C.POINTER(C.c_int64), C.c_float, C.c_float, C.c_float,

@@ -539,6 +539,28 @@ __global__ __launch_bounds__(256) void dedup_apply_kernel(int B, int L, const lo
 
 }  // namespace rbr
 
+// The backward's side of the dedup: the gradient rows of the repeated documents are added onto their first occurrence's row (which
+// is the one the encoder's backward will see: the repeated rows' masks are blank) and cleared.  One wave per row.
+namespace rbr {
+__global__ __launch_bounds__(256) void dedup_fold_kernel(int n_rows, int H, const long long* __restrict__ first, float* __restrict__ d_rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    const int f = (int)first[r];
+    if (f == r) return;
+    for (int h = lane; h < H; h += 64) {
+        atomicAdd(d_rows + (long)f * H + h, d_rows[(long)r * H + h]);
+        d_rows[(long)r * H + h] = 0.f;
+    }
+}
+}  // namespace rbr
+extern "C" int rbr_dedup_fold_rows(int32_t n_rows, int32_t H, const int64_t* first, float* d_rows, void* stream) {
+    if (n_rows <= 0 || H <= 0 || !first || !d_rows) { rbr::set_error("rbr_dedup_fold_rows: bad argument"); return RBR_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(rbr::dedup_fold_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_rows, H,
+                       reinterpret_cast<const long long*>(first), d_rows);
+    RBR_CHECK_LAUNCH("dedup fold launch");
+    return 0;
+}
+
 extern "C" size_t rbr_dedup_ws_bytes(int32_t U, int32_t I) { return (U > 0 && I > 0) ? ((size_t)U + (size_t)I) * sizeof(int) : 0; }
 
 extern "C" int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const int64_t* i_ids, int32_t U, int32_t I,

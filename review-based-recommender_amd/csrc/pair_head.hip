@@ -138,6 +138,8 @@ struct HeadPool {
     PtrArray bias;
     float* feat;               // [2B, C]
     int* argmax;               // [2B, C]
+    const long long* first;    // [2B] or NULL: document r takes the pool partials of document first[r] (in-batch dedup by id: the
+                               // repeated documents were blanked and not encoded; rbr_dedup_rows)
 };
 
 __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, const HeadPool hp, int B, int K,
@@ -176,16 +178,19 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
     static_assert(kMaxSlots <= 256, "one thread per slot below");
     if (t < kMaxSlots) { s_chan[t] = P.slot_chan[t]; s_sw[t] = P.slot_w[t]; s_skz[t] = P.slot_kz[t]; }
     if (t < RBR_MAX_WIDTHS) { s_choff[t] = P.ch_off[t]; s_biasp[t] = hp.bias.p[t]; }
+    __shared__ int s_src[2];                                           // the documents whose partials this pair reads
+    if (t < 2) s_src[t] = hp.first != nullptr ? (int)hp.first[t * B + b] : t * B + b;
+    __syncthreads();
     for (int i = t; i < 2 * wpd; i += 256) {
         const int side = i >= wpd, w = side ? i - wpd : i;
-        s_flag[i] = flags[(side * B + b) * wpd + w];
+        s_flag[i] = flags[s_src[side] * wpd + w];
     }
     __syncthreads();
     const float NEG = -__builtin_huge_valf();
     for (int i = t; i < 2 * wpd * nslots; i += 256) {
         const int side = i >= wpd * nslots, r = side ? i - wpd * nslots : i;
         const int w = r / nslots, ls = r - w * nslots;
-        const long base = ((long)(side * B + b) * wpd + w) * P.nslots_total + (long)P.tile_base * kTile + ls;
+        const long base = ((long)s_src[side] * wpd + w) * P.nslots_total + (long)P.tile_base * kTile + ls;
         float v = NEG;
         if (s_chan[ls] >= 0) {
             const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (P.L - (int)s_skz[ls] + 1) : P.L;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void head_fwd_pool_kernel(const ConvPlan P, co
         }
         int bidx = 0;
         if (bw_tile >= 0) {
-            if (s_flag[side * wpd + bw_tile] == 1) bidx = hp.pidx[((long)doc * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
+            if (s_flag[side * wpd + bw_tile] == 1) bidx = hp.pidx[((long)s_src[side] * wpd + bw_tile) * P.nslots_total + (long)P.tile_base * kTile + ls];
             else bidx = bw_tile * kTile;
         }
         const int bw = s_sw[ls];
@@ -460,10 +465,10 @@ extern "C" int rbr_pair_head_fwd_train(int32_t B, int32_t H, int32_t K, const fl
 // Head forward with the encoder's pool epilogue (rbr_textcnn_pool_finalize) in front and, optionally, the trainers' MSELoss
 // behind: one launch.  The encoder batch holds the B user documents, then the B item documents.
 extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pval, const int32_t* pidx, const float* const* bias,
-                                      float* feat, int32_t* argmax, int32_t K, const int64_t* u_id, const int64_t* i_id,
-                                      const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed, uint64_t* rng_state,
-                                      float* drop_out, float* zero_buf, int64_t zero_n, float* ul, float* il, float* pred,
-                                      const float* target, float* loss, float* d_pred_unit, int32_t* ticket, void* stream) {
+                                      float* feat, int32_t* argmax, const int64_t* first, int32_t K, const int64_t* u_id,
+                                      const int64_t* i_id, const rbr_head_params* p, const float* drop, float p_drop, uint64_t seed,
+                                      uint64_t* rng_state, float* drop_out, float* zero_buf, int64_t zero_n, float* ul, float* il,
+                                      float* pred, const float* target, float* loss, float* d_pred_unit, int32_t* ticket, void* stream) {
     ConvPlan plans[kMaxGroups];
     const int ng = build_plans(d, plans, kMaxTiles);
     if (!ng) return RBR_ERR_BAD_ARG;
@@ -481,7 +486,7 @@ extern "C" int rbr_pair_head_fwd_pool(const rbr_textcnn_desc* d, const float* pv
     tr.rng_state = (p_drop > 0.f) ? reinterpret_cast<unsigned long long*>(rng_state) : nullptr;
     tr.drop_out = drop_out; tr.zero_buf = zero_buf; tr.zero_n = zero_n;
     HeadPool hp{};
-    hp.pval = pval; hp.pidx = pidx; hp.feat = feat; hp.argmax = argmax;
+    hp.pval = pval; hp.pidx = pidx; hp.feat = feat; hp.argmax = argmax; hp.first = reinterpret_cast<const long long*>(first);
     for (int w = 0; w < d->n_widths; ++w) hp.bias.p[w] = bias[w];
     HeadMse mse{target, loss, d_pred_unit, ticket};
     const int zblocks = zero_n > 0 ? (int)std::min<long>((zero_n + 1023) / 1024, 256) : 0;

@@ -817,7 +817,7 @@ class _EncodeHead(torch.autograd.Function):
     (+ MSELoss) -- and its backward as head_bwd, then [zero G, G build, G @ Wprod^T] beside [dW] (see _textcnn_backward)."""
 
     @staticmethod
-    def forward(ctx, table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i, n_widths, *params):
+    def forward(ctx, table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i, n_widths, first, *params):
         ws_, bs_ = [w.contiguous() for w in params[:n_widths]], [b.contiguous() for b in params[n_widths:2 * n_widths]]
         head = [t.contiguous() for t in params[2 * n_widths:]]
         L_ = _lib.lib()
@@ -910,7 +910,7 @@ class _EncodeHead(torch.autograd.Function):
         ev = TIMER.record("pair_head_fwd_pool")
         check(L_.rbr_pair_head_fwd_pool(C.byref(desc), dev_ptr(pval, F32, "pval"), dev_ptr(pidx, I32, "pidx"),
                                         ptr_array(bs_, F32, "conv bias"), dev_ptr(feat, F32, "feat"), dev_ptr(argmax, I32, "argmax"),
-                                        K, dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
+                                        dev_ptr(first, I64, "first"), K, dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
                                         dev_ptr(drop_t, F32, "drop") if p_drop == 0.0 else None, float(p_drop), seed,
                                         state.data_ptr() if state is not None else None,
                                         dev_ptr(drop_t, F32, "drop") if p_drop > 0.0 else None, dev_ptr(flat_zero, F32, "zero_buf"),
@@ -922,6 +922,7 @@ class _EncodeHead(torch.autograd.Function):
         ctx.conv = _ConvSaved(table=table_c, ids=ids, packed=None, feat=feat, argmax=argmax, mask8=mask8, gate=None, ws=ws_,
                               desc=desc, prod_ws=prod_ws, fanout_acc=None, bws=None)
         ctx.head = (u_id, i_id, ul, il, head, drop_t, flat_zero, d_unit)
+        ctx.first = first
         ctx.dims = (B, Ctot, K, int(pad_u), int(pad_i), n_widths)
         ctx.set_materialize_grads(False)
         if loss is None:
@@ -953,27 +954,31 @@ class _EncodeHead(torch.autograd.Function):
         hg = _lib.HeadGrads(*[dev_ptr(t, F32, "d" + n) for t, n in zip(grads, _HEAD_NAMES)])
         d_pair = torch.empty(2 * B, H, dtype=F32, device=dev)
         feat = S.feat
-        need_conv = any(ctx.needs_input_grad[12:12 + 2 * n_widths]) or ctx.needs_input_grad[0]
+        need_conv = any(ctx.needs_input_grad[13:13 + 2 * n_widths]) or ctx.needs_input_grad[0]
         check(L_.rbr_pair_head_bwd(B, H, K, dev_ptr(feat[:B], F32, "u_feat"), dev_ptr(feat[B:], F32, "i_feat"),
                                    dev_ptr(u_id, I64, "u_id"), dev_ptr(i_id, I64, "i_id"), C.byref(hp),
                                    dev_ptr(drop_t, F32, "drop"), dev_ptr(ul, F32, "ul"), dev_ptr(il, F32, "il"),
                                    dev_ptr(d_pred, F32, "d_pred"), pad_u, pad_i, C.byref(hg),
                                    dev_ptr(d_pair[:B], F32, "d_ufeat"), dev_ptr(d_pair[B:], F32, "d_ifeat"), None,
                                    current_stream()), "rbr_pair_head_bwd")
+        if need_conv and ctx.first is not None:      # in-batch dedup: the repeated documents' gradient rows onto their first occurrence
+            check(L_.rbr_dedup_fold_rows(2 * B, H, dev_ptr(ctx.first, I64, "first"), dev_ptr(d_pair, F32, "d_feat"), current_stream()),
+                  "rbr_dedup_fold_rows")
         if need_conv:
             dtable, _, dWs, dbs = _textcnn_backward(S, d_pair, ctx.needs_input_grad[0], False)
         else:
             dtable, dWs, dbs = None, [None] * n_widths, [None] * n_widths
-        return (dtable, None, None, None, None, None, None, None, None, None, None, None, *dWs, *dbs, *grads)
+        return (dtable, None, None, None, None, None, None, None, None, None, None, None, None, *dWs, *dbs, *grads)
 
 
 def encode_head(table, ids, mask, u_id, i_id, conv_weights, conv_biases, head_params, *, id_sets=None, drop=None,
-                padding_idx=0, pad_u=0, pad_i=0):
+                padding_idx=0, pad_u=0, pad_i=0, first=None):
     """DeepCoNN++'s forward from token ids to predictions in one autograd function (see _EncodeHead).  ids / mask: the stacked
     [2B, L] towers (user rows first) -- or id_sets = [(u_docs, V, pad), (i_docs, V, pad), (u_ids, U, 0), (i_ids, I, 0)], the raw
     id tensors, whose range check then rides in the prepare stage's first launch (ids / u_id / i_id are ignored).
     head_params: (Wu, bu, Eu, Wi, bi, Ei, h, g, ub, ib).  drop: None, a [B, K] multiplier, or the dropout probability of a
-    training forward.  Inside `with fused_loss(target)` the MSE against target is computed by the head launch as well."""
+    training forward.  first [2B] (dedup_rows; `mask` then carries the blanked rows): document r's features are document
+    first[r]'s -- the in-batch dedup by id, inside the fused step.  Inside `with fused_loss(target)` the MSE against target is computed by the head launch as well."""
     req = _LOSS_REQUEST[-1] if _LOSS_REQUEST else None
     target = None
     if req is not None and req.loss is None and req.target.is_cuda and req.target.dtype == F32 and req.target.dim() == 1 \
@@ -982,7 +987,7 @@ def encode_head(table, ids, mask, u_id, i_id, conv_weights, conv_biases, head_pa
         if req.target.shape[0] == B:
             target = req.target
     pred, loss = _EncodeHead.apply(table, id_sets, ids, mask, u_id, i_id, drop, target, padding_idx, pad_u, pad_i,
-                                   len(conv_weights), *conv_weights, *conv_biases, *head_params)
+                                   len(conv_weights), first, *conv_weights, *conv_biases, *head_params)
     if target is not None:
         req.pred_ptr, req.loss = pred.data_ptr(), loss
     return pred

@@ -31,7 +31,7 @@ class DeepCoNNpp(nn.Module):
         self.validate_ids = True
 
     def _fused_ok(self, u_revs, i_revs) -> bool:
-        if self.dedup_by_id or self.ngram.arch != "CNN" or u_revs.shape != i_revs.shape or u_revs.dim() != 2:
+        if self.ngram.arch != "CNN" or u_revs.shape != i_revs.shape or u_revs.dim() != 2:
             return False
         conv = self.ngram.feature_layer[0]
         return RF.encode_head_applicable(self.word_embeddings.weight, 2 * u_revs.shape[0], u_revs.shape[1], conv.kernel_sizes,
@@ -57,15 +57,22 @@ class DeepCoNNpp(nn.Module):
                 drop = RF.dropout_multiplier((bz, fm.h.shape[0]), fm.dropout.p, fm.training, u_revs.device)
             head = (uf.W, uf.b, uf.ebd.weight, itf.W, itf.b, itf.ebd.weight, fm.h, fm.g_bias, fm.user_bias.weight, fm.item_bias.weight)
             masks = RF.stack_rows(u_rev_masks, i_rev_masks)
+            first = None
+            if self.dedup_by_id:
+                # first occurrence of every user / item id of the batch (two short launches, static shapes, no sync; ids outside
+                # their table count as unique): the repeated documents' masks are blanked -- the encoder skips them -- and the
+                # head launch reads the first occurrence's pooled features in their place
+                first, masks = RF.dedup_rows(u_ids, i_ids, self.user_size, self.item_size, masks, u_revs.shape[1])
             if self.validate_ids:
                 sets = [(u_revs, self.vocab_size, pad), (i_revs, self.vocab_size, pad), (u_ids, self.user_size, 0),
                         (i_ids, self.item_size, 0)]
                 preds = RF.encode_head(self.word_embeddings.weight, None, masks, None, None, conv.weights(), conv.biases(), head,
-                                       id_sets=sets, drop=drop, padding_idx=pad, pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)
+                                       id_sets=sets, drop=drop, padding_idx=pad, pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx,
+                                       first=first)
             else:
                 preds = RF.encode_head(self.word_embeddings.weight, RF.stack_rows(u_revs, i_revs), masks, u_ids, i_ids,
                                        conv.weights(), conv.biases(), head, drop=drop, padding_idx=pad,
-                                       pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx)
+                                       pad_u=fm.user_padding_idx, pad_i=fm.item_padding_idx, first=first)
             return preds.view(bz)
         if self.validate_ids:
             pad = self.word_embeddings.padding_idx

@@ -169,7 +169,15 @@ def test_dedup_by_id_matches_the_oracle_on_the_duplicated_batch(conv_mode):
         assert float((p.grad.cpu() - ref).abs().max()) <= 2e-6 + 2e-4 * scale, k
 
 
-def test_dedup_step_is_graph_capturable_and_skips_repeated_documents():
+@pytest.fixture
+def product_mode():
+    from review_based_recommender_amd import _lib
+    _lib.lib().rbr_set_conv_mode(2)          # the token-product formulation (and with it the fused step) also at the small shape
+    yield
+    _lib.lib().rbr_set_conv_mode(0)
+
+
+def test_dedup_step_is_graph_capturable_and_skips_repeated_documents(product_mode):
     """The first-occurrence pass is a device kernel with static shapes (no torch.unique, no host sync): the dedup step
     replays as a hipGraph on new batches, and the blanked repeated rows are the ones that are not first occurrences."""
     from review_based_recommender_amd import functional as RF
@@ -188,7 +196,11 @@ def test_dedup_step_is_graph_capturable_and_skips_repeated_documents():
     m_g.dedup_by_id = m_e.dedup_by_id = True
     m_g.train(); m_e.train()
     o_g, o_e = make_optimizer(m_g, hip_clip_adam=True), make_optimizer(m_e, hip_clip_adam=True)
-    stepper = GraphedTrainStep(m_g, o_g, args, ratings)
+    stepper = GraphedTrainStep(m_g, o_g, args, ratings, keep_graph=True)
+    n_launch = stepper.kernel_launches()
+    # the dedup rides the fused step now -- dedup_mark + dedup_apply + the gradient fold on top of the 14-15
+    # launches of the fused DeepCoNN step (it used to fall back to the un-fused ~25-launch step with a torch index_select)
+    assert n_launch is None or n_launch <= 19, n_launch
     for step in range(3):
         b2 = _dup_batch(cfg)
         perm = torch.randperm(B, generator=torch.Generator().manual_seed(step))      # another duplicate pattern every step
