@@ -497,6 +497,15 @@ int rbr_linear_fwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const 
 int rbr_linear_bwd_ex(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
                       int32_t relu, const float* drop, float* d_x, float* dW, float* db, float* ws, void* stream);
 
+/* ---- MyConv1d.forward (deepconn/layers.py:46-60; dup narre/layers.py:139-153) on materialised inputs: the contraction is an
+ *      rbr_linear_* product T [bz * L, sum kz*ch] = x @ Wprod^T (column (w, j, c) = poff[w] + j * ch[w] + c); these two calls are its
+ *      epilogue -- 'same' zero padding, the kz shifted adds, the bias and the channel concatenation, written in the reference's
+ *      N x C x L layout -- and the epilogue's backward (dT overwritten, dbias[w] [ch[w]] overwritten).  kz odd.              ---- */
+int rbr_conv_shift_add_fwd(int32_t bz, int32_t L, int32_t n_widths, const int32_t* kz, const int32_t* ch, const float* T,
+                           const float* const* bias, float* out, void* stream);
+int rbr_conv_shift_add_bwd(int32_t bz, int32_t L, int32_t n_widths, const int32_t* kz, const int32_t* ch, const float* d_out,
+                           float* dT, float* const* dbias, void* stream);
+
 /* ---- standalone word-embedding row gather / scatter-add (WordEmbedding.forward, deepconn/layers.py:22-24).
  *      The models never call these (the gather is fused into the conv kernel); they serve callers that
  *      want the materialised rows.  out [n_tok, D];  dtable ACCUMULATED, row pad_idx excluded.   ---- */

@@ -201,6 +201,8 @@ SIGNATURES = {
     "rbr_linear_fwd_ex": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_stream]),
     "rbr_linear_bwd_ex": (C.c_int, [i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p,
                                     c_f32p, c_stream]),
+    "rbr_conv_shift_add_fwd": (C.c_int, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), c_f32p, _PP, c_f32p, c_stream]),
+    "rbr_conv_shift_add_bwd": (C.c_int, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), c_f32p, c_f32p, _PP, c_stream]),
     "rbr_sanitize_ids": (C.c_int, [i32, C.POINTER(IdSet), C.c_void_p, c_stream]),
     "rbr_dedup_ws_bytes": (C.c_size_t, [i32, i32]),
     "rbr_dedup_rows": (C.c_int, [i32, i32, c_i64p, c_i64p, i32, i32, c_u8p, C.c_void_p, c_i64p, c_u8p, c_stream]),

@@ -579,6 +579,109 @@ extern "C" int rbr_dedup_rows(int32_t B, int32_t L, const int64_t* u_ids, const 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ MyConv1d.forward's epilogue
+// The layer-level conv (deepconn/layers.py:46-60: per width Conv1d(padding = (kz-1)/2), cat on the channel dim) as a product +
+// shifted adds: T[(b, n), (w, j, c)] = <x[b, :, n], W_w[c, :, j]> comes from the GEMM, and
+//     out[b, ch_off[w] + c, l] = bias_w[c] + sum_j T[(b, l + j - pad_w), (w, j, c)]      (rows outside the document are zero)
+// in the reference's N x C x L layout -- one launch instead of a pad, kz adds, a cat and a transpose per width.  Backward:
+// dT[(b, n), (w, j, c)] = d_out[b, ch_off[w] + c, n - j + pad_w] (0 outside), dbias_w[c] = sum_{b, l} d_out (fixed order).
+namespace rbr {
+struct ShiftAdd {
+    int bz, L, n_widths, C, cp;
+    int kz[RBR_MAX_WIDTHS], ch[RBR_MAX_WIDTHS], ch_off[RBR_MAX_WIDTHS], poff[RBR_MAX_WIDTHS];
+};
+__device__ __forceinline__ int shift_bank(const ShiftAdd& S, int c) {
+    int w = 0;
+#pragma unroll
+    for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+        if (k < S.n_widths && c >= S.ch_off[k]) w = k;
+    return w;
+}
+__global__ __launch_bounds__(256) void conv_shift_add_fwd_kernel(const ShiftAdd S, const float* __restrict__ T, const PtrArray bias,
+                                                                 float* __restrict__ out) {
+    const long n = (long)S.bz * S.C * S.L;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int l = (int)(e % S.L);
+        const int c = (int)((e / S.L) % S.C), b = (int)(e / ((long)S.L * S.C));
+        const int w = shift_bank(S, c), cl = c - S.ch_off[w], kz = S.kz[w], pad = (kz - 1) / 2;
+        float acc = bias.p[w][cl];
+        for (int j = 0; j < kz; ++j) {
+            const int row = l + j - pad;
+            if (row >= 0 && row < S.L) acc += T[((long)b * S.L + row) * S.cp + S.poff[w] + j * S.ch[w] + cl];
+        }
+        out[e] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void conv_shift_add_bwd_kernel(const ShiftAdd S, const float* __restrict__ d_out, float* __restrict__ dT) {
+    const long n = (long)S.bz * S.L * S.cp;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int pc = (int)(e % S.cp);
+        const int row = (int)((e / S.cp) % S.L), b = (int)(e / ((long)S.cp * S.L));
+        int w = 0;
+#pragma unroll
+        for (int k = 1; k < RBR_MAX_WIDTHS; ++k)
+            if (k < S.n_widths && pc >= S.poff[k]) w = k;
+        const int rel = pc - S.poff[w], j = rel / S.ch[w], cl = rel - j * S.ch[w];
+        const int l = row - j + (S.kz[w] - 1) / 2;
+        dT[e] = (l >= 0 && l < S.L) ? d_out[((long)b * S.C + S.ch_off[w] + cl) * S.L + l] : 0.f;
+    }
+}
+// dbias[c] = sum over (b, l) of d_out[b, c, l]: one workgroup per channel, fixed order
+__global__ __launch_bounds__(256) void conv_shift_add_dbias_kernel(const ShiftAdd S, const float* __restrict__ d_out, const MutPtrArray dbias) {
+    __shared__ float s_red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (long k = threadIdx.x; k < (long)S.bz * S.L; k += 256) {
+        const int b = (int)(k / S.L), l = (int)(k - (long)b * S.L);
+        acc += d_out[((long)b * S.C + c) * S.L + l];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int w = shift_bank(S, c);
+        dbias.p[w][c - S.ch_off[w]] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+static bool shift_add_job(int32_t bz, int32_t L, int32_t n_widths, const int32_t* kz, const int32_t* ch, ShiftAdd& S) {
+    if (bz <= 0 || L <= 0 || n_widths <= 0 || n_widths > RBR_MAX_WIDTHS || !kz || !ch || (long)bz * L >= (1L << 31)) return false;
+    memset(&S, 0, sizeof(S));
+    S.bz = bz; S.L = L; S.n_widths = n_widths;
+    for (int w = 0; w < n_widths; ++w) {
+        if (kz[w] <= 0 || kz[w] % 2 == 0 || kz[w] > kMaxKF || ch[w] <= 0 || ch[w] > kMaxChannels) return false;
+        S.kz[w] = kz[w]; S.ch[w] = ch[w]; S.ch_off[w] = S.C; S.poff[w] = S.cp;
+        S.C += ch[w]; S.cp += kz[w] * ch[w];
+    }
+    return S.C <= kMaxChannels;
+}
+}  // namespace rbr
+
+extern "C" int rbr_conv_shift_add_fwd(int32_t bz, int32_t L, int32_t n_widths, const int32_t* kz, const int32_t* ch, const float* T,
+                                      const float* const* bias, float* out, void* stream) {
+    rbr::ShiftAdd S;
+    if (!rbr::shift_add_job(bz, L, n_widths, kz, ch, S) || !T || !bias || !out) { rbr::set_error("rbr_conv_shift_add_fwd: bad argument"); return RBR_ERR_BAD_ARG; }
+    rbr::PtrArray bp{};
+    for (int w = 0; w < n_widths; ++w) { if (!bias[w]) { rbr::set_error("null bias"); return RBR_ERR_BAD_ARG; } bp.p[w] = bias[w]; }
+    const long n = (long)bz * S.C * L;
+    hipLaunchKernelGGL(rbr::conv_shift_add_fwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, S, T, bp, out);
+    RBR_CHECK_LAUNCH("conv shift-add fwd launch");
+    return 0;
+}
+extern "C" int rbr_conv_shift_add_bwd(int32_t bz, int32_t L, int32_t n_widths, const int32_t* kz, const int32_t* ch, const float* d_out,
+                                      float* dT, float* const* dbias, void* stream) {
+    rbr::ShiftAdd S;
+    if (!rbr::shift_add_job(bz, L, n_widths, kz, ch, S) || !d_out || !dT || !dbias) { rbr::set_error("rbr_conv_shift_add_bwd: bad argument"); return RBR_ERR_BAD_ARG; }
+    rbr::MutPtrArray dbp{};
+    for (int w = 0; w < n_widths; ++w) { if (!dbias[w]) { rbr::set_error("null dbias"); return RBR_ERR_BAD_ARG; } dbp.p[w] = dbias[w]; }
+    const long n = (long)bz * L * S.cp;
+    hipLaunchKernelGGL(rbr::conv_shift_add_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, S, d_out, dT);
+    RBR_CHECK_LAUNCH("conv shift-add bwd launch");
+    hipLaunchKernelGGL(rbr::conv_shift_add_dbias_kernel, dim3(S.C), dim3(256), 0, (hipStream_t)stream, S, d_out, dbp);
+    RBR_CHECK_LAUNCH("conv shift-add dbias launch");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ dropout multiplier
 // out[i] = 0 with probability p, else 1/(1-p): the multiplier nn.Dropout / F.dropout applies (deepconn/layers.py:202,
 // narre.py:73, dual_att.py:33).  Philox4x32-10 keyed by `seed`, counter = (element quad, call number); the call number

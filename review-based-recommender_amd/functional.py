@@ -1337,6 +1337,42 @@ def linear(x, W, b=None, *, relu=False, drop=None, tanh=False):
     return _Linear.apply(x, W, b, 2 if tanh else int(bool(relu)), drop)
 
 
+class _ConvShiftAdd(torch.autograd.Function):
+    """out [bz, C, L] = bias + the kz shifted adds of the product T [bz * L, sum kz*ch]  -- rbr_conv_shift_add_* in rbr_hip.h."""
+
+    @staticmethod
+    def forward(ctx, t, bz, L, kernel_sizes, channels, *biases):
+        t = t.contiguous()
+        bs = [b.contiguous() for b in biases]
+        n = len(kernel_sizes)
+        kz = (C.c_int32 * n)(*[int(k) for k in kernel_sizes])
+        ch = (C.c_int32 * n)(*[int(c) for c in channels])
+        out = torch.empty(bz, sum(channels), L, dtype=F32, device=t.device)
+        check(_lib.lib().rbr_conv_shift_add_fwd(bz, L, n, kz, ch, dev_ptr(t, F32, "T"), ptr_array(bs, F32, "bias"), dev_ptr(out, F32, "out"),
+                                                current_stream()), "rbr_conv_shift_add_fwd")
+        ctx.job = (bz, L, tuple(kernel_sizes), tuple(channels), tuple(t.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        bz, L, kernel_sizes, channels, tshape = ctx.job
+        n = len(kernel_sizes)
+        kz = (C.c_int32 * n)(*kernel_sizes)
+        ch = (C.c_int32 * n)(*channels)
+        d_out = d_out.contiguous()
+        dT = torch.empty(tshape, dtype=F32, device=d_out.device)
+        dbs = [torch.empty(c, dtype=F32, device=d_out.device) for c in channels]
+        check(_lib.lib().rbr_conv_shift_add_bwd(bz, L, n, kz, ch, dev_ptr(d_out, F32, "d_out"), dev_ptr(dT, F32, "dT"),
+                                                ptr_array(dbs, F32, "dbias"), current_stream()), "rbr_conv_shift_add_bwd")
+        return (dT, None, None, None, None, *dbs)
+
+
+def conv_shift_add(t, bz, L, kernel_sizes, channels, biases):
+    """MyConv1d.forward's epilogue (deepconn/layers.py:46-60): 'same' padding, shifted adds, bias, channel cat, N x C x L layout --
+    one launch.  t [bz * L, sum kz*ch] is the layer's product (functional.linear); returns [bz, sum ch, L]."""
+    return _ConvShiftAdd.apply(t, bz, L, kernel_sizes, channels, *biases)
+
+
 # --------------------------------------------------------------------------- SimpleSiamese encoder (SURVEY.md 8 f-4)
 class _ReviewBag(torch.autograd.Function):
     """out[n_rev, D] = drop * masked mean of table[ids]  -- rbr_review_bag_* in rbr_hip.h."""

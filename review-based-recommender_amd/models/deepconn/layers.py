@@ -76,21 +76,14 @@ class MyConv1d(nn.Module):
         every width zero-padded 'same', channels width-major.  The models never call this (their conv is fused with the
         gather and the max-pool and never materialises a [bz, C, L] activation); it serves callers of the layer itself.
         The contraction runs on the HIP GEMM (functional.linear, forward and backward): T[n, (w, j, c)] = <x[n, :], W_w[c, :, j]>
-        for every position n, then out[b, l, c] = bias[c] + sum_j T[(b, l + j - pad_w), (w, j, c)] as kz shifted adds."""
+        for every position n, then out[b, c, l] = bias[c] + sum_j T[(b, l + j - pad_w), (w, j, c)] (rbr_conv_shift_add_*).  What is
+        left to torch is re-layout only: the N x C x L input as rows, and the weights as one [sum kz*ch, D] matrix."""
         bz, cin, L = inputs.shape
         x = inputs.transpose(1, 2).reshape(bz * L, cin)                       # one row per position
         wp = torch.cat([c.weight.permute(2, 0, 1).reshape(-1, cin) for c in self.list_of_conv1d], dim=0)   # [(w, j, c), D]
-        t = RF.linear(x, wp, None).view(bz, L, -1)
-        outs, o = [], 0
-        for conv, kz in zip(self.list_of_conv1d, self.kernel_sizes):
-            ch, pad = conv.weight.shape[0], (kz - 1) // 2
-            tw = torch.nn.functional.pad(t[:, :, o:o + kz * ch].reshape(bz, L, kz, ch), (0, 0, 0, 0, pad, pad))   # zero rows outside the doc
-            acc = conv.bias.view(1, 1, ch)
-            for j in range(kz):
-                acc = acc + tw[:, j:j + L, j, :]
-            outs.append(acc)
-            o += kz * ch
-        return torch.cat(outs, dim=2).transpose(1, 2).contiguous()            # [bz, out_features, seq_len]
+        t = RF.linear(x, wp, None)                                            # [bz * L, sum kz * ch] on the HIP GEMM
+        # padding, the kz shifted adds, bias and the channel cat in the N x C x L layout: one HIP launch (forward) / two (backward)
+        return RF.conv_shift_add(t, bz, L, self.kernel_sizes, [c.weight.shape[0] for c in self.list_of_conv1d], self.biases())
 
 
 class HierPooling(nn.Module):
