@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librbr_hip.so")
+# RBR_LIB_PATH: another build of the same library (dev: A/B measurements of two builds in one gpurun call, tools/gpu_ab2.sh)
+LIB_PATH = os.environ.get("RBR_LIB_PATH") or os.path.join(HERE, "csrc", "librbr_hip.so")
 
 RBR_MAX_WIDTHS = 8
 PAD_SAME, PAD_VALID = 0, 1

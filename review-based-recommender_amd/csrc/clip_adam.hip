@@ -58,6 +58,17 @@ __device__ __forceinline__ AdamK adam_constants(float coef, float lr, float beta
     return AdamK{coef, 1.f - beta1, beta2, 1.f - beta2, lr / bc1, bc2_sqrt, eps};
 }
 
+// Adam's moments are touched once per step and by nobody else: streamed past the caches (nontemporal), so that they do not evict
+// what the next step's forward wants to find (the parameters -- read again by the forward -- keep ordinary accesses)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* base, int i) {
+    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(base) + i);
+    return float4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void nt_store4(float* base, int i, const float4& x) {
+    __builtin_nontemporal_store(f32x4_nt{x.x, x.y, x.z, x.w}, reinterpret_cast<f32x4_nt*>(base) + i);
+}
+
 __device__ __forceinline__ int tensor_of_chunk(const OptTable& T, long chunk) {
     int k = 0;
     for (int i = 1; i < T.count; ++i)        // <= 64 tensors: a short scalar scan
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = threadIdx.x + 256 * u;
-                M[u] = reinterpret_cast<float4*>(m)[i]; V[u] = reinterpret_cast<float4*>(v)[i]; P[u] = reinterpret_cast<float4*>(p)[i];
+                M[u] = nt_load4(m, i); V[u] = nt_load4(v, i); P[u] = reinterpret_cast<float4*>(p)[i];
             }
             int rl[U];
             unsigned ofs[U];
@@ -190,8 +201,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
                 RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
                 RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
                 if (clipped && rl[u] >= 0) *reinterpret_cast<float4*>(T.grows + (long)rl[u] * D + ofs[u]) = G[u];
-                reinterpret_cast<float4*>(m)[i] = M[u];
-                reinterpret_cast<float4*>(v)[i] = V[u];
+                nt_store4(m, i, M[u]);
+                nt_store4(v, i, V[u]);
                 reinterpret_cast<float4*>(p)[i] = P[u];
             }
             continue;
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = threadIdx.x + 256 * u;
-                G[u] = reinterpret_cast<float4*>(g)[i]; M[u] = reinterpret_cast<float4*>(m)[i];
-                V[u] = reinterpret_cast<float4*>(v)[i]; P[u] = reinterpret_cast<float4*>(p)[i];
+                G[u] = reinterpret_cast<float4*>(g)[i]; M[u] = nt_load4(m, i);
+                V[u] = nt_load4(v, i); P[u] = reinterpret_cast<float4*>(p)[i];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -232,8 +243,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const OptTable T, long n
                 RBR_ADAM1(G[u], M[u], V[u], P[u], x) RBR_ADAM1(G[u], M[u], V[u], P[u], y)
                 RBR_ADAM1(G[u], M[u], V[u], P[u], z) RBR_ADAM1(G[u], M[u], V[u], P[u], w)
                 if (clipped) reinterpret_cast<float4*>(g)[i] = G[u];
-                reinterpret_cast<float4*>(m)[i] = M[u];
-                reinterpret_cast<float4*>(v)[i] = V[u];
+                nt_store4(m, i, M[u]);
+                nt_store4(v, i, V[u]);
                 reinterpret_cast<float4*>(p)[i] = P[u];
             }
             continue;

@@ -218,29 +218,36 @@ __device__ __forceinline__ void gather_pool_kernel(const ConvPlan& P, const Prod
         s_gate_b[wave][r] = gvb;
     }
     __builtin_amdgcn_wave_barrier();
-    const int ps = lane >> 4, ql = lane & 15;
     const float NEG = -__builtin_huge_valf();
     for (int w = 0; w < P.n_widths; ++w) {
         const int kz = P.kz[w], ch = P.ch[w];
         const int off = (P.pad_mode == RBR_PAD_SAME) ? (P.KF - kz) / 2 : 0;      // frame tap of the bank's tap 0
         const int Lv = (P.pad_mode == RBR_PAD_VALID) ? (L - kz + 1) : L;          // pool length of this bank
         const int nquads = (ch + 3) >> 2;
+        // Lanes per position = the bank's quads rounded up to 16 / 32 / 64 (wave-uniform), so that ONE load instruction covers a
+        // (row, tap) segment of the bank whole whenever it can: with a fixed 16 quads (256 bytes) per pass, a 100-channel bank's
+        // 400-byte segments were fetched as a 256-byte and a 144-byte window in two passes -- each window rounded out to whole
+        // 128-byte lines, 1.5x the segment's bytes in L2 requests (D-ATT cfg4: 2.34 GB of requests for 1.44 GB of segments);
+        // a 50-channel bank (cfg2: 13 quads) always was one window.
+        const int lq = nquads <= 16 ? 4 : (nquads <= 32 ? 5 : 6);               // log2(lanes per position)
+        const int QL = 1 << lq, PS = 64 >> lq;                                  // quads per pass, position classes
+        const int ps = lane >> lq, ql = lane & (QL - 1);
         const float* sg = (P.gate_split > 0 && w >= P.gate_split) ? s_gate_b[wave] : s_gate[wave];     // wave-uniform
-        for (int qb = 0; qb < nquads; qb += 16) {
+        for (int qb = 0; qb < nquads; qb += QL) {
             const int q = qb + ql;
             const bool valid = q < nquads;
             const float* tcol = T + A.poff[w] + 4 * (valid ? q : 0);
             const unsigned short* tcol16 = T16 + A.poff[w] + 4 * (valid ? q : 0);
             float best[4] = {NEG, NEG, NEG, NEG};
             int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-            for (int p0 = 0; p0 < kTile; p0 += 8) {                       // two positions per lane and round:
+            for (int p0 = 0; p0 < kTile; p0 += 2 * PS) {                  // two positions per lane and round:
                 f32x4 y[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // 2 * kz independent float4 loads in flight
 #pragma unroll
                 for (int j = 0; j < kMaxKF; ++j) {
                     if (j < kz) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const int r = p0 + 4 * u + ps + j + off;
+                            const int r = p0 + PS * u + ps + j + off;
                             f32x4 v;
                             if (TB16) {
                                 const u32x2u b = *reinterpret_cast<const u32x2u*>(tcol16 + (long)s_row[wave][r] * A.pitch + j * ch);
@@ -257,7 +264,7 @@ __device__ __forceinline__ void gather_pool_kernel(const ConvPlan& P, const Prod
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int pos = l0 + p0 + 4 * u + ps;
+                    const int pos = l0 + p0 + PS * u + ps;
                     if (pos < Lv) {                                       // ascending positions per lane: '>' keeps the first max
                         if (y[u].x > best[0]) { best[0] = y[u].x; bidx[0] = pos; }
                         if (y[u].y > best[1]) { best[1] = y[u].y; bidx[1] = pos; }
@@ -267,9 +274,8 @@ __device__ __forceinline__ void gather_pool_kernel(const ConvPlan& P, const Prod
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {                                 // meet the four position classes
-#pragma unroll
-                for (int o = 16; o < 64; o <<= 1) {
+            for (int c = 0; c < 4; ++c) {                                 // meet the position classes
+                for (int o = QL; o < 64; o <<= 1) {
                     const float ob = __shfl_xor(best[c], o);
                     const int oi = __shfl_xor(bidx[c], o);
                     if (ob > best[c] || (ob == best[c] && oi < bidx[c])) { best[c] = ob; bidx[c] = oi; }
