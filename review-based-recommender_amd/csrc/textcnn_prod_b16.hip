@@ -371,6 +371,159 @@ __device__ __forceinline__ void prod_gemm_b16d_kernel(const B16Gemm& g) {
     }
 }
 
+// ---------------------------------------------------------------------------------- rows stationary (short K)
+// The same GEMM for a SHORT contraction (D <= 128: D-ATT's 100-wide embeddings are 7 steps).  With so few steps the kernels
+// above spend as long filling their ring and storing their tile as multiplying: a 128 x 128 item is ~9 us of which 4.5 are the
+// K loop (D-ATT cfg4: 2 088 items in five rounds, 69 us for 18 us of MFMA time).  Here a workgroup keeps its 128 token rows --
+// every K step of them, split into planes ONCE -- in registers (12 VGPRs per step) and walks the column groups with them: the
+// weight fragments stream through the same 4-stage LDS ring without a break from one group to the next, and a finished group's
+// tiles are stored while the next group's fills and MFMAs are already under way.
+// The accumulators are held TRANSPOSED (weights as the MFMA's A operand, token rows as B: the hardware's k order is the same,
+// so the bits are those of the kernels above): a lane then owns 4 adjacent columns of one token row per register quad and a tile
+// leaves as 4 dwordx4 stores instead of 16 dword stores -- 16 store instructions per group and wave, which keeps the counted
+// vmcnt waits of the fill pipeline (6 bits: at most 63) exact across the group boundary: in the first three stages of a group
+// the previous group's 16 stores are younger than the stage's own fills and are allowed for.  A workgroup whose row block is cut
+// by the end of the list (its stores are predicated, their count is not known) waits for everything instead.
+// Grid: row blocks x up to kB16kSplit column splits; the kernel uses as many splits as give ~one resident round (512 slots).
+// D-ATT cfg4 (29.7 k rows x 100 x 1 152 columns, 464 workgroups of 4 or 5 groups): 54 us against the ring kernel's 69.
+constexpr int kB16kSplit = 4;
+constexpr int kB16kPitch = 144;                                // bytes per staging row (128 + 16: the rows start 4 banks apart)
+constexpr int kB16kLds = kB16Stages * kB16BBytes + kB16Waves * 32 * kB16kPitch;
+
+template <int NPROD, int NCH>
+__device__ __forceinline__ void prod_gemm_b16k_kernel(const B16Gemm& g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int NPLANES = NPROD == 6 ? 3 : NPROD == 3 ? 2 : 1;
+    constexpr int S = kB16Stages;
+    const int n = min(*g.counter, g.cap);
+    const int smax = min(kB16kSplit, g.ngroups);
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    // the split is the SLOW index of the grid: the workgroups that have nothing to do (splits not used for this n, row blocks
+    // past the list) then sit in long runs.  With the split as the fast index every other pair of consecutive workgroups left at
+    // once, the dispatcher's round robin over the shader engines gave the real ones to two engines of four, and the kernel ran
+    // in two rounds on half the CUs (105 us; seen in per-workgroup s_memtime stamps and HW_ID)
+    const int nb8 = (int)(gridDim.x >> 3) / smax;              // octets of row blocks
+    const int mblock = (jj % nb8) * 8 + xcd, sp = jj / nb8;
+    const int m0 = mblock * kB16BM;
+    if (m0 >= n) return;
+    const int nsplit = max(1, min(smax, 512 / ((n + kB16BM - 1) / kB16BM)));
+    if (sp >= nsplit) return;
+    const int g0 = (g.ngroups * sp) / nsplit, g1 = (g.ngroups * (sp + 1)) / nsplit;
+    const int nst = (g1 - g0) * NCH;                           // stages of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = g.D;
+    unsigned char* const Bbuf = smem;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int row = m0 + wave * 32 + r32;
+    const bool full = m0 + kB16BM <= n;                        // workgroup-uniform
+    const unsigned char* const bsrc = g.bimg + ((size_t)g0 * NCH) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
+    auto issue_b = [&](int s) {                                // ALWAYS three fills (source clamped past the end, slot unused)
+        const int ss = min(s, nst - 1);
+        unsigned char* B = Bbuf + (s & (S - 1)) * kB16BBytes + wave * 3 * kB16BFrag;
+        const unsigned char* s_ = bsrc + (size_t)ss * kB16BBytes;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) b16_dma16(s_ + t * kB16BFrag, B + t * kB16BFrag);
+    };
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue_b(s);
+    // the rows: every step's 8 floats of this lane, requested together, split once
+    bf16x8 a_hi[NCH], a_mid[NCH], a_lo[NCH];
+    {
+        const float* const arow = (row < n) ? g.table + (g.tok_of_row != nullptr ? g.tok_of_row[row] : (long long)row) * (long)D + 8 * h : nullptr;
+        f32x4 x0[NCH], x1[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * kB16KC + 8 * h;
+            const float* s0 = (arow != nullptr && col + 4 <= D) ? arow + c * kB16KC : g_b16_zero;
+            const float* s1 = (arow != nullptr && col + 8 <= D) ? arow + c * kB16KC + 4 : g_b16_zero;
+            x0[c] = *reinterpret_cast<const f32x4*>(s0);
+            x1[c] = *reinterpret_cast<const f32x4*>(s1);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            unsigned h4[4], m4[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0};
+            split_pair<NPLANES>(x0[c].x, x0[c].y, h4[0], m4[0], l4[0]);
+            split_pair<NPLANES>(x0[c].z, x0[c].w, h4[1], m4[1], l4[1]);
+            split_pair<NPLANES>(x1[c].x, x1[c].y, h4[2], m4[2], l4[2]);
+            split_pair<NPLANES>(x1[c].z, x1[c].w, h4[3], m4[3], l4[3]);
+            const u32x4 ah = {h4[0], h4[1], h4[2], h4[3]}, am = {m4[0], m4[1], m4[2], m4[3]}, al = {l4[0], l4[1], l4[2], l4[3]};
+            a_hi[c] = __builtin_bit_cast(bf16x8, ah);
+            a_mid[c] = a_lo[c] = a_hi[c];
+            if (NPLANES >= 2) a_mid[c] = __builtin_bit_cast(bf16x8, am);
+            if (NPLANES >= 3) a_lo[c] = __builtin_bit_cast(bf16x8, al);
+        }
+    }
+    // (the split needed the rows, the rows were requested after the first three stages' fills and memory returns in order:
+    // stages 0 .. 2 have landed for this wave)
+    f32x16 acc[4];
+    unsigned char* const stg = smem + S * kB16BBytes + wave * (32 * kB16kPitch);      // this wave's 32 staging rows
+    unsigned char* const stg_w = stg + r32 * kB16kPitch + 16 * h;                       // + 32 q: quad q of row (lane & 31)
+    const unsigned char* const stg_r = stg + (lane >> 3) * kB16kPitch + (lane & 7) * 16;  // + 8 i rows: 16 bytes of row 8 i + lane / 8
+    const int orow0 = m0 + wave * 32 + (lane >> 3);
+    float* const otile = g.T + (size_t)orow0 * g.pitch + (lane & 7) * 4;
+    for (int gi = 0; gi < g1 - g0; ++gi) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int s = gi * NCH + c;
+            // stage s has landed once only what was issued after its fills is outstanding: the fills of stages s + 1 and s + 2,
+            // and -- in the first three stages of a group but the first -- the 16 stores of the previous group
+            if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (c < 3 && gi > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // the stage landed for every wave; every wave is done with stage s - 1
+            asm volatile("" ::: "memory");
+            const unsigned char* B = Bbuf + (s & (S - 1)) * kB16BBytes + lane * 16;
+            // (Measured and dropped: every tile's fragments requested ahead of the previous tile's MFMA chain, the order pinned
+            // with sched_group_barrier -- 202 registers, the same 54-55 us.  Per-workgroup s_memtime stamps: ~2.5 k cycles per
+            // stage with two workgroups on the CU (1 536 of them MFMA issue), ~2.9 k with one; neither the fills' latency --
+            // vmcnt(0) in every stage costs 1 us -- nor the stores -- without them 48 us -- nor the fragment reads' latency.)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned char* bf = B + (t * 3) * kB16BFrag;
+                const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(bf);
+                if (NPROD == 6) {       // small terms first, as above
+                    const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+                    const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(bf + 2 * kB16BFrag);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_lo[c], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo, a_hi[c], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_mid, a_mid[c], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_mid[c], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_mid, a_hi[c], acc[t], 0, 0, 0);
+                } else if (NPROD == 3) {
+                    const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(bf + kB16BFrag);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_mid[c], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_mid, a_hi[c], acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi, a_hi[c], acc[t], 0, 0, 0);
+                if (t == 0) issue_b(s + S - 1);                // into the slot stage s - 1 has just left
+            }
+        }
+        // transposed C/D map: register quad q of tile t = columns t*32 + 8q + 4h .. +3 of token row (lane & 31).  Stored as it
+        // lies, a dwordx4 store would be 64 separate 16-byte writes (105 us at cfg4 against the ring kernel's 69): the tile goes
+        // through this wave's staging rows in LDS (144-byte pitch) and leaves row-major, 8 whole 128-byte lines per instruction
+        float* out = otile + (size_t)(g0 + gi) * kB16BN;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(stg_w + 32 * q) = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg_r + i * 8 * kB16kPitch);
+                if (full || orow0 + 8 * i < n) *reinterpret_cast<f32x4*>(out + (size_t)(8 * i) * g.pitch + t * 32) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the surplus fills have drained before the LDS is released
+}
+
 // ---------------------------------------------------------------------------------- bf16 storage form (RBR_PROD_BF16)
 // The reduced-precision class as BASELINE configs 3 and 5 name it: not only the MFMA operands but the byte streams are bf16.
 //   rows_to_b16   : the distinct tokens' table rows, rounded once, as a compact [list rows][Dp] bf16 array (zero-padded to a
@@ -741,6 +894,20 @@ int prod_b16_gemm(const rbr_textcnn_desc* d, int cp_real, int cap, int pitch, co
     // once) and a K of at least 12 steps.  NARRE cfg3 (4 groups: 314 workgroups) 36.5 us against 32.0, D-ATT's merged conv (9
     // groups but K = 100: 7 steps) 61 against 58 -- those keep the kernel above.
     static const bool direct_ok = getenv("RBR_GEMM_ROWS_IN_LDS") == nullptr || atoi(getenv("RBR_GEMM_ROWS_IN_LDS")) == 0;
+    // Short contractions (D <= 128) with at least four column groups: the rows-stationary kernel (D-ATT's merged conv: 9 groups
+    // x 7 steps).  RBR_GEMM_ROWS_STATIONARY=0: the ring kernel below.
+    static const bool stationary_ok = getenv("RBR_GEMM_ROWS_STATIONARY") == nullptr || atoi(getenv("RBR_GEMM_ROWS_STATIONARY")) != 0;
+    if (stationary_ok && g.nchunks >= 4 && g.nchunks <= 8 && g.ngroups >= 4 && prod_precision_of(d) == RBR_PROD_BF16X3) {
+        const dim3 grid_k((unsigned)(mblocks * std::min(kB16kSplit, g.ngroups)));
+        constexpr int kLdsK = kB16kLds;
+        switch (g.nchunks) {
+            case 4: return rbr::launch<prod_gemm_b16k_kernel<6, 4>, kB16Threads, 2>(grid_k, block, kLdsK, st, "textcnn prod_gemm_b16k launch", g);
+            case 5: return rbr::launch<prod_gemm_b16k_kernel<6, 5>, kB16Threads, 2>(grid_k, block, kLdsK, st, "textcnn prod_gemm_b16k launch", g);
+            case 6: return rbr::launch<prod_gemm_b16k_kernel<6, 6>, kB16Threads, 2>(grid_k, block, kLdsK, st, "textcnn prod_gemm_b16k launch", g);
+            case 7: return rbr::launch<prod_gemm_b16k_kernel<6, 7>, kB16Threads, 2>(grid_k, block, kLdsK, st, "textcnn prod_gemm_b16k launch", g);
+            default: return rbr::launch<prod_gemm_b16k_kernel<6, 8>, kB16Threads, 2>(grid_k, block, kLdsK, st, "textcnn prod_gemm_b16k launch", g);
+        }
+    }
     if (direct_ok && g.ngroups >= 6 && g.nchunks >= 12) {
         const dim3 grid_d((unsigned)(mblocks * ((g.ngroups + 1) / 2)));
         switch (prod_precision_of(d)) {

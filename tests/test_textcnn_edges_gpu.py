@@ -68,6 +68,13 @@ def _case(n_docs, L, D, V, kzs, chans, seed, mask_p=0.2, gate=False, valid=False
     dict(n_docs=3, L=48, D=24, V=50, kzs=[3, 5], chans=[6, 6], mask_p=None),            # mask == NULL
     dict(n_docs=3, L=30, D=104, V=60, kzs=[2, 3, 4], chans=[20, 20, 20], mask_p=None, gate=True, valid=True, tanh=True),
     dict(n_docs=2, L=37, D=60, V=60, kzs=[1], chans=[70], mask_p=None, gate=True, tanh=True),   # D-ATT local conv shape
+    # short contractions with >= 4 column groups: the rows-stationary GEMM (prod_gemm_b16k_kernel), 4 .. 8 K steps, row blocks
+    # that are whole (counted waits across the group boundary) and cut by the end of the token list
+    dict(n_docs=6, L=200, D=100, V=300, kzs=[2, 3, 4], chans=[100, 100, 100], mask_p=None, gate=True, valid=True, tanh=True),
+    dict(n_docs=8, L=160, D=64, V=200, kzs=[3, 5], chans=[64, 64]),
+    dict(n_docs=8, L=160, D=72, V=131, kzs=[3, 5], chans=[64, 64]),
+    dict(n_docs=8, L=160, D=88, V=257, kzs=[1, 3, 5], chans=[70, 64, 64], mask_p=None),
+    dict(n_docs=8, L=256, D=128, V=600, kzs=[3, 5, 7], chans=[40, 40, 40]),
 ])
 def test_textcnn_edge_shapes(shape, conv_mode):
     _case(seed=11, **shape)
@@ -276,3 +283,33 @@ def test_split_gate_conv_equals_the_two_gated_convs(runs):
                            act=RF.ACT_TANH, padding_idx=0)
     finally:
         _lib.lib().rbr_set_conv_mode(0)
+
+
+def test_rows_stationary_gemm_gives_the_ring_kernels_bits(tmp_path):
+    """prod_gemm_b16k_kernel (token rows stationary in registers, transposed accumulators) against prod_gemm_b16_kernel (the
+    4-stage ring) on the same input: the same plane products into the same accumulators in the same order, so the pooled
+    features must agree bit for bit.  The switch is read once per process: two child processes."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from review_based_recommender_amd import functional as RF, _lib\n"
+        "_lib.lib().rbr_set_conv_mode(2)\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "V, D, n_docs, L = 700, 100, 16, 256\n"
+        "table = torch.randn(V, D, generator=g).cuda()\n"
+        "ids = torch.randint(0, V, (n_docs, L), generator=g).cuda()\n"
+        "ws = [(torch.randn(c, D, k, generator=g) * 0.05).cuda() for k, c in ((1, 200), (2, 100), (3, 100), (4, 100))]\n"
+        "bs = [torch.zeros(w.shape[0]).cuda() for w in ws]\n"
+        "out = RF.textcnn(table, ids, None, ws, bs, pad_mode=RF.PAD_VALID, act=RF.ACT_TANH, padding_idx=None)\n"
+        "np.save(sys.argv[1], out.cpu().numpy())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for flag in ("1", "0"):
+        path = str(tmp_path / ("feat%s.npy" % flag))
+        env = dict(os.environ, RBR_GEMM_ROWS_STATIONARY=flag)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        outs.append(np.load(path))
+    assert outs[0].shape == (16, 500) and np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1])
