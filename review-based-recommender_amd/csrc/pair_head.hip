@@ -272,7 +272,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int K, cons
                                                        float* __restrict__ d_uf, float* __restrict__ d_if) {
     // (Measured and dropped in round 3: clearing the conv backward's G with extra workgroups of this launch instead of the
     // zero_g_rows launch -- the step got 19 us SLOWER: the weight-gradient branch then starts beside the L2-bound sparse product
-    // instead of beside the zero fill and the atomics-bound G build, and both crawl.)
+    // instead of beside the zero fill and the atomics-bound G build, and both crawl.  Round 4, the same 64 MB cleared by extra
+    // workgroups of the FORWARD's head launch, which has the chip to itself for 25 us: that launch 26 -> 37 us -- its pair blocks'
+    // dependent round trips wait behind the write burst -- and the step +25 us: a G cleared 130 us before build_g has left the
+    // Infinity Cache again by then, cleared right in front of it the atomics and g_times_w's reads find it there.)
     extern __shared__ __attribute__((aligned(16))) float sm[];   // pair role: [2][K4]; reduce role: [3][8][32]
     const int t = threadIdx.x;
     if ((int)blockIdx.x < B) {
