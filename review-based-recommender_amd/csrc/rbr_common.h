@@ -103,7 +103,7 @@ bool prod_b16_rows_applicable(const rbr_textcnn_desc* d);
 size_t prod_b16_rows_image_bytes(int KG, int D);
 long prod_b16_rows_image_items(int KG, int D);
 int prod_b16_rows_partials(int cap, int D);
-int prod_b16_rows_gemm(int KG, int D, int cap, const int* counter, const float* G, const void* bimg_t, float* rows, float* sq_part,
+int prod_b16_rows_gemm(int KG, int D, int cap, const int* counter, const float* G, const void* bimg_t, float* rows, float* sq_part, bool plain_bf16,
                        hipStream_t st);
 // bf16 STORAGE of the plain-bf16 class (textcnn_prod_b16.hip): T holds bf16, and `a16` (prod_b16_rows_bytes) the compact bf16 rows
 bool prod_t_bf16(const rbr_textcnn_desc* d);

@@ -968,6 +968,7 @@ __device__ __forceinline__ void dbias_partial_block(int n_docs, int C, int act, 
 // 8 coalesced loads -- splits its 8 values into planes ONCE and writes each plane's 16 bytes to LDS as [plane][m][32 k] (16-byte
 // chunks XOR-swizzled by m: the fragment reads of 8 lanes cover all banks), so an MFMA operand is one ds_read_b128.  Same grid,
 // same partials as dw_from_g_kernel (RBR_DW_FROM_G_F32=1 selects that one).
+template <int NPL>      // 3: the exact split (f32-class); 1: operands rounded to bf16 (the bf16 class)
 __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int cap, const int* __restrict__ counter,
                                                             const float* __restrict__ G, const long long* __restrict__ tok_of_row,
                                                             const float* __restrict__ table, float* __restrict__ part,
@@ -982,8 +983,8 @@ __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int c
         for (int w = b0; w < ncb * kDbChunks; w += nb) dbias_partial_block(n_docs, C, act, feat, d_feat, part_b, w % ncb, w / ncb);
         return;
     }
-    __shared__ __attribute__((aligned(16))) unsigned char As[3][64][64];      // [plane][column][32 k as bf16]
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3][64][64];      // [plane][d][32 k as bf16]
+    __shared__ __attribute__((aligned(16))) unsigned char As[NPL][64][64];      // [plane][column][32 k as bf16]
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NPL][64][64];      // [plane][d][32 k as bf16]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int col0 = blockIdx.x * 64, d0 = blockIdx.y * 64, z = blockIdx.z;
@@ -1035,17 +1036,19 @@ __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int c
         }
     };
     const int wchunk = (kq ^ ((c >> 1) & 3)) * 16;                        // where this thread's 8 k land in its column's row
-    auto stage = [&](const float (&x)[8], unsigned char (&dst)[3][64][64]) {
+    auto stage = [&](const float (&x)[8], unsigned char (&dst)[NPL][64][64]) {
         u32x4 ph, pm, pl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned a, b, cc;
-            split_pair<3>(x[2 * q], x[2 * q + 1], a, b, cc);
+            unsigned a, b = 0, cc = 0;
+            split_pair<NPL>(x[2 * q], x[2 * q + 1], a, b, cc);
             ph[q] = a; pm[q] = b; pl[q] = cc;
         }
         *reinterpret_cast<u32x4*>(&dst[0][c][wchunk]) = ph;
-        *reinterpret_cast<u32x4*>(&dst[1][c][wchunk]) = pm;
-        *reinterpret_cast<u32x4*>(&dst[2][c][wchunk]) = pl;
+        if (NPL == 3) {
+            *reinterpret_cast<u32x4*>(&dst[NPL - 2][c][wchunk]) = pm;
+            *reinterpret_cast<u32x4*>(&dst[NPL - 1][c][wchunk]) = pl;
+        }
     };
     const int am = wm * 32 + i, bn = wn * 32 + i;
     const int aswz = (am >> 1) & 3, bswz = (bn >> 1) & 3;
@@ -1054,16 +1057,18 @@ __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int c
         for (int s2 = 0; s2 < 2; ++s2) {    // two 16-deep MFMA steps per 32-row tile; lane half h holds k = 8h .. 8h+7 of the step
             const int ca = ((2 * s2 + h) ^ aswz) * 16, cb = ((2 * s2 + h) ^ bswz) * 16;
             const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&As[0][am][ca]);
-            const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(&As[1][am][ca]);
-            const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&As[2][am][ca]);
             const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(&Bs[0][bn][cb]);
-            const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(&Bs[1][bn][cb]);
-            const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(&Bs[2][bn][cb]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);      // small terms first, as the forward
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc, 0, 0, 0);
+            if (NPL == 3) {
+                const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(&As[NPL - 2][am][ca]);
+                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][am][ca]);
+                const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 2][bn][cb]);
+                const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][bn][cb]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);      // small terms first, as the forward
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
         }
     };
@@ -1425,7 +1430,8 @@ static int dtable_through_list(const rbr_textcnn_desc* d, const ConvPlan* plans,
     if (phases & kGRows) {
         if (sq_part == nullptr) { set_error("compact row gradient needs sq_part"); return RBR_ERR_BAD_ARG; }
         if (B.rows_gemm)          // many short documents: G is dense enough for the bf16-plane GEMM (textcnn_prod_b16.hip)
-            return prod_b16_rows_gemm(B.KG, d->D, Lo.cap, counter, G, static_cast<char*>(bwd_ws) + B.bimg_t, dtable, sq_part, st);
+            return prod_b16_rows_gemm(B.KG, d->D, Lo.cap, counter, G, static_cast<char*>(bwd_ws) + B.bimg_t, dtable, sq_part,
+                                      prod_precision_of(d) == RBR_PROD_BF16, st);
         if (int e_ = rbr::launch<g_times_w_kernel<kGtwRows>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, sq_part)) return e_;
     } else if (phases & kGAccumulate) {
         if (int e_ = rbr::launch<g_times_w_kernel<kGtwAccumulate>, 256>(grid, dim3(256), lds, st, "textcnn g_times_w launch", A, B.KGW, counter, G, WT, tok_of_row, row_of_token, d->V, dtable, (float*)nullptr)) return e_;
@@ -1686,8 +1692,12 @@ extern "C" int rbr_textcnn_bwd_dw_from_g(const rbr_textcnn_desc* d, const float*
         hipLaunchKernelGGL(dw_from_g_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit), dim3(256), 0, st, B.KG, d->D, Lo.cap,
                            counter, G, tok_of_row, table, part);
     else      // (the bias gradient's partials in the same launch: one z slice more)
-        hipLaunchKernelGGL(dw_from_g_b16_kernel, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit + db_slices), dim3(256), 0, st, B.KG, d->D, Lo.cap,
-                           counter, G, tok_of_row, table, part, d->n_docs, A.C, d->act, feat, d_feat, part_b);
+        if (prod_precision_of(d) == RBR_PROD_BF16)      // the bf16 class: one plane product of operands rounded to bf16
+            hipLaunchKernelGGL(dw_from_g_b16_kernel<1>, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit + db_slices), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                               counter, G, tok_of_row, table, part, d->n_docs, A.C, d->act, feat, d_feat, part_b);
+        else
+            hipLaunchKernelGGL(dw_from_g_b16_kernel<3>, dim3((B.KG + 63) / 64, (d->D + 63) / 64, kDwgSplit + db_slices), dim3(256), 0, st, B.KG, d->D, Lo.cap,
+                               counter, G, tok_of_row, table, part, d->n_docs, A.C, d->act, feat, d_feat, part_b);
     RBR_CHECK_LAUNCH("textcnn dw_from_g launch");
     if (f32_form) {
         hipLaunchKernelGGL(dbias_partial_kernel, dim3((A.C + 255) / 256, kDbChunks), dim3(256), 0, st, d->n_docs, A.C, d->act, feat, d_feat,

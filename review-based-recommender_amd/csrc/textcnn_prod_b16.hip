@@ -842,13 +842,18 @@ int prod_b16_rows_partials(int cap, int D) {
     return (((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8) * ((D + kB16BN - 1) / kB16BN);
 }
 int prod_b16_rows_gemm(int KG, int D, int cap, const int* counter, const float* G, const void* bimg_t, float* rows, float* sq_part,
-                       hipStream_t st) {
+                       bool plain_bf16, hipStream_t st) {
     if ((((uintptr_t)G) & 15) != 0 || (KG & 3) != 0 || (D & 3) != 0) { set_error("row GEMM operands must be 16-byte aligned"); return RBR_ERR_UNSUPPORTED; }
     B16Gemm g{};
     g.counter = counter; g.tok_of_row = nullptr; g.table = G; g.bimg = static_cast<const unsigned char*>(bimg_t); g.T = rows;
     g.cap = cap; g.D = KG; g.pitch = D; g.ngroups = (D + kB16BN - 1) / kB16BN; g.nchunks = (KG + kB16KC - 1) / kB16KC;
     g.ncols = D; g.sq_part = sq_part;
     const int mblocks = ((cap + kB16BM - 1) / kB16BM + 7) / 8 * 8;
+    // the bf16 class (RBR_PROD_BF16): G and Wprod^T rounded to bf16, one plane product, f32 accumulation -- what a bf16 autocast
+    // backward computes; every other class keeps the exact three-plane product
+    if (plain_bf16)
+        return rbr::launch<prod_gemm_b16_kernel<1>, kB16Threads, 2>(dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16Lds, st,
+                                                                   "textcnn rows GEMM launch", g);
     return rbr::launch<prod_gemm_b16_kernel<6>, kB16Threads, 2>(dim3((unsigned)(mblocks * g.ngroups)), dim3(kB16Threads), kB16Lds, st,
                                                                "textcnn rows GEMM launch", g);
 }
