@@ -58,6 +58,14 @@ __device__ __forceinline__ void b16_dma16(const void* gsrc, void* lds_base) {
 }
 
 // NPROD plane products per f32 product: 6 (bf16x3), 3 (bf16x2), 1 (bf16)
+// all but the two youngest stages' fills (2 row + NPLANES weight instructions per wave and stage) have landed
+template <int NPLANES>
+__device__ __forceinline__ void b16_wait_two_stages() {
+    if (NPLANES == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (NPLANES == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
 template <int NPROD>
 __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -88,8 +96,9 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
         aoff[q] = (row < n) ? (g.tok_of_row != nullptr ? g.tok_of_row[row] : (long long)row) * (long)D : -1;      // NULL: rows in place
         aseg[q] = ((lane & 3) ^ ((rl >> 2) & 3)) * 4;          // position p of the row holds segment p ^ swz(row)
     }
-    // weight fragments of a stage: 12 x 1 KiB, three per wave.  Every wave issues 5 LDS-DMA instructions per stage, also
-    // past the last stage (source clamped, slot unused), so the counted waits below hold in every step
+    // weight fragments of a stage: 12 x 1 KiB, tile `wave`'s planes per wave -- only the planes this precision multiplies.  Every
+    // wave issues kOps = 2 + NPLANES LDS-DMA instructions per stage, also past the last stage (source clamped, slot unused), so
+    // the counted waits below (two younger stages in flight) hold in every step
     const unsigned char* bsrc = g.bimg + ((size_t)ng * g.nchunks) * kB16BBytes + (size_t)wave * 3 * kB16BFrag + lane * 16;
     const int nch = g.nchunks;
     auto issue_a = [&](int c) {
@@ -107,7 +116,7 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
         unsigned char* B = Bbuf + buf * kB16BBytes + wave * 3 * kB16BFrag;
         const unsigned char* s = bsrc + (size_t)cs * kB16BBytes;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) b16_dma16(s + t * kB16BFrag, B + t * kB16BFrag);
+        for (int t = 0; t < NPLANES; ++t) b16_dma16(s + t * kB16BFrag, B + t * kB16BFrag);
     };
 
     f32x16 acc[4];
@@ -158,14 +167,14 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
     // fill instructions of stage c + 3 are issued between the MFMA groups too -- in front of the chain they cost the wave
     // ~100 cycles each with the matrix pipe idle.
     for (int c = 0; c < 3; ++c) { issue_a(c); issue_b(c); }
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            // stage 0 (this wave's share)
+    b16_wait_two_stages<NPLANES>();            // stage 0 (this wave's share)
     {
         const unsigned char* A = Abuf + arow;
         split_rows(*reinterpret_cast<const f32x4*>(A + seg0), *reinterpret_cast<const f32x4*>(A + seg1));
     }
     for (int c = 0; c < nch; ++c) {
         // stage c has landed once at most the two younger stages' fills (5 instructions each) are outstanding
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        b16_wait_two_stages<NPLANES>();
         // a bare s_barrier: __syncthreads() would add a fence that drains the fills meant to stay in flight
         __builtin_amdgcn_s_barrier();         // weights of stage c landed for every wave; every wave is done with stage c - 1
         asm volatile("" ::: "memory");
@@ -176,7 +185,7 @@ __device__ __forceinline__ void prod_gemm_b16_kernel(const B16Gemm& g) {
         mma_tile(B, 1);
         issue_b(c + 3);
         mma_tile(B, 2);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // this wave's rows of stage c + 1
+        b16_wait_two_stages<NPLANES>();        // this wave's rows of stage c + 1
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(An + seg0), x1 = *reinterpret_cast<const f32x4*>(An + seg1);
         mma_tile(B, 3);
         split_rows(x0, x1);
