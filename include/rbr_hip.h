@@ -464,7 +464,10 @@ int rbr_datt_global_gate_bwd(int32_t B, int32_t L, int32_t E, const int64_t* ids
  * dtable [V,E] is OVERWRITTEN (absent tokens and pad_idx: 0).
  * ws: rbr_datt_global_gate_bwd_rows_ws_floats floats (0: E > 256 or L % 4 != 0 -> use rbr_datt_global_gate_bwd).
  * `accumulate` != 0 (here and in rbr_datt_local_gate_bwd_prod): the rows of the batch's tokens are ADDED to dtable -- a gradient
- * buffer shared by the producers of one step, which run one after the other on one stream -- and nothing else is written. */
+ * buffer shared by the producers of one step, which run one after the other on one stream -- and nothing else is written.
+ * rbr_datt_global_gate_bwd_rows in two calls (the phases on different streams): first with dtable == NULL (dw, db0; dpre stays
+ * in `ws`), then with accumulate | 2 and dtable (the table rows alone, from the dpre in `ws`; table / gate / dgate / dw / db0
+ * are not read and may be NULL). */
 size_t rbr_datt_token_rows_ws_bytes(int32_t B, int32_t L, int32_t V);
 int rbr_datt_token_rows(int32_t B, int32_t L, int32_t V, const int64_t* ids, void* rows, void* stream);
 size_t rbr_datt_global_gate_bwd_rows_ws_floats(int32_t B, int32_t L, int32_t E, int32_t V);

@@ -993,14 +993,20 @@ extern "C" int rbr_datt_global_gate_bwd_rows(int32_t B, int32_t L, int32_t E, in
     TokenRowsLayout T;
     if (!gate_args_ok(B, L, E, 1) || !token_rows_layout(B, L, V, T)) return RBR_ERR_BAD_ARG;
     if (E > kGgChunks * 64 || L % 4 != 0) { set_error("global gate over token rows needs E <= %d and L %% 4 == 0 (E=%d L=%d)", kGgChunks * 64, E, L); return RBR_ERR_UNSUPPORTED; }
-    if (!ids || !table || !w || !gate || !dgate || !dw || !db0 || !ws || !rows) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
+    // accumulate & 2: the table-gradient phase alone -- dpre is in `ws` already (an earlier call with dtable == NULL on the same
+    // workspace did the weight phase); a caller that puts the two phases of its towers on different streams (functional._DattTowers)
+    const bool rows_only = (accumulate & 2) != 0;
+    accumulate &= 1;
+    if (!ids || !w || !ws || !rows || (!rows_only && (!table || !gate || !dgate || !dw || !db0)) || (rows_only && !dtable)) { set_error("null pointer"); return RBR_ERR_BAD_ARG; }
     hipStream_t st = (hipStream_t)stream;
     const long long* ids64 = reinterpret_cast<const long long*>(ids);
     const char* base = static_cast<const char*>(rows);
     const int* counter = reinterpret_cast<const int*>(base + T.counter);
     const int* row_of_token = reinterpret_cast<const int*>(base + T.row_of_token);
-    if (int e_ = rbr::launch<global_gate_bwd_dpre_kernel, 256>(dim3(B), dim3(256), 0, st, "datt global gate bwd dpre launch", B, L, gate, dgate, ws)) return e_;
-    if (int e_ = rbr::launch<global_gate_bwd_dw_kernel, 256>(dim3(L + 1), dim3(256), 0, st, "datt global gate bwd dw launch", B, L, E, ids64, table, ws, dw, db0)) return e_;
+    if (!rows_only) {
+        if (int e_ = rbr::launch<global_gate_bwd_dpre_kernel, 256>(dim3(B), dim3(256), 0, st, "datt global gate bwd dpre launch", B, L, gate, dgate, ws)) return e_;
+        if (int e_ = rbr::launch<global_gate_bwd_dw_kernel, 256>(dim3(L + 1), dim3(256), 0, st, "datt global gate bwd dw launch", B, L, E, ids64, table, ws, dw, db0)) return e_;
+    }
     if (dtable != nullptr) {
         float* wT = ws + B;
         float* A = wT + (((size_t)E * L + 3) & ~(size_t)3);             // 16-byte aligned behind wT when ws is

@@ -1849,8 +1849,13 @@ class _DattTowers(torch.autograd.Function):
             d_feats = torch.zeros_like(ctx.keep[0])
         d_feats = d_feats.contiguous()
         need_table = ctx.needs_input_grad[0]
-        # one zeroed gradient buffer per tower (see the class comment); allocated and cleared BEFORE the region
-        dtab = torch.zeros(2, V, E, dtype=F32, device=dev) if need_table else None
+        # Table-gradient buffers [4, V, E], allocated (and the gates' cleared) BEFORE the regions: [t] receives tower t's gate rows
+        # (added: local gate, then global gate, one after the other on this stream), [2 + t] its conv rows (g_times_w's dense
+        # form: every row written, absent tokens' rows zero).  Gates and conv of a tower run on DIFFERENT streams below, and two
+        # towers' workgroups of one launch may meet in a row: four writers, four buffers, summed once at the end.
+        dtab = torch.empty(4, V, E, dtype=F32, device=dev) if need_table else None
+        if need_table:
+            dtab[:2].zero_()
         bws_bytes = L_.rbr_textcnn_bwd_prod_ws_bytes(C.byref(desc))
         gg_floats = L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V)
         wsn = L_.rbr_textcnn_bwd_ws_floats(C.byref(desc))
@@ -1863,54 +1868,76 @@ class _DattTowers(torch.autograd.Function):
                          torch.empty(1, dtype=F32, device=dev)] + [torch.empty_like(w) for w in tw.ws]
                         + [torch.empty(w.shape[0], dtype=F32, device=dev) for w in tw.ws])
         st = current_stream()
-        # the conv weight gradient (dw_partial4, dw_reduce) starts from d_feats alone: second stream, beside the table-gradient
-        # chain, as in _textcnn_backward.  The fork is recorded before the region's launches leave, the join after them.
+        # Two streams, two regions.  Region A: G and d(gate) of both towers on this stream (zero_g_rows, build_g), the conv weight
+        # gradient (dw_partial4, dw_reduce: it starts from d_feats alone) on the second one.  Region B: the gates' backwards on
+        # this stream -- they need d(gate) -- and the conv's sparse product G @ Wprod^T on the second stream behind the weight
+        # gradient -- it needs G.  (One stream for everything but the weight gradient, as in round 3: the second stream idle for
+        # 600 us of the backward's 750.)
         side = _side_stream(dev)
         fork = join = None
         if side is not None:
             fork = torch.cuda.Event()
             fork.record()
             side.wait_event(fork)
-        st_dw = side.cuda_stream if side is not None else st
+        st2 = side.cuda_stream if side is not None else st
+        st_prod = st if TIMER.enabled else st2      # (the timing pass brackets calls with events on THIS stream)
         ev = TIMER.record("datt_towers_bwd")
+        tab = dev_ptr(table, F32, "table")
+        paired = singles = 0
         with _region_or_timed() as region:
             for t, tw in enumerate(towers):
                 if t == 1:
                     region.next()
                 ids_p = dev_ptr(tw.ids, I64, "ids")
                 d_feat = d_feats[t * B:(t + 1) * B]
-                dt = dev_ptr(dtab[t], F32, "dtable") if need_table else None
-                tab = dev_ptr(table, F32, "table")
-                # first in the list: the weight-gradient pair goes to the second stream before the long chain below is
-                # enqueued (recorded last it started ~400 us late in the replayed graph, under the global gate's kernels)
                 check(L_.rbr_textcnn_bwd_dw(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"), tab,
                                             dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
                                             dev_ptr(d_feat, F32, "d_feat"), ptr_array(tw.grads[4:8], F32, "dW"),
-                                            ptr_array(tw.grads[8:12], F32, "dbias"), dev_ptr(tw.wsb, F32, "ws"), st_dw), "rbr_textcnn_bwd_dw")
-                # G, d(gate) and -- when wanted -- this tower's conv share of the table gradient
-                if TIMER.enabled and need_table:      # the two phases as two calls: the sparse product (one launch) gets events of its own
-                    check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
-                                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
-                                                            dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), None,
-                                                            dev_ptr(tw.dgate2, F32, "dgate"), None, _lib.G_BUILD, st), "rbr_textcnn_bwd_g_build")
+                                            ptr_array(tw.grads[8:12], F32, "dbias"), dev_ptr(tw.wsb, F32, "ws"), st2), "rbr_textcnn_bwd_dw")
+                check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
+                                                        dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
+                                                        dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), None,
+                                                        dev_ptr(tw.dgate2, F32, "dgate"), None, _lib.G_BUILD, st), "rbr_textcnn_bwd_g_build")
+        paired, singles = paired + region.paired, singles + region.singles
+        if side is not None:          # G is complete on this stream (the region's launches have left): the product may follow it
+            g_done = torch.cuda.Event()
+            g_done.record()
+            side.wait_event(g_done)
+        with _region_or_timed() as region:
+            for t, tw in enumerate(towers):
+                if t == 1:
+                    region.next()
+                ids_p = dev_ptr(tw.ids, I64, "ids")
+                dt = dev_ptr(dtab[t], F32, "dtable") if need_table else None
+                if need_table:
+                    dc = dev_ptr(dtab[2 + t], F32, "dtable")
                     _timed_call("textcnn_bwd_g_product", lambda: L_.rbr_textcnn_bwd_dtable_prod_ex(
-                        C.byref(desc), None, None, None, None, None, None, tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt, None, None,
-                        _lib.G_PRODUCT | _lib.G_ACCUMULATE, st))
-                else:
-                    check(L_.rbr_textcnn_bwd_dtable_prod_ex(C.byref(desc), ids_p, None, dev_ptr(tw.gate2, F32, "gate"),
-                                                            dev_ptr(tw.feat, F32, "feat"), dev_ptr(tw.argmax, I32, "argmax"),
-                                                            dev_ptr(d_feat, F32, "d_feat"), tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dt,
-                                                            dev_ptr(tw.dgate2, F32, "dgate"), None,
-                                                            _lib.G_BUILD | ((_lib.G_PRODUCT | _lib.G_ACCUMULATE) if need_table else 0), st),
-                          "rbr_textcnn_bwd_dtable_prod")
+                        C.byref(desc), None, None, None, None, None, None, tw.prod_ws.data_ptr(), tw.bws.data_ptr(), dc, None, None,
+                        _lib.G_PRODUCT, st_prod))
                 check(L_.rbr_datt_local_gate_bwd_prod(B, L, E, win, V, ids_p, tab, dev_ptr(tw.lw, F32, "w"),
                                                       dev_ptr(tw.gate2[0], F32, "gate"), dev_ptr(tw.dgate2[0], F32, "dgate"), pad,
                                                       dev_ptr(tw.grads[0], F32, "dw"), dev_ptr(tw.grads[1], F32, "db0"), dt,
                                                       tw.gate_ws.data_ptr(), tw.rows.data_ptr(), 1, st), "rbr_datt_local_gate_bwd_prod")
+                # the global gate's weight phase (dpre, dw: both towers per launch); its table rows follow outside the region
                 check(L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, ids_p, tab, dev_ptr(tw.gw, F32, "w"),
                                                        dev_ptr(tw.gate2[1], F32, "gate"), dev_ptr(tw.dgate2[1], F32, "dgate"), pad,
-                                                       dev_ptr(tw.grads[2], F32, "dw"), dev_ptr(tw.grads[3], F32, "db0"), dt,
+                                                       dev_ptr(tw.grads[2], F32, "dw"), dev_ptr(tw.grads[3], F32, "db0"), None,
                                                        dev_ptr(tw.gg_ws, F32, "ws"), tw.rows.data_ptr(), 1, st),
+                      "rbr_datt_global_gate_bwd_rows")
+        paired, singles = paired + region.paired, singles + region.singles
+        if need_table:
+            # ... a chain of four launches over the tower's 120 MB occurrence matrix, one tower at a time either way: tower 0's on
+            # this stream into its gate buffer, tower 1's on the second stream behind the sparse products, into the buffer its
+            # conv rows were written to there (same stream: no fifth buffer) -- both streams then end about together
+            if side is not None and not TIMER.enabled:
+                dpre_done = torch.cuda.Event()
+                dpre_done.record()
+                side.wait_event(dpre_done)
+            for t, tw in enumerate(towers):
+                on_side = t == 1 and side is not None and not TIMER.enabled
+                check(L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, dev_ptr(tw.ids, I64, "ids"), None, dev_ptr(tw.gw, F32, "w"), None, None,
+                                                       pad, None, None, dev_ptr(dtab[3] if on_side else dtab[t], F32, "dtable"),
+                                                       dev_ptr(tw.gg_ws, F32, "ws"), tw.rows.data_ptr(), 1 | 2, st2 if on_side else st),
                       "rbr_datt_global_gate_bwd_rows")
         if side is not None:
             with torch.cuda.stream(side):
@@ -1919,9 +1946,9 @@ class _DattTowers(torch.autograd.Function):
             _join(join)
         if ev is not None:
             ev.record()
-        PAIR_STATS["paired"] += region.paired
-        PAIR_STATS["singles"] += region.singles
-        dtable = (dtab[0].add_(dtab[1])) if need_table else None
+        PAIR_STATS["paired"] += paired
+        PAIR_STATS["singles"] += singles
+        dtable = dtab.sum(0) if need_table else None
         grads = towers[0].grads + towers[1].grads
         for tw in towers:
             tw.bws = tw.dgate2 = tw.gg_ws = tw.wsb = tw.grads = None
