@@ -37,17 +37,33 @@ struct Epi {
 // partial tiles in slice order and applies the epilogue.  (Measured and dropped: ONE launch in which the last slice of a tile
 // to arrive -- a ticket per tile -- does the reduction: the release / acquire fences that make the partial tiles visible across
 // the 8 XCDs write back and invalidate whole L2s, and the 1024 x 500 x 500 fc took 84 us instead of 24.)
-__global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K_all, const float* __restrict__ A, long sam, long sak,
-                                                   const float* __restrict__ B, long sbn, long sbk, float* __restrict__ C,
-                                                   long ldc, const Epi ep, long bytes_a, long bytes_b, int kper,
-                                                   float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) float As[64 * GS];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
-    const int kb = (gridDim.z > 1) ? (int)blockIdx.z * kper : 0;
-    const int K = (gridDim.z > 1) ? min(K_all - kb, kper) : K_all;          // this slice's K extent (kper is a multiple of GK)
+// One product as a kernel argument (the launcher fills it; tx x ty output tiles, `slices` K slices)
+struct GemmJob {
+    int M, N, K_all, kper, tx, ty, slices;
+    long sam, sak, sbn, sbk, ldc, bytes_a, bytes_b;
+    const float* A;
+    const float* B;
+    float* C;
+    float* part;
+    Epi ep;
+};
+
+// workgroup (bx, by, bz) of product J
+__device__ __forceinline__ void gemm_body(const GemmJob& J, const int bx, const int by, const int bz, float* __restrict__ As,
+                                          float* __restrict__ Bs) {
+    const int M = J.M, N = J.N, K_all = J.K_all, kper = J.kper;
+    const long sam = J.sam, sak = J.sak, sbn = J.sbn, sbk = J.sbk, ldc = J.ldc, bytes_a = J.bytes_a, bytes_b = J.bytes_b;
+    const float* __restrict__ A = J.A;
+    const float* __restrict__ B = J.B;
+    float* __restrict__ C = J.C;
+    float* __restrict__ part = J.part;
+    const Epi ep = J.ep;
+    const bool sliced = J.slices > 1;
+    const int kb = sliced ? bz * kper : 0;
+    const int K = sliced ? min(K_all - kb, kper) : K_all;          // this slice's K extent (kper is a multiple of GK)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = bx * 64;
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc;
 #pragma unroll
@@ -128,9 +144,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K_all, cons
         chunk(k0, std::true_type{}, ra[0], rb[0]);
         if (k0 + GK < K) chunk(k0 + GK, std::true_type{}, ra[1], rb[1]);
     }
-    if (gridDim.z > 1) {                              // a K slice: the partial tile goes to `part`, gemm_reduce_kernel finishes
-        const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
-        float* mine = part + (((long)blockIdx.z * ntiles + tile) * 4 + wave) * 1024 + lane;
+    if (sliced) {                                     // a K slice: the partial tile goes to `part`, the reduce kernel finishes
+        const int tile = by * J.tx + bx, ntiles = J.tx * J.ty;
+        float* mine = part + (((long)bz * ntiles + tile) * 4 + wave) * 1024 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
         return;
@@ -151,15 +167,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(int M, int N, int K_all, cons
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmJob J) {
+    __shared__ __attribute__((aligned(16))) float As[64 * GS];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
+    gemm_body(J, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Two independent products in one launch (a layer's weight gradient and its input gradient: same g, nothing else shared):
+// the workgroups of J0 first, then J1's, in a flat grid.  Two inlined bodies behind a workgroup-uniform branch -- a select
+// between the two argument structs would copy them to scratch (rbr_launch.h).
+__global__ __launch_bounds__(256) void gemm2_kernel(const GemmJob J0, const GemmJob J1) {
+    __shared__ __attribute__((aligned(16))) float As[64 * GS];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * GS];
+    const int n0 = J0.tx * J0.ty * J0.slices;
+    int b = blockIdx.x;
+    if (b < n0) {
+        const int t = J0.tx * J0.ty;
+        gemm_body(J0, (b % t) % J0.tx, (b % t) / J0.tx, b / t, As, Bs);
+    } else {
+        b -= n0;
+        const int t = J1.tx * J1.ty;
+        gemm_body(J1, (b % t) % J1.tx, (b % t) / J1.tx, b / t, As, Bs);
+    }
+}
+
 // C tile = epilogue(sum over the slices, in slice order); same (wave, register, lane) -> (m, n) map as gemm_kernel's epilogue
 // One WAVE per 32 x 32 quadrant (grid z = quadrant): four times the workgroups of the product's grid, every load of a lane in flight
 // at once -- the kernel is two memory round trips long.
-__global__ __launch_bounds__(64) void gemm_reduce_kernel(int M, int N, int slices, const float* __restrict__ part, float* __restrict__ C,
-                                                         long ldc, const Epi ep) {
-    const int wave = blockIdx.z, lane = threadIdx.x;
+struct ReduceJob {                // the reduction of one sliced product: tx x ty tiles (0 tiles: nothing to reduce)
+    int M, N, slices, tx, ty;
+    const float* part;
+    float* C;
+    long ldc;
+    Epi ep;
+};
+
+// quadrant `wave` of tile (bx, by)
+__device__ __forceinline__ void gemm_reduce_body(const ReduceJob& J, const int bx, const int by, const int wave, const int lane) {
+    const int M = J.M, N = J.N, slices = J.slices;
+    const float* __restrict__ part = J.part;
+    float* __restrict__ C = J.C;
+    const long ldc = J.ldc;
+    const Epi ep = J.ep;
     const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x, ntiles = gridDim.x * gridDim.y;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tile = by * J.tx + bx, ntiles = J.tx * J.ty;
+    const int m0 = by * 64, n0 = bx * 64;
     float acc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -196,6 +248,10 @@ __global__ __launch_bounds__(64) void gemm_reduce_kernel(int M, int N, int slice
     }
 }
 
+__global__ __launch_bounds__(64) void gemm_reduce_kernel(const ReduceJob J) {
+    gemm_reduce_body(J, blockIdx.x, blockIdx.y, blockIdx.z, threadIdx.x);
+}
+
 // slices and K per slice for an M x N x K product: enough workgroups for two per CU, at least two chunks of K per slice
 static void gemm_split(int M, int N, int K, int& slices, int& kper) {
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
@@ -212,20 +268,30 @@ static size_t gemm_split_floats(int M, int N, int K) {
 }
 
 // part: split-K scratch (gemm_split_floats floats) or NULL = one slice
-static int launch_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
-                       long ldc, Epi ep, hipStream_t st, float* part = nullptr) {
+static bool make_job(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc,
+                     Epi ep, float* part, GemmJob& J) {
     const long bytes_a = ((long)(M - 1) * sam + (long)(K - 1) * sak + 1) * 4, bytes_b = ((long)(N - 1) * sbn + (long)(K - 1) * sbk + 1) * 4;
     if (bytes_a >= (1L << 30) || bytes_b >= (1L << 30)) {
         set_error("gemm operand of %ld / %ld bytes exceeds the 1 GiB the buffer addressing of this kernel covers", bytes_a, bytes_b);
-        return RBR_ERR_UNSUPPORTED;
+        return false;
     }
     int slices = 1, kper = K;
     if (part != nullptr) gemm_split(M, N, K, slices, kper);
-    hipLaunchKernelGGL(gemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, slices), dim3(256), 0, st, M, N, K, A, sam, sak, B, sbn, sbk, C,
-                       ldc, ep, bytes_a, bytes_b, kper, part);
+    J = GemmJob{M, N, K, kper, (N + 63) / 64, (M + 63) / 64, slices, sam, sak, sbn, sbk, ldc, bytes_a, bytes_b, A, B, C, part, ep};
+    return true;
+}
+static ReduceJob reduce_of(const GemmJob& J) {
+    if (J.slices <= 1) return ReduceJob{0, 0, 0, 0, 0, nullptr, nullptr, 0, Epi{nullptr, nullptr, 0}};
+    return ReduceJob{J.M, J.N, J.slices, J.tx, J.ty, J.part, J.C, J.ldc, J.ep};
+}
+static int launch_gemm(int M, int N, int K, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C,
+                       long ldc, Epi ep, hipStream_t st, float* part = nullptr) {
+    GemmJob J;
+    if (!make_job(M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, ep, part, J)) return RBR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_kernel, dim3(J.tx, J.ty, J.slices), dim3(256), 0, st, J);
     RBR_CHECK_LAUNCH("gemm launch");
-    if (slices > 1) {
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((N + 63) / 64, (M + 63) / 64, 4), dim3(64), 0, st, M, N, slices, part, C, ldc, ep);
+    if (J.slices > 1) {
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3(J.tx, J.ty, 4), dim3(64), 0, st, reduce_of(J));
         RBR_CHECK_LAUNCH("gemm reduce launch");
     }
     return 0;
@@ -252,10 +318,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long n, const float* __res
 
 // db[n] = sum_m g[m, n]   (fixed order).  64 columns per workgroup, the rows split over its four waves (8 loads in
 // flight per thread), partial sums met in LDS in wave order.
-__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ g, float* __restrict__ db) {
-    __shared__ float s_part[4][64];
+__device__ __forceinline__ void colsum_body(int M, int N, const float* __restrict__ g, float* __restrict__ db, const int cb,
+                                            float (*s_part)[64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
+    const int n = cb * 64 + lane;
     float s = 0.f;
     if (n < N) {
         int m = wave;
@@ -271,6 +337,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
     s_part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && n < N) db[n] = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ g, float* __restrict__ db) {
+    __shared__ float s_part[4][64];
+    colsum_body(M, N, g, db, blockIdx.x, s_part);
+}
+
+// What follows a layer's two backward products (gemm2_kernel) in ONE launch: the reductions of the sliced ones -- a workgroup per
+// tile, wave = quadrant: the waves of gemm_reduce_kernel's grid -- and the bias gradient's column sums (cs_n > 0: blocks of 64
+// columns of g [cs_m, cs_n]).  Flat grid: R0's tiles, R1's tiles, column blocks.
+__global__ __launch_bounds__(256) void gemm_reduce2_kernel(const ReduceJob R0, const ReduceJob R1, int cs_m, int cs_n,
+                                                           const float* __restrict__ g, float* __restrict__ db) {
+    __shared__ float s_part[4][64];
+    const int n0 = R0.tx * R0.ty, n1 = R1.tx * R1.ty;
+    int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (b < n0) { gemm_reduce_body(R0, b % R0.tx, b / R0.tx, wave, lane); return; }
+    b -= n0;
+    if (b < n1) { gemm_reduce_body(R1, b % R1.tx, b / R1.tx, wave, lane); return; }
+    colsum_body(cs_m, cs_n, g, db, b - n1, s_part);
 }
 
 // ------------------------------------------------------------------------------------ embedding
@@ -370,7 +456,7 @@ extern "C" int rbr_linear_fwd_ex(int32_t N, int32_t IN, int32_t OUT, const float
 extern "C" size_t rbr_linear_bwd_ws_floats(int32_t N, int32_t OUT) { return (N > 0 && OUT > 0) ? (size_t)N * OUT : 0; }
 extern "C" size_t rbr_linear_bwd_ex_ws_floats(int32_t N, int32_t IN, int32_t OUT) {
     if (N <= 0 || IN <= 0 || OUT <= 0) return 0;
-    return (size_t)N * OUT + std::max(gemm_split_floats(OUT, IN, N), gemm_split_floats(N, IN, OUT));
+    return (size_t)N * OUT + gemm_split_floats(OUT, IN, N) + gemm_split_floats(N, IN, OUT);      // g | dW's partials | d_x's
 }
 
 static int linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const float* W, const float* y, const float* d_y,
@@ -402,14 +488,42 @@ static int linear_bwd(int32_t N, int32_t IN, int32_t OUT, const float* x, const 
         g = ws;
     }
     Epi none{nullptr, nullptr, 0};
+    if (split) {
+        // the weight gradient and the input gradient start from the same g and share nothing else: ONE launch for both products
+        // (gemm2_kernel), ONE for what follows them -- their split-K reductions and the bias gradient's column sums -- instead of
+        // up to five (D-ATT's shared fc: 11 launches of 5-10 us in the step's backward, now 5)
+        GemmJob Jw, Jx;
+        float* part_w = part;
+        float* part_x = part + gemm_split_floats(OUT, IN, N);
+        // dW[OUT, IN] = g^T[OUT, N] . x[N, IN]:  A(m=o, k=n) = g[n*OUT + o], B(n=i, k=n) = x[n*IN + i]
+        if (!make_job(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, part_w, Jw)) return RBR_ERR_UNSUPPORTED;
+        if (d_x) {
+            // d_x[N, IN] = g[N, OUT] . W[OUT, IN]:  A(m=n, k=o) = g[n*OUT + o], B(n=i, k=o) = W[o*IN + i]
+            if (!make_job(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, part_x, Jx)) return RBR_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL(gemm2_kernel, dim3((unsigned)(Jw.tx * Jw.ty * Jw.slices + Jx.tx * Jx.ty * Jx.slices)), dim3(256), 0, st, Jw, Jx);
+            RBR_CHECK_LAUNCH("linear backward products launch");
+        } else {
+            Jx = GemmJob{};
+            Jx.slices = 1;
+            hipLaunchKernelGGL(gemm_kernel, dim3(Jw.tx, Jw.ty, Jw.slices), dim3(256), 0, st, Jw);
+            RBR_CHECK_LAUNCH("gemm launch");
+        }
+        const ReduceJob Rw = reduce_of(Jw), Rx = reduce_of(Jx);
+        const int nb = Rw.tx * Rw.ty + Rx.tx * Rx.ty + (db ? (OUT + 63) / 64 : 0);
+        if (nb > 0) {
+            hipLaunchKernelGGL(gemm_reduce2_kernel, dim3((unsigned)nb), dim3(256), 0, st, Rw, Rx, db ? N : 0, db ? OUT : 0, g, db);
+            RBR_CHECK_LAUNCH("linear backward reductions launch");
+        }
+        return 0;
+    }
     // dW[OUT, IN] = g^T[OUT, N] . x[N, IN]:  A(m=o, k=n) = g[n*OUT + o], B(n=i, k=n) = x[n*IN + i]
-    if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st, part)) return e;
+    if (int e = launch_gemm(OUT, IN, N, g, 1, OUT, x, 1, IN, dW, IN, none, st, nullptr)) return e;
     if (db) {
         hipLaunchKernelGGL(colsum_kernel, dim3((OUT + 63) / 64), dim3(256), 0, st, N, OUT, g, db);
         RBR_CHECK_LAUNCH("linear colsum launch");
     }
     // d_x[N, IN] = g[N, OUT] . W[OUT, IN]:  A(m=n, k=o) = g[n*OUT + o], B(n=i, k=o) = W[o*IN + i]
-    if (d_x) return launch_gemm(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, st, part);
+    if (d_x) return launch_gemm(N, IN, OUT, g, OUT, 1, W, 1, IN, d_x, IN, none, st, nullptr);
     return 0;
 }
 

@@ -4,7 +4,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_narre_datt_gpu.py tests/test_datt_pair_gpu.py tests/test_fused_step_gpu.py tests/test_graph_step_gpu.py tests/test_trainer_gpu.py -m gpu -q -x > gpurun_out/tests_k.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_ops_random_gpu.py tests/test_siamese_gpu.py tests/test_narre_datt_gpu.py tests/test_datt_pair_gpu.py tests/test_fused_step_gpu.py tests/test_graph_step_gpu.py tests/test_trainer_gpu.py -m gpu -q -x > gpurun_out/tests_k.log 2>&1
 rc=$?; tail -4 gpurun_out/tests_k.log; echo "tests rc=$rc"
 [ $rc -ne 0 ] && exit $rc
 timeout -k 10 300 python tools/bench_models.py datt 2>/dev/null | tail -1 | cut -c1-600
