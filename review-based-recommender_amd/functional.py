@@ -1805,6 +1805,9 @@ class _DattTowers(torch.autograd.Function):
             tw.prod_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             tw.feat, tw.argmax = feats[t * B:(t + 1) * B], argmax[t * B:(t + 1) * B]
         ev = TIMER.record("datt_towers_fwd")
+        # (Measured and dropped, round 4: tower 1's product-table GEMM on a second stream beside tower 0's gather -- MFMA / LDS work
+        # beside L2-request work.  The GEMM's 137 MB of product-table writes push the table the gather is reading out of the L2s and
+        # the Infinity Cache: the gather 125 -> 205 us, the GEMM 48 -> 150 us, the step +80 us.)
         with _region_or_timed() as region:
             for t, tw in enumerate(towers):
                 if t == 1:
