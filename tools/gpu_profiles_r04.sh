@@ -38,7 +38,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_'); rm -rf $O/dpmc_$n
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/dpmc_$n -o r -- python3 tools/bench_models.py datt --no-graph > $O/dpmc_$n.log 2>&1
 done
-for k in gather_pool g_times_w prod_gemm_b16_kernel gg_rows global_gate_fwd; do
+for k in gather_pool g_times_w prod_gemm_b16k_kernel gg_rows global_gate_fwd; do
   python tools/pmc_summary.py $k $O/r04_datt_${k}_pmc.json $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum > /dev/null 2>&1 || echo "datt pmc summary $k failed"
 done
 rm -rf $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum
