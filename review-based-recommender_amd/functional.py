@@ -1807,7 +1807,9 @@ class _DattTowers(torch.autograd.Function):
         ev = TIMER.record("datt_towers_fwd")
         # (Measured and dropped, round 4: tower 1's product-table GEMM on a second stream beside tower 0's gather -- MFMA / LDS work
         # beside L2-request work.  The GEMM's 137 MB of product-table writes push the table the gather is reading out of the L2s and
-        # the Infinity Cache: the gather 125 -> 205 us, the GEMM 48 -> 150 us, the step +80 us.)
+        # the Infinity Cache: the gather 125 -> 205 us, the GEMM 48 -> 150 us, the step +80 us.  Also dropped: both gates on the second
+        # stream beside tower 0's GEMM, which needs the token list only -- the GEMM 49 -> 81 us, the gates' three kernels 102 -> 134,
+        # the gather starts 4 us earlier: everything here queues at the same L2s.)
         with _region_or_timed() as region:
             for t, tw in enumerate(towers):
                 if t == 1:
