@@ -385,6 +385,11 @@ __device__ __forceinline__ void g_times_w_kernel(const ProdBwdArgs& A, const int
     // kGtwRows: the gradient in COMPACT form -- row r of `dtable` is the gradient of token tok_of_row[r] (the rows of absent
     // tokens are not written anywhere: rbr_clip_adam_step_rows takes them as zero), and sq_part[workgroup] = the sum of squares
     // of the rows this workgroup wrote (static row -> workgroup -> thread mapping: the same bits on every run).
+    // (Measured and dropped, round 4: a WAVE per row -- the row scanned, listed and multiplied out by one wave, 8 weight-row loads in
+    // flight, rows of <= 32 quads two per instruction; rows with more than 64 non-zeros marked and left to this kernel, launched
+    // behind it with a filter.  Same results (191 tests).  cfg2: 43 us + 28 us for the marked rows -- the Zipf head, 750 non-zeros
+    // in the first rows of the list, which THIS kernel starts at t = 0 beside everything else and the split runs as a tail --
+    // against 46 us; D-ATT 93 against 88.  Four rows in flight per workgroup do not make the weight rows arrive faster.)
     // (Measured and dropped, round 4: the NEXT row's quarter of G fetched by LDS-DMA while this row is worked on -- two buffers per
     // wave, no registers, the wait placed in front of the previous row's stores.  cfg2: the step +3.5 us; D-ATT cfg4: 89 -> 86 us.
     // The ~5 us a workgroup spends per row are not the G read: they are the chain list -> weight rows -> barrier -> store.)
