@@ -155,6 +155,52 @@ def test_global_gate_backward_over_token_rows_matches_the_plain_one(L):
     assert RF.datt_token_rows(ids[:2, :64], V) is None                   # too few positions: the plain path is kept
 
 
+def test_global_gate_backward_in_two_calls_equals_one():
+    """rbr_datt_global_gate_bwd_rows as two calls -- dtable == NULL (dw, db0; dpre stays in ws), then accumulate | 2 (the table
+    rows alone, possibly on another stream: functional._DattTowers puts tower 1's there) -- against the single call: the same
+    kernels on the same inputs; the second phase reads neither table nor gate nor dgate (NULL)."""
+    import ctypes as C
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd import functional as RF
+    from review_based_recommender_amd._lib import dev_ptr
+    F32, I64 = torch.float32, torch.int64
+    L_ = _lib.lib()
+    gen = torch.Generator().manual_seed(9)
+    B, L, V, E = 16, 512, 2000, 100
+    ids = (torch.rand(B, L, generator=gen) ** 4 * V).long().clamp_(0, V - 1).to(DEV)
+    table = (torch.randn(V, E, generator=gen) * 0.3).to(DEV)
+    w = (torch.randn(1, E, L, generator=gen) * 0.05).to(DEV)
+    gate = torch.sigmoid(torch.randn(B, 1, generator=gen)).expand(B, L).contiguous().to(DEV)
+    dgate = torch.randn(B, L, generator=gen).to(DEV)
+    rows = RF.datt_token_rows(ids, V)
+    assert rows is not None
+    st = torch.cuda.current_stream().cuda_stream
+    n_ws = L_.rbr_datt_global_gate_bwd_rows_ws_floats(B, L, E, V)
+
+    def call(dtable, flags, full=True, ws=None, dw=None, db0=None):
+        return L_.rbr_datt_global_gate_bwd_rows(B, L, E, V, dev_ptr(ids, I64, "ids"), dev_ptr(table, F32, "t") if full else None,
+                                                dev_ptr(w, F32, "w"), dev_ptr(gate, F32, "g") if full else None,
+                                                dev_ptr(dgate, F32, "dg") if full else None, 0,
+                                                dev_ptr(dw, F32, "dw") if dw is not None else None,
+                                                dev_ptr(db0, F32, "db0") if db0 is not None else None,
+                                                dev_ptr(dtable, F32, "dt") if dtable is not None else None, dev_ptr(ws, F32, "ws"),
+                                                rows.data_ptr(), flags, st)
+
+    base = torch.randn(V, E, generator=gen).to(DEV)       # accumulate mode: rows are added to what the buffer holds
+    one, dw1, db1, ws1 = base.clone(), torch.empty_like(w), torch.empty(1, device=DEV), torch.empty(n_ws, device=DEV)
+    assert call(one, 1, ws=ws1, dw=dw1, db0=db1) == 0
+    two, dw2, db2, ws2 = base.clone(), torch.empty_like(w), torch.empty(1, device=DEV), torch.empty(n_ws, device=DEV)
+    assert call(None, 1, ws=ws2, dw=dw2, db0=db2) == 0
+    assert torch.equal(two, base)                          # the first phase writes no table row
+    assert call(two, 1 | 2, full=False, ws=ws2) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    # (the occurrence matrix is filled with float atomics: a hot row's sum may round differently from run to run)
+    assert float((one - two).abs().max()) <= 2e-6 * float((one - base).abs().max())
+    assert call(None, 1 | 2, full=False, ws=ws2) != 0      # rows-only without a table gradient buffer: refused
+    assert b"null pointer" in L_.rbr_last_error()
+
+
 def test_datt_shared_table_gradient_buffer_survives_interleaved_steps():
     """functional.table_fanout: the eight producers of word-table gradient of a D-ATT step add their rows into one buffer that
     hangs on the step's own fan-out node.  Two micro-batches run forward, forward, backward, backward (gradient accumulation)
