@@ -74,13 +74,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(int B, int R, int H, int 
     }
 }
 
-// output index of the batch reductions: [0, H*A) dW_rv | [H*A, H*A + A*A) dW_id | + A db1 | + A dh | + 1 db2
-__device__ __forceinline__ int attn_n_out(int H, int A) { return H * A + A * A + 2 * A + 1; }
-
-// per-sample backward: d_feat, embedding-row gradient, and the sample's partial of the batch reductions
+// per-sample backward: d_feat, embedding-row gradient, and the per-row d_pre / d_logit the reduction needs
 struct AttnBwdSide {
     const float* feat; const long long* oid; rbr_attn_params p; const float* att; const float* hid; const float* d_out;
-    const float* drop; const float* d_att; int pad_idx; float* debd; float* d_feat; float* part;
+    const float* drop; const float* d_att; int pad_idx; float* debd; float* d_feat; float* ws_dpre; float* ws_dl; float* part;
     rbr_attn_grads g;
 };
 
@@ -98,6 +95,8 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
     const int pad_idx = SD.pad_idx;
     float* __restrict__ debd = SD.debd;
     float* __restrict__ d_feat = SD.d_feat;
+    float* __restrict__ ws_dpre = SD.ws_dpre;
+    float* __restrict__ ws_dl = SD.ws_dl;
     extern __shared__ float sm[];
     float* s_dpre = sm;            // [R*A]
     float* s_da = sm + R * A;      // [R] d(att)
@@ -126,6 +125,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         // att = e / (sum e + eps)  =>  d logit_r = att_r * (d att_r - sum_q d att_q * att_q)   (exact with eps)
         const float dl = ab[r] * (s_da[r] - S);
         s_dl[r] = dl;
+        ws_dl[(long)b * R + r] = dl;
     }
     __syncthreads();
     for (int idx = tid; idx < R * A; idx += 256) {
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         const float hv = hid[((long)b * R + r) * A + a];
         const float v = (hv > 0.f) ? s_dl[r] * p.h[a] : 0.f;
         s_dpre[idx] = v;
+        ws_dpre[((long)b * R + r) * A + a] = v;
     }
     __syncthreads();
     const bool vec = (A & 3) == 0 && ((((uintptr_t)p.W_rv) | ((uintptr_t)p.W_id)) & 15) == 0;     // rows of A floats as float4
@@ -168,41 +169,63 @@ __global__ __launch_bounds__(256) void attn_bwd_sample_kernel(int B, int R, int 
         }
         atomicAdd(debd + id * A + a2, s);
     }
-    // ---- this sample's share of the batch reductions (it was a launch of its own over chunks of 16 rows that re-read d_pre,
-    // d_logit, feat, hid and the embedding rows: everything but the last two is in LDS or L1 here).  One partial per sample,
-    // summed over the samples in order by attn_bwd_final_kernel: bitwise reproducible.
-    float* s_eb = s_dl + R;                 // [R][A] embedding rows
-    float* s_hd = s_eb + R * A;             // [R][A] hidden activations
-    for (int e = tid; e < R * A; e += 256) {
-        const int r = e / A;
-        s_eb[e] = p.ebd[oid[(long)b * R + r] * A + (e - r * A)];
-        s_hd[e] = hid[(long)b * R * A + e];
+}
+
+// reductions over the N = B*R rows in two stages, fixed partition and order (bitwise reproducible):
+//   stage 1: one workgroup per chunk of kRedRows rows stages d_pre / feat / embedding rows / hid / d_logit in LDS and writes the
+//            chunk's partial of every output;   stage 2: one thread per output sums the chunks in order.
+// output index: [0, H*A) dW_rv | [H*A, H*A + A*A) dW_id | + A db1 | + A dh | + 1 db2
+constexpr int kRedRows = 16;      // rows per chunk: B*R = 2560 rows give 160 workgroups (64-row chunks left 5/6 of the CUs idle)
+
+__device__ __forceinline__ int attn_n_out(int H, int A) { return H * A + A * A + 2 * A + 1; }
+
+__global__ __launch_bounds__(256) void attn_bwd_partial_kernel(int N, int H, int A, const AttnBwdSide side0, const AttnBwdSide side1) {
+    const AttnBwdSide& SD = blockIdx.y ? side1 : side0;
+    const float* __restrict__ feat = SD.feat;
+    const long long* __restrict__ oid = SD.oid;
+    const float* __restrict__ ebd = SD.p.ebd;
+    const float* __restrict__ hid = SD.hid;
+    const float* __restrict__ ws_dpre = SD.ws_dpre;
+    const float* __restrict__ ws_dl = SD.ws_dl;
+    float* __restrict__ part = SD.part;
+    extern __shared__ float sm[];
+    float* s_dp = sm;                       // [rows][A]
+    float* s_f = s_dp + kRedRows * A;       // [rows][H]
+    float* s_eb = s_f + kRedRows * H;       // [rows][A]
+    float* s_hd = s_eb + kRedRows * A;      // [rows][A]
+    float* s_dl = s_hd + kRedRows * A;      // [rows]
+    const int n0 = blockIdx.x * kRedRows, rows = min(kRedRows, N - n0), tid = threadIdx.x;
+    for (int e = tid; e < rows * A; e += 256) {
+        s_dp[e] = ws_dpre[(long)n0 * A + e];
+        s_hd[e] = hid[(long)n0 * A + e];
+        s_eb[e] = ebd[oid[n0 + e / A] * A + (e % A)];
     }
+    for (int e = tid; e < rows * H; e += 256) s_f[e] = feat[(long)n0 * H + e];
+    for (int e = tid; e < rows; e += 256) s_dl[e] = ws_dl[n0 + e];
     __syncthreads();
     const int n_out = attn_n_out(H, A);
-    float* my = SD.part + (long)b * n_out;
+    float* my = part + (long)blockIdx.x * n_out;
     for (int o = tid; o < n_out; o += 256) {
         float acc = 0.f;
         if (o < H * A) {
             const int hh = o / A, a = o - hh * A;
-            for (int n = 0; n < R; ++n) acc = fmaf(fb[(long)n * H + hh], s_dpre[n * A + a], acc);
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_f[n * H + hh], s_dp[n * A + a], acc);
         } else if (o < H * A + A * A) {
             const int q = o - H * A, a2 = q / A, a = q - a2 * A;
-            for (int n = 0; n < R; ++n) acc = fmaf(s_eb[n * A + a2], s_dpre[n * A + a], acc);
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_eb[n * A + a2], s_dp[n * A + a], acc);
         } else if (o < H * A + A * A + A) {
             const int a = o - H * A - A * A;
-            for (int n = 0; n < R; ++n) acc += s_dpre[n * A + a];
+            for (int n = 0; n < rows; ++n) acc += s_dp[n * A + a];
         } else if (o < H * A + A * A + 2 * A) {
             const int a = o - H * A - A * A - A;
-            for (int n = 0; n < R; ++n) acc = fmaf(s_dl[n], s_hd[n * A + a], acc);
+            for (int n = 0; n < rows; ++n) acc = fmaf(s_dl[n], s_hd[n * A + a], acc);
         } else {
-            for (int n = 0; n < R; ++n) acc += s_dl[n];
+            for (int n = 0; n < rows; ++n) acc += s_dl[n];
         }
         my[o] = acc;
     }
 }
 
-// the batch reductions' second stage: one thread per output sums the samples' partials in order
 __global__ __launch_bounds__(256) void attn_bwd_final_kernel(int n_chunks, int H, int A, const AttnBwdSide side0,
                                                              const AttnBwdSide side1) {
     const AttnBwdSide& SD = blockIdx.y ? side1 : side0;
@@ -234,7 +257,8 @@ using namespace rbr;
 
 static bool attn_args_ok(int B, int R, int H, int A) {
     if (B <= 0 || R <= 0 || H <= 0 || A <= 0) { set_error("bad attention shape B=%d R=%d H=%d A=%d", B, R, H, A); return false; }
-    if ((size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float) > 64 * 1024 || (size_t)(3 * R * A + 2 * R) * sizeof(float) > 64 * 1024) {
+    if ((size_t)(2 * R * A + R + R * H + H * A + A * A) * sizeof(float) > 64 * 1024 ||
+        (size_t)kRedRows * (3 * A + H + 1) * sizeof(float) > 64 * 1024) {
         set_error("R=%d H=%d A=%d too large for the LDS tiles", R, H, A);
         return false;
     }
@@ -271,15 +295,19 @@ extern "C" int rbr_review_attn2_fwd(int32_t B, int32_t R, int32_t H, int32_t A, 
 
 extern "C" size_t rbr_review_attn_bwd_ws_floats(int32_t B, int32_t R, int32_t H, int32_t A) {
     if (B <= 0 || R <= 0 || H <= 0 || A <= 0) return 0;
-    return (size_t)B * ((size_t)H * A + (size_t)A * A + 2 * (size_t)A + 1);      // a partial of the batch reductions per sample
+    const size_t chunks = ((size_t)B * R + kRedRows - 1) / kRedRows;
+    return (size_t)B * R * A + (size_t)B * R + chunks * ((size_t)H * A + (size_t)A * A + 2 * (size_t)A + 1);
 }
 
-// the two stages of the backward for `sides` (1 or 2) sides
+// the three stages of the backward for `sides` (1 or 2) sides
 static int attn_bwd_launch(int B, int R, int H, int A, const AttnBwdSide& S0, const AttnBwdSide& S1, int sides, hipStream_t st) {
-    hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B, sides), dim3(256), (size_t)(3 * R * A + 2 * R) * sizeof(float), st, B, R, H, A, S0, S1);
+    hipLaunchKernelGGL(attn_bwd_sample_kernel, dim3(B, sides), dim3(256), (size_t)(R * A + 2 * R) * sizeof(float), st, B, R, H, A, S0, S1);
     RBR_CHECK_LAUNCH("review_attn_bwd sample launch");
-    const int n_out = H * A + A * A + 2 * A + 1;
-    hipLaunchKernelGGL(attn_bwd_final_kernel, dim3((n_out + 255) / 256, sides), dim3(256), 0, st, B, H, A, S0, S1);
+    const int N = B * R, chunks = (N + kRedRows - 1) / kRedRows, n_out = H * A + A * A + 2 * A + 1;
+    hipLaunchKernelGGL(attn_bwd_partial_kernel, dim3(chunks, sides), dim3(256), (size_t)kRedRows * (3 * A + H + 1) * sizeof(float), st, N,
+                       H, A, S0, S1);
+    RBR_CHECK_LAUNCH("review_attn_bwd partial launch");
+    hipLaunchKernelGGL(attn_bwd_final_kernel, dim3((n_out + 255) / 256, sides), dim3(256), 0, st, chunks, H, A, S0, S1);
     RBR_CHECK_LAUNCH("review_attn_bwd final launch");
     return 0;
 }
@@ -290,7 +318,7 @@ static AttnBwdSide attn_bwd_side(int B, int R, int A, const float* feat, const l
     AttnBwdSide S{};
     S.feat = feat; S.oid = oid; S.p = p; S.att = att; S.hid = hid; S.d_out = d_out; S.drop = drop; S.d_att = d_att;
     S.pad_idx = pad_idx; S.debd = g.debd; S.d_feat = d_feat; S.g = g;
-    S.part = ws;
+    S.ws_dpre = ws; S.ws_dl = ws + (size_t)B * R * A; S.part = S.ws_dl + (size_t)B * R;
     return S;
 }
 
