@@ -1050,9 +1050,9 @@ __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int c
             ph[q] = a; pm[q] = b; pl[q] = cc;
         }
         *reinterpret_cast<u32x4*>(&dst[0][c][wchunk]) = ph;
-        if (NPL == 3) {
-            *reinterpret_cast<u32x4*>(&dst[NPL - 2][c][wchunk]) = pm;
-            *reinterpret_cast<u32x4*>(&dst[NPL - 1][c][wchunk]) = pl;
+        if constexpr (NPL == 3) {
+            *reinterpret_cast<u32x4*>(&dst[1][c][wchunk]) = pm;
+            *reinterpret_cast<u32x4*>(&dst[2][c][wchunk]) = pl;
         }
     };
     const int am = wm * 32 + i, bn = wn * 32 + i;
@@ -1063,11 +1063,11 @@ __global__ __launch_bounds__(256) void dw_from_g_b16_kernel(int KG, int D, int c
             const int ca = ((2 * s2 + h) ^ aswz) * 16, cb = ((2 * s2 + h) ^ bswz) * 16;
             const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&As[0][am][ca]);
             const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(&Bs[0][bn][cb]);
-            if (NPL == 3) {
-                const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(&As[NPL - 2][am][ca]);
-                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][am][ca]);
-                const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 2][bn][cb]);
-                const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][bn][cb]);
+            if constexpr (NPL == 3) {
+                const bf16x8 a_mid = *reinterpret_cast<const bf16x8*>(&As[1][am][ca]);
+                const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&As[2][am][ca]);
+                const bf16x8 b_mid = *reinterpret_cast<const bf16x8*>(&Bs[1][bn][cb]);
+                const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(&Bs[2][bn][cb]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc, 0, 0, 0);      // small terms first, as the forward
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_mid, acc, 0, 0, 0);
