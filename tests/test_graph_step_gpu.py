@@ -130,7 +130,10 @@ def test_capture_guard_refuses_an_op_on_a_stream_nobody_forked():
     from review_based_recommender_amd import _lib, functional as RF
     x = torch.randn(64, device="cuda:0")
     y = torch.randn(64, device="cuda:0")
-    cs, other = torch.cuda.Stream(), torch.cuda.Stream()
+    cs = torch.cuda.Stream()
+    # torch hands out streams from a pool: one that an earlier test's side stream was drawn from is a forked stream to the guard
+    other = next(st for st in (torch.cuda.Stream() for _ in range(64))
+                 if st.cuda_stream != cs.cuda_stream and st.cuda_stream not in _lib.FORKED_STREAMS)
     torch.cuda.synchronize()
     with _lib.capture_guard(cs):
         with torch.cuda.stream(cs):
