@@ -201,6 +201,43 @@ def test_linear_split_along_k_matches_torch_and_is_reproducible(N, IN, OUT, act)
         assert float((got.double().cpu() - r).abs().max()) <= 2e-5 * max(1.0, scale), (tuple(r.shape), scale)
 
 
+@pytest.mark.parametrize("want_dx,want_db", [(True, True), (False, True), (True, False), (False, False)])
+def test_linear_backward_ex_without_input_or_bias_gradient(want_dx, want_db):
+    """rbr_linear_bwd_ex through the C ABI with d_x and / or db NULL: the weight gradient alone is one product (gemm_kernel), with the
+    input gradient both are one launch (gemm2_kernel); their reductions and the bias column sums share the second launch
+    (gemm_reduce2_kernel).  Every combination against torch in float64; what was not asked for is not written."""
+    from review_based_recommender_amd import _lib
+    from review_based_recommender_amd._lib import dev_ptr
+    L_ = _lib.lib()
+    N, IN, OUT = 1024, 500, 50                                   # D-ATT's second fc layer: dW split along K, d_x not
+    g = torch.Generator().manual_seed(3)
+    x, W = torch.randn(N, IN, generator=g), torch.randn(OUT, IN, generator=g) / np.sqrt(IN)
+    d_y = torch.randn(N, OUT, generator=g)
+    y = x @ W.t()
+    xd, Wd, yd, dyd = (t.to(DEV) for t in (x, W, y, d_y))
+    F32 = torch.float32
+    dW = torch.full((OUT, IN), 7.0, device=DEV)
+    d_x = torch.full((N, IN), 7.0, device=DEV)
+    db = torch.full((OUT,), 7.0, device=DEV)
+    ws = torch.empty(L_.rbr_linear_bwd_ex_ws_floats(N, IN, OUT), device=DEV)
+    rc = L_.rbr_linear_bwd_ex(N, IN, OUT, dev_ptr(xd, F32, "x"), dev_ptr(Wd, F32, "W"), dev_ptr(yd, F32, "y"), dev_ptr(dyd, F32, "d_y"), 0,
+                              None, dev_ptr(d_x, F32, "d_x") if want_dx else None, dev_ptr(dW, F32, "dW"),
+                              dev_ptr(db, F32, "db") if want_db else None, dev_ptr(ws, F32, "ws"), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L_.rbr_last_error()
+    torch.cuda.synchronize()
+    ref_dW = d_y.double().t() @ x.double()
+    assert float((dW.double().cpu() - ref_dW).abs().max()) <= 2e-5 * float(ref_dW.abs().max())
+    if want_dx:
+        ref_dx = d_y.double() @ W.double()
+        assert float((d_x.double().cpu() - ref_dx).abs().max()) <= 2e-5 * float(ref_dx.abs().max())
+    else:
+        assert float((d_x - 7.0).abs().max()) == 0.0
+    if want_db:
+        assert float((db.double().cpu() - d_y.double().sum(0)).abs().max()) <= 1e-4
+    else:
+        assert float((db - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n", [1, 7, 256, 1000, 70001])
 def test_mse_loss_matches_torch(n):
     """rbr_mse_loss_fwd/_bwd vs nn.MSELoss (train_deepconn_pp.py:137,164): loss, d_pred, and a non-unit upstream gradient."""
