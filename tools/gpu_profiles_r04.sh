@@ -34,14 +34,14 @@ for m in narre datt; do
   rm -rf $O/ks_$m
 done
 # 6. D-ATT: HBM / L2 counters of its long kernels (eager step)
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   n=$(echo $c | tr ' ' '_'); rm -rf $O/dpmc_$n
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/dpmc_$n -o r -- python3 tools/bench_models.py datt --no-graph > $O/dpmc_$n.log 2>&1
 done
 for k in gather_pool g_times_w prod_gemm_b16k_kernel gg_rows global_gate_fwd; do
-  python tools/pmc_summary.py $k $O/r04_datt_${k}_pmc.json $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum > /dev/null 2>&1 || echo "datt pmc summary $k failed"
+  python tools/pmc_summary.py $k $O/r04_datt_${k}_pmc.json $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum $O/dpmc_GRBM_GUI_ACTIVE_SQ_BUSY_CYCLES_SQ_VALU_MFMA_BUSY_CYCLES_SQ_WAVE_CYCLES > /dev/null 2>&1 || echo "datt pmc summary $k failed"
 done
-rm -rf $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum
+rm -rf $O/dpmc_FETCH_SIZE $O/dpmc_WRITE_SIZE $O/dpmc_TCC_HIT_sum_TCC_MISS_sum $O/dpmc_GRBM_GUI_ACTIVE_SQ_BUSY_CYCLES_SQ_VALU_MFMA_BUSY_CYCLES_SQ_WAVE_CYCLES
 ls -la $O | head -50
 for f in $O/r04_bench_line_bf16.json $O/r04_narre_bench_line.json $O/r04_narre_bf16_bench_line.json $O/r04_datt_bench_line.json $O/r04_siamese_bench_line.json; do echo "--- $f"; cut -c1-300 $f; done
 exit 0
