@@ -138,3 +138,27 @@ def test_pair_region_refuses_entry_points_that_launch_directly():
     assert L_.rbr_pair_end(None, None) != 0                  # nothing open any more
     assert L_.rbr_embedding_fwd(4, 8, ids.data_ptr(), x.data_ptr(), out.data_ptr(), st) == 0
     torch.cuda.synchronize()
+
+
+def test_paired_step_with_a_frozen_word_table():
+    """freeze_embeddings (reference dual_att/layers.py:11-14): no table gradient is wanted -- the paired backward then skips the
+    sparse products and the gates' table rows (two regions, two streams, no gradient buffers) and every other gradient must be
+    the unfrozen step's to summation order."""
+    from review_based_recommender_amd import functional as RF
+    grads = []
+    for frozen in (False, True):
+        m = _model(MID)
+        m.train()
+        m.word_embeddings.embedding.weight.requires_grad_(not frozen)
+        b = synth.datt_batch(MID, 1)
+        with _paired(True):
+            pred = m(b["u_docs"].to(DEV), b["i_docs"].to(DEV))
+            assert RF.PAIR_STATS["paired"] > 0                       # the paired path ran
+            torch.nn.functional.mse_loss(pred, b["ratings"].to(DEV)).backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert "word_embeddings.embedding.weight" in grads[0] and "word_embeddings.embedding.weight" not in grads[1]
+    assert len(grads[1]) == len(grads[0]) - 1
+    for k, g in grads[1].items():
+        ref = grads[0][k]
+        assert float((g - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-12, k
