@@ -1023,9 +1023,15 @@ def main():
         if world == 1 and not a.no_configs:
             stepper = None                      # the headline's graphs and their memory pools are not needed any more
             torch.cuda.empty_cache()
-            out["configs"] = secondary_configs(device, a, precision)
+            try:
+                out["configs"] = secondary_configs(device, a, precision)
+            except Exception as e:          # the secondary configurations must not cost the headline's line
+                out["configs"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_budget)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
